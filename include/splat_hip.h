@@ -1,0 +1,170 @@
+/*
+ * splat_hip.h -- C ABI of libsplat_hip.so, the MI355X (gfx950) drop-in for the native half of the
+ * Splat-SLAM mapping hot path.  Torch-free: plain device pointers, sizes and a stream handle.
+ *
+ * Which reference interface each entry point replaces (paths relative to /root/reference):
+ *
+ *   sgr_forward            -> diff_gaussian_rasterization._C.rasterize_gaussians, reached through
+ *                             GaussianRasterizer.forward at
+ *                             thirdparty/gaussian_splatting/gaussian_renderer/__init__.py:130-141
+ *                             (settings built at :58-72).  The native source is the un-vendored submodule
+ *                             thirdparty/diff-gaussian-rasterization-w-pose (.gitmodules:4-6, README.md:88-92).
+ *   sgr_backward           -> diff_gaussian_rasterization._C.rasterize_gaussians_backward, triggered by
+ *                             loss.backward() at src/mapper.py:329,490,699.
+ *   sgr_saved_bytes,
+ *   sgr_scratch_bytes      -> the resizeFunctional geom/binning/image buffer callbacks of the same module.
+ *   sgr_mapping_loss       -> get_loss_mapping / get_loss_mapping_rgbd, thirdparty/monogs/utils/slam_utils.py:71-105
+ *   sgr_adam_step          -> torch.optim.Adam(eps=1e-15) over the GaussianModel groups,
+ *                             thirdparty/gaussian_splatting/scene/gaussian_model.py:264-313, stepped at
+ *                             src/mapper.py:352,557,703
+ *   sknn_dist2             -> simple_knn._C.distCUDA2, thirdparty/gaussian_splatting/scene/gaussian_model.py:18,194-200
+ *   se3_*                  -> lietorch SE3 ops used on the mapping path, thirdparty/glorie_slam/depth_video.py:327-330
+ *                             (SE3(pose).inv().matrix()), and the tau convention of
+ *                             thirdparty/monogs/utils/pose_utils.py:66-98.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 / int32 unless it says "host";
+ *   - [N,C] arrays are row-major; images are CHW; 4x4 matrices are 16 floats in the layout the reference
+ *     passes them (transposed / row-vector convention: camera_utils.py:94-104, mapper.py:841-850);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it;
+ *   - functions return 0 on success, a negative SgrStatus otherwise; sgr_last_error() gives the text;
+ *   - the library never allocates device memory: the caller owns inputs, outputs and both workspaces.
+ */
+#ifndef SPLAT_HIP_H_
+#define SPLAT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGR_ABI_VERSION 1
+
+typedef enum SgrStatus {
+  SGR_OK = 0,
+  SGR_ERR_INVALID = -1,     /* bad argument (null pointer, inconsistent option set, ...)            */
+  SGR_ERR_WORKSPACE = -2,   /* saved / scratch workspace smaller than sgr_*_bytes() demands          */
+  SGR_ERR_CAPACITY = -3,    /* more (tile, Gaussian) pairs than `capacity`; *num_rendered_host = need */
+  SGR_ERR_HIP = -4          /* a HIP runtime call failed                                              */
+} SgrStatus;
+
+/* The 13 fields of GaussianRasterizationSettings (gaussian_renderer/__init__.py:58-72) + array extents. */
+typedef struct SgrSettings {
+  int32_t num_gaussians;       /* N */
+  int32_t image_height;
+  int32_t image_width;
+  int32_t sh_degree;           /* active degree (0..3) */
+  int32_t sh_coeffs;           /* M: `shs` is [N, M, 3]; ignored when colors_precomp is given */
+  float tanfovx;
+  float tanfovy;
+  float scale_modifier;
+  int32_t prefiltered;
+  int32_t debug;
+  const float* bg;             /* [3]  */
+  const float* viewmatrix;     /* [16] world_view_transform  (W2C transposed) */
+  const float* projmatrix;     /* [16] full_proj_transform   */
+  const float* projmatrix_raw; /* [16] projection_matrix     */
+  const float* campos;         /* [3]  */
+} SgrSettings;
+
+/* Arguments of GaussianRasterizer.forward (gaussian_renderer/__init__.py:130-141). NULL = "None". */
+typedef struct SgrInputs {
+  const float* means3D;        /* [N,3] */
+  const float* opacities;      /* [N]   */
+  const float* shs;            /* [N,M,3] or NULL */
+  const float* colors_precomp; /* [N,3]   or NULL */
+  const float* scales;         /* [N,3]   or NULL */
+  const float* rotations;      /* [N,4]   or NULL (w,x,y,z; used as given, not re-normalised) */
+  const float* cov3D_precomp;  /* [N,6]   or NULL */
+} SgrInputs;
+
+/* The 5-tuple returned at gaussian_renderer/__init__.py:130. */
+typedef struct SgrOutputs {
+  float* color;                /* [3,H,W] */
+  float* depth;                /* [1,H,W] */
+  float* opacity;              /* [1,H,W] */
+  int32_t* radii;              /* [N] */
+  int32_t* n_touched;          /* [N] */
+} SgrOutputs;
+
+typedef struct SgrWorkspace {
+  void* saved;                 /* lives from forward until the matching backward (one per forward call) */
+  size_t saved_bytes;
+  void* scratch;               /* transient inside one call; may be shared by calls on the same stream   */
+  size_t scratch_bytes;
+  int64_t capacity;            /* max (tile, Gaussian) pairs the workspaces were sized for               */
+} SgrWorkspace;
+
+typedef struct SgrGradOutputs {
+  const float* dL_dcolor;      /* [3,H,W] */
+  const float* dL_ddepth;      /* [1,H,W] or NULL (= zeros) */
+} SgrGradOutputs;
+
+/* Every pointer may be NULL when the caller does not need that gradient. Written, not accumulated. */
+typedef struct SgrGradInputs {
+  float* dL_dmeans3D;          /* [N,3] */
+  float* dL_dmeans2D;          /* [N,3]  (x,y in NDC-scaled pixel units, z = 0) */
+  float* dL_dopacities;        /* [N]   */
+  float* dL_dshs;              /* [N,M,3] */
+  float* dL_dcolors_precomp;   /* [N,3] */
+  float* dL_dscales;           /* [N,3] */
+  float* dL_drotations;        /* [N,4] */
+  float* dL_dcov3D_precomp;    /* [N,6] */
+  float* dL_dtau;              /* [6] = (rho[3], theta[3]) summed over Gaussians */
+} SgrGradInputs;
+
+int sgr_abi_version(void);
+const char* sgr_last_error(void);
+
+size_t sgr_saved_bytes(int32_t num_gaussians, int32_t image_height, int32_t image_width, int64_t capacity);
+size_t sgr_scratch_bytes(int32_t num_gaussians, int32_t image_height, int32_t image_width, int64_t capacity);
+
+/* num_rendered_host: host pointer or NULL.
+ *   non-NULL: the call synchronises once on `stream` to learn the pair count R, sorts exactly R pairs, stores R
+ *             there, and fails with SGR_ERR_CAPACITY (outputs untouched) when R > ws->capacity;
+ *   NULL    : fully asynchronous; pairs beyond ws->capacity are dropped and the overflow word of the saved
+ *             block is raised -- poll it with sgr_query(). */
+int sgr_forward(const SgrSettings* settings, const SgrInputs* in, const SgrOutputs* out,
+                const SgrWorkspace* ws, int64_t* num_rendered_host, void* stream);
+
+int sgr_backward(const SgrSettings* settings, const SgrInputs* in, const int32_t* radii,
+                 const SgrGradOutputs* grad_out, const SgrGradInputs* grad_in,
+                 const SgrWorkspace* ws, void* stream);
+
+/* Synchronous read-back of (pair count, overflow flag) from a saved block produced by sgr_forward. */
+int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_host, void* stream);
+
+/* Fused mapping loss (slam_utils.py:71-105): loss = alpha*mean|m*(e^a*I+b) - m*gt| + (1-alpha)*mean|md*D - md*gtD|
+ * with m = (sum_c gt > rgb_boundary_threshold), md = (gtD > 0.01).  Writes loss[1] and the four gradients
+ * scaled by `upstream` (dLoss/dloss).  exposure may be NULL (initialization=True branch, :72-73). */
+int sgr_mapping_loss(int32_t H, int32_t W, const float* image, const float* depth,
+                     const float* gt_image, const float* gt_depth,
+                     const float* exposure_a, const float* exposure_b,
+                     float alpha, float rgb_boundary_threshold, float upstream,
+                     float* loss, float* dL_dimage, float* dL_ddepth, float* dL_dexp_a, float* dL_dexp_b,
+                     void* scratch, size_t scratch_bytes, void* stream);
+
+/* One torch.optim.Adam step (no weight decay, no amsgrad) on a flat parameter slab. step = the value AFTER
+ * increment (1 on the first call).  lr may differ per call (update_learning_rate, gaussian_model.py:315-329). */
+int sgr_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
+/* simple_knn distCUDA2: mean squared distance to the 3 nearest neighbours (self excluded). */
+size_t sknn_scratch_bytes(int32_t n);
+int sknn_dist2(const float* xyz, int32_t n, float* mean_dist2, void* scratch, size_t scratch_bytes, void* stream);
+
+/* SE3 ops, batched over n.  Pose = (tx,ty,tz,qx,qy,qz,qw) as in lietorch / depth_video.py:69; tau = (rho, theta). */
+int se3_exp(const float* tau, int64_t n, float* pose_out, void* stream);
+int se3_log(const float* pose, int64_t n, float* tau_out, void* stream);
+int se3_inv(const float* pose, int64_t n, float* pose_out, void* stream);
+int se3_mul(const float* pose_a, const float* pose_b, int64_t n, float* pose_out, void* stream);
+int se3_act(const float* pose, const float* pts, int64_t n, float* pts_out, void* stream);
+int se3_adjT(const float* pose, const float* a, int64_t n, float* out, void* stream);
+int se3_matrix(const float* pose, int64_t n, float* mat_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLAT_HIP_H_ */

@@ -1,0 +1,107 @@
+"""ctypes binding of libsplat_hip.so (C ABI declared in include/splat_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or cannot be loaded the import of the
+product path fails with a clear error (a silent CPU path would void every parity claim).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsplat_hip.so")
+
+SGR_OK, SGR_ERR_INVALID, SGR_ERR_WORKSPACE, SGR_ERR_CAPACITY, SGR_ERR_HIP = 0, -1, -2, -3, -4
+
+_fp = C.c_void_p
+
+
+class SgrSettings(C.Structure):
+    _fields_ = [("num_gaussians", C.c_int32), ("image_height", C.c_int32), ("image_width", C.c_int32),
+                ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("bg", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("projmatrix_raw", _fp), ("campos", _fp)]
+
+
+class SgrInputs(C.Structure):
+    _fields_ = [("means3D", _fp), ("opacities", _fp), ("shs", _fp), ("colors_precomp", _fp), ("scales", _fp),
+                ("rotations", _fp), ("cov3D_precomp", _fp)]
+
+
+class SgrOutputs(C.Structure):
+    _fields_ = [("color", _fp), ("depth", _fp), ("opacity", _fp), ("radii", _fp), ("n_touched", _fp)]
+
+
+class SgrWorkspace(C.Structure):
+    _fields_ = [("saved", _fp), ("saved_bytes", C.c_size_t), ("scratch", _fp), ("scratch_bytes", C.c_size_t),
+                ("capacity", C.c_int64)]
+
+
+class SgrGradOutputs(C.Structure):
+    _fields_ = [("dL_dcolor", _fp), ("dL_ddepth", _fp)]
+
+
+class SgrGradInputs(C.Structure):
+    _fields_ = [("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dopacities", _fp), ("dL_dshs", _fp),
+                ("dL_dcolors_precomp", _fp), ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_dcov3D_precomp", _fp),
+                ("dL_dtau", _fp)]
+
+
+# name -> (restype, argtypes); must list every symbol include/splat_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "sgr_abi_version": (C.c_int, []),
+    "sgr_last_error": (C.c_char_p, []),
+    "sgr_saved_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    "sgr_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    "sgr_forward": (C.c_int, [C.POINTER(SgrSettings), C.POINTER(SgrInputs), C.POINTER(SgrOutputs),
+                              C.POINTER(SgrWorkspace), C.POINTER(C.c_int64), _fp]),
+    "sgr_backward": (C.c_int, [C.POINTER(SgrSettings), C.POINTER(SgrInputs), _fp, C.POINTER(SgrGradOutputs),
+                               C.POINTER(SgrGradInputs), C.POINTER(SgrWorkspace), _fp]),
+    "sgr_query": (C.c_int, [_fp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _fp]),
+    "sgr_mapping_loss": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float,
+                                   C.c_float, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "sgr_adam_step": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_int64, _fp]),
+    "sknn_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "sknn_dist2": (C.c_int, [_fp, C.c_int32, _fp, _fp, C.c_size_t, _fp]),
+    "se3_exp": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
+    "se3_log": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
+    "se3_inv": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
+    "se3_mul": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp]),
+    "se3_act": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp]),
+    "se3_adjT": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp]),
+    "se3_matrix": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads (once) and returns the ctypes handle.  Raises, never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). splat_slam_amd has no CPU fallback by design.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        if h.sgr_abi_version() != 1:
+            raise ImportError("libsplat_hip.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def last_error():
+    return lib().sgr_last_error().decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,340 @@
+// The smaller C-ABI entry points around the rasterizer (include/splat_hip.h):
+//   sgr_mapping_loss  fused fwd+bwd of get_loss_mapping        /root/reference/thirdparty/monogs/utils/slam_utils.py:71-105
+//   sgr_adam_step     torch.optim.Adam step on a flat slab     /root/reference/thirdparty/gaussian_splatting/scene/gaussian_model.py:264-313
+//   sknn_dist2        simple_knn distCUDA2                     /root/reference/thirdparty/gaussian_splatting/scene/gaussian_model.py:194-200
+//   se3_*             lietorch SE3 ops of the mapping path     /root/reference/thirdparty/glorie_slam/depth_video.py:327-330
+// All are HBM-streaming or tiny; each is a single pass with fixed-order reductions (bitwise reproducible).
+#include <cmath>
+
+#include "sgr_common.h"
+
+namespace sgr {
+int set_error(int code, const char* fmt, ...);
+
+// ------------------------------------------------------------------------------------------------ mapping loss
+struct LossPart { float rgb, dep, da, db; };
+
+__global__ void __launch_bounds__(256) mapping_loss_kernel(
+    int HW, const float* __restrict__ image, const float* __restrict__ depth, const float* __restrict__ gt_image,
+    const float* __restrict__ gt_depth, const float* __restrict__ exp_a, const float* __restrict__ exp_b, float w_rgb,
+    float w_dep, float thr, float* __restrict__ dimage, float* __restrict__ ddepth, LossPart* __restrict__ parts) {
+  const float ea = exp_a ? __expf(exp_a[0]) : 1.f;
+  const float eb = exp_b ? exp_b[0] : 0.f;
+  LossPart acc = {0.f, 0.f, 0.f, 0.f};
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    float g0 = gt_image[p], g1 = gt_image[HW + p], g2 = gt_image[2 * HW + p];
+    bool m = (g0 + g1 + g2) > thr;
+    float gt[3] = {g0, g1, g2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float I = image[c * HW + p];
+      float r = m ? (ea * I + eb) - gt[c] : 0.f;
+      acc.rgb += fabsf(r);
+      float sgn = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+      float dab = w_rgb * sgn;            // dL/d(image_ab)
+      if (dimage) dimage[c * HW + p] = dab * ea;
+      acc.da += dab * ea * I;
+      acc.db += dab;
+    }
+    float gd = gt_depth[p];
+    bool md = gd > 0.01f;
+    float rd = md ? depth[p] - gd : 0.f;
+    acc.dep += fabsf(rd);
+    if (ddepth) ddepth[p] = w_dep * ((rd > 0.f) ? 1.f : ((rd < 0.f) ? -1.f : 0.f));
+  }
+  __shared__ LossPart red[4];
+  float v[4] = {acc.rgb, acc.dep, acc.da, acc.db};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) red[wv] = {v[0], v[1], v[2], v[3]};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    LossPart t = red[0];
+    for (int w = 1; w < 4; ++w) { t.rgb += red[w].rgb; t.dep += red[w].dep; t.da += red[w].da; t.db += red[w].db; }
+    parts[blockIdx.x] = t;
+  }
+}
+
+__global__ void mapping_loss_final_kernel(int nparts, const LossPart* __restrict__ parts, float inv_rgb, float inv_dep,
+                                          float alpha, float* __restrict__ loss, float* __restrict__ da,
+                                          float* __restrict__ db) {
+  __shared__ LossPart red[64];
+  int lane = threadIdx.x;
+  LossPart t = {0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < nparts; i += 64) { t.rgb += parts[i].rgb; t.dep += parts[i].dep; t.da += parts[i].da; t.db += parts[i].db; }
+  red[lane] = t;
+  __syncthreads();
+  if (lane == 0) {
+    LossPart s = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 64; ++i) { s.rgb += red[i].rgb; s.dep += red[i].dep; s.da += red[i].da; s.db += red[i].db; }
+    if (loss) loss[0] = alpha * (s.rgb * inv_rgb) + (1.f - alpha) * (s.dep * inv_dep);
+    if (da) da[0] = s.da;
+    if (db) db[0] = s.db;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ void __launch_bounds__(256) adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float b1, float b2,
+                                                   float eps, float step_size, float bc2_sqrt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - b1);                 // lerp_
+    vi = vi * b2 + (1.f - b2) * gi * gi;              // mul_ + addcmul_
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 3-NN
+struct Top3 { float a, b, c; };
+__device__ __forceinline__ void top3_push(Top3& t, float d) {
+  if (d < t.c) {
+    if (d < t.b) {
+      t.c = t.b;
+      if (d < t.a) { t.b = t.a; t.a = d; } else { t.b = d; }
+    } else {
+      t.c = d;
+    }
+  }
+}
+
+// grid = (query blocks, splits): each block scans one slice of the candidates through LDS for 256 queries
+__global__ void __launch_bounds__(256) knn_partial_kernel(int n, const float* __restrict__ xyz, int per_split,
+                                                          Top3* __restrict__ part) {
+  __shared__ float sx[256], sy[256], sz[256];
+  int i = blockIdx.x * 256 + threadIdx.x;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (i < n) { qx = xyz[3 * i]; qy = xyz[3 * i + 1]; qz = xyz[3 * i + 2]; }
+  Top3 best = {INFINITY, INFINITY, INFINITY};
+  int j0 = blockIdx.y * per_split, j1 = min(n, j0 + per_split);
+  for (int base = j0; base < j1; base += 256) {
+    int j = base + threadIdx.x;
+    if (j < j1) { sx[threadIdx.x] = xyz[3 * j]; sy[threadIdx.x] = xyz[3 * j + 1]; sz[threadIdx.x] = xyz[3 * j + 2]; }
+    __syncthreads();
+    int cnt = min(256, j1 - base);
+    for (int k = 0; k < cnt; ++k) {
+      float dx = sx[k] - qx, dy = sy[k] - qy, dz = sz[k] - qz;
+      float d = dx * dx + dy * dy + dz * dz;
+      if (base + k != i) top3_push(best, d);
+    }
+    __syncthreads();
+  }
+  if (i < n) part[(size_t)blockIdx.y * n + i] = best;
+}
+
+__global__ void __launch_bounds__(256) knn_merge_kernel(int n, int splits, const Top3* __restrict__ part,
+                                                        float* __restrict__ out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Top3 best = {INFINITY, INFINITY, INFINITY};
+  for (int s = 0; s < splits; ++s) {
+    Top3 t = part[(size_t)s * n + i];
+    top3_push(best, t.a); top3_push(best, t.b); top3_push(best, t.c);
+  }
+  // fewer than 4 points: missing neighbours count as 0 like an unfilled best-list would not -- keep finite
+  float a = isinf(best.a) ? 0.f : best.a, b = isinf(best.b) ? 0.f : best.b, c = isinf(best.c) ? 0.f : best.c;
+  out[i] = (a + b + c) / 3.f;
+}
+
+static int knn_splits(int n) {
+  int qb = (n + 255) / 256;
+  int s = (2048 + qb - 1) / qb;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  int max_s = (n + 255) / 256;      // at least one 256-chunk per split
+  if (s > max_s) s = max_s;
+  return s < 1 ? 1 : s;
+}
+
+// ------------------------------------------------------------------------------------------------ SE3
+struct Pose { float t[3]; float q[4]; };   // q = (x, y, z, w)
+__device__ __forceinline__ Pose load_pose(const float* p) { return {{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}}; }
+__device__ __forceinline__ void store_pose(float* p, const Pose& a) {
+  p[0] = a.t[0]; p[1] = a.t[1]; p[2] = a.t[2]; p[3] = a.q[0]; p[4] = a.q[1]; p[5] = a.q[2]; p[6] = a.q[3];
+}
+__device__ __forceinline__ void quat_rotate(const float q[4], const float v[3], float out[3]) {
+  // v + 2w (u x v) + 2 u x (u x v),  u = (x,y,z)
+  float ux = q[0], uy = q[1], uz = q[2], w = q[3];
+  float cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+  float dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+  out[0] = v[0] + 2.f * (w * cx + dx);
+  out[1] = v[1] + 2.f * (w * cy + dy);
+  out[2] = v[2] + 2.f * (w * cz + dz);
+}
+__device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float o[4]) {
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+enum Se3Op { OP_EXP, OP_LOG, OP_INV, OP_MUL, OP_ACT, OP_ADJT, OP_MATRIX };
+
+template <int OP>
+__global__ void __launch_bounds__(256) se3_kernel(int64_t n, const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (OP == OP_EXP) {
+    const float* tau = a + 6 * i;
+    float rho[3] = {tau[0], tau[1], tau[2]}, th[3] = {tau[3], tau[4], tau[5]};
+    float t2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+    float ang = sqrtf(t2);
+    float A, Bc, Cc, imag, real;   // sin(a)/a, (1-cos a)/a^2, (a - sin a)/a^3, sin(a/2)/a, cos(a/2)
+    if (ang < 1e-4f) {
+      A = 1.f - t2 / 6.f; Bc = 0.5f - t2 / 24.f; Cc = 1.f / 6.f - t2 / 120.f;
+      imag = 0.5f - t2 / 48.f; real = 1.f - t2 / 8.f;
+    } else {
+      float s = sinf(ang), c = cosf(ang);
+      A = s / ang; Bc = (1.f - c) / t2; Cc = (ang - s) / (t2 * ang);
+      imag = sinf(0.5f * ang) / ang; real = cosf(0.5f * ang);
+    }
+    (void)A;
+    // t = V rho,  V = I + B [th]x + C [th]x^2
+    float c1[3] = {th[1] * rho[2] - th[2] * rho[1], th[2] * rho[0] - th[0] * rho[2], th[0] * rho[1] - th[1] * rho[0]};
+    float c2[3] = {th[1] * c1[2] - th[2] * c1[1], th[2] * c1[0] - th[0] * c1[2], th[0] * c1[1] - th[1] * c1[0]};
+    Pose p;
+    for (int k = 0; k < 3; ++k) p.t[k] = rho[k] + Bc * c1[k] + Cc * c2[k];
+    p.q[0] = imag * th[0]; p.q[1] = imag * th[1]; p.q[2] = imag * th[2]; p.q[3] = real;
+    store_pose(out + 7 * i, p);
+  } else if (OP == OP_LOG) {
+    Pose p = load_pose(a + 7 * i);
+    float n2 = p.q[0] * p.q[0] + p.q[1] * p.q[1] + p.q[2] * p.q[2];
+    float nn = sqrtf(n2), w = p.q[3];
+    float k;   // theta = k * (x,y,z)
+    if (nn < 1e-6f) {
+      k = 2.f / w - 2.f * n2 / (3.f * w * w * w);
+    } else {
+      // atan(n/w) with the branch that keeps the angle in (-pi, pi]
+      float half = (fabsf(w) < 1e-12f) ? (w >= 0.f ? 1.f : -1.f) * 1.57079632679f : atanf(nn / w);
+      k = 2.f * half / nn;
+    }
+    float th[3] = {k * p.q[0], k * p.q[1], k * p.q[2]};
+    float t2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2], ang = sqrtf(t2);
+    // rho = V^-1 t,  V^-1 = I - 1/2 [th]x + D [th]x^2,  D = (1 - (a/2) cot(a/2)) / a^2
+    float D;
+    if (ang < 1e-4f) D = 1.f / 12.f + t2 / 720.f;
+    else { float h = 0.5f * ang; D = (1.f - h * cosf(h) / sinf(h)) / t2; }
+    float c1[3] = {th[1] * p.t[2] - th[2] * p.t[1], th[2] * p.t[0] - th[0] * p.t[2], th[0] * p.t[1] - th[1] * p.t[0]};
+    float c2[3] = {th[1] * c1[2] - th[2] * c1[1], th[2] * c1[0] - th[0] * c1[2], th[0] * c1[1] - th[1] * c1[0]};
+    float* o = out + 6 * i;
+    for (int k2 = 0; k2 < 3; ++k2) { o[k2] = p.t[k2] - 0.5f * c1[k2] + D * c2[k2]; o[3 + k2] = th[k2]; }
+  } else if (OP == OP_INV) {
+    Pose p = load_pose(a + 7 * i), r;
+    r.q[0] = -p.q[0]; r.q[1] = -p.q[1]; r.q[2] = -p.q[2]; r.q[3] = p.q[3];
+    float rt[3];
+    quat_rotate(r.q, p.t, rt);
+    r.t[0] = -rt[0]; r.t[1] = -rt[1]; r.t[2] = -rt[2];
+    store_pose(out + 7 * i, r);
+  } else if (OP == OP_MUL) {
+    Pose x = load_pose(a + 7 * i), y = load_pose(b + 7 * i), r;
+    quat_mul(x.q, y.q, r.q);
+    float rt[3];
+    quat_rotate(x.q, y.t, rt);
+    r.t[0] = x.t[0] + rt[0]; r.t[1] = x.t[1] + rt[1]; r.t[2] = x.t[2] + rt[2];
+    store_pose(out + 7 * i, r);
+  } else if (OP == OP_ACT) {
+    Pose x = load_pose(a + 7 * i);
+    float v[3] = {b[3 * i], b[3 * i + 1], b[3 * i + 2]}, r[3];
+    quat_rotate(x.q, v, r);
+    out[3 * i] = r[0] + x.t[0]; out[3 * i + 1] = r[1] + x.t[1]; out[3 * i + 2] = r[2] + x.t[2];
+  } else if (OP == OP_ADJT) {
+    Pose x = load_pose(a + 7 * i);
+    const float* v = b + 6 * i;
+    float ar[3] = {v[0], v[1], v[2]}, at[3] = {v[3], v[4], v[5]};
+    float qi[4] = {-x.q[0], -x.q[1], -x.q[2], x.q[3]};
+    float txa[3] = {x.t[1] * ar[2] - x.t[2] * ar[1], x.t[2] * ar[0] - x.t[0] * ar[2], x.t[0] * ar[1] - x.t[1] * ar[0]};
+    float m[3] = {at[0] - txa[0], at[1] - txa[1], at[2] - txa[2]};
+    float o1[3], o2[3];
+    quat_rotate(qi, ar, o1);
+    quat_rotate(qi, m, o2);
+    float* o = out + 6 * i;
+    o[0] = o1[0]; o[1] = o1[1]; o[2] = o1[2]; o[3] = o2[0]; o[4] = o2[1]; o[5] = o2[2];
+  } else {   // OP_MATRIX
+    Pose x = load_pose(a + 7 * i);
+    float ex[3] = {1.f, 0.f, 0.f}, ey[3] = {0.f, 1.f, 0.f}, ez[3] = {0.f, 0.f, 1.f}, c0[3], c1[3], c2[3];
+    quat_rotate(x.q, ex, c0); quat_rotate(x.q, ey, c1); quat_rotate(x.q, ez, c2);
+    float* o = out + 16 * i;
+    for (int r = 0; r < 3; ++r) { o[4 * r] = c0[r]; o[4 * r + 1] = c1[r]; o[4 * r + 2] = c2[r]; o[4 * r + 3] = x.t[r]; }
+    o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+  }
+}
+
+template <int OP>
+static int se3_launch(int64_t n, const float* a, const float* b, float* out, void* stream) {
+  if (n < 0 || (n > 0 && (!a || !out))) return set_error(SGR_ERR_INVALID, "se3: null argument");
+  if (n == 0) return SGR_OK;
+  hipLaunchKernelGGL(se3_kernel<OP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, a, b, out);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "se3 launch failed");
+}
+
+}  // namespace sgr
+
+using namespace sgr;
+
+extern "C" {
+
+int sgr_mapping_loss(int32_t H, int32_t W, const float* image, const float* depth, const float* gt_image,
+                     const float* gt_depth, const float* exposure_a, const float* exposure_b, float alpha,
+                     float rgb_boundary_threshold, float upstream, float* loss, float* dL_dimage, float* dL_ddepth,
+                     float* dL_dexp_a, float* dL_dexp_b, void* scratch, size_t scratch_bytes, void* stream) {
+  if (H <= 0 || W <= 0 || !image || !depth || !gt_image || !gt_depth) return set_error(SGR_ERR_INVALID, "mapping_loss: null/size");
+  const int HW = H * W;
+  int blocks = (HW + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (!scratch || scratch_bytes < (size_t)blocks * sizeof(LossPart))
+    return set_error(SGR_ERR_WORKSPACE, "mapping_loss scratch too small (need %zu)", (size_t)1024 * sizeof(LossPart));
+  float inv_rgb = 1.f / (3.f * (float)HW), inv_dep = 1.f / (float)HW;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mapping_loss_kernel, dim3(blocks), dim3(256), 0, st, HW, image, depth, gt_image, gt_depth, exposure_a,
+                     exposure_b, upstream * alpha * inv_rgb, upstream * (1.f - alpha) * inv_dep, rgb_boundary_threshold,
+                     dL_dimage, dL_ddepth, (LossPart*)scratch);
+  hipLaunchKernelGGL(mapping_loss_final_kernel, dim3(1), dim3(64), 0, st, blocks, (const LossPart*)scratch, inv_rgb, inv_dep,
+                     alpha, loss, dL_dexp_a, dL_dexp_b);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "mapping_loss launch failed");
+}
+
+int sgr_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, int64_t step, void* stream) {
+  if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return set_error(SGR_ERR_INVALID, "adam: bad argument");
+  if (n == 0) return SGR_OK;
+  double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  float step_size = (float)((double)lr / bc1);
+  float bc2_sqrt = (float)std::sqrt(bc2);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq,
+                     beta1, beta2, eps, step_size, bc2_sqrt);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "adam launch failed");
+}
+
+size_t sknn_scratch_bytes(int32_t n) { return n <= 0 ? 256 : (size_t)knn_splits(n) * (size_t)n * sizeof(Top3) + 256; }
+
+int sknn_dist2(const float* xyz, int32_t n, float* mean_dist2, void* scratch, size_t scratch_bytes, void* stream) {
+  if (n < 0 || (n > 0 && (!xyz || !mean_dist2))) return set_error(SGR_ERR_INVALID, "sknn: null argument");
+  if (n == 0) return SGR_OK;
+  if (!scratch || scratch_bytes < sknn_scratch_bytes(n)) return set_error(SGR_ERR_WORKSPACE, "sknn scratch too small");
+  int splits = knn_splits(n);
+  int per = ((n + splits - 1) / splits + 255) / 256 * 256;
+  int qb = (n + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(knn_partial_kernel, dim3(qb, splits), dim3(256), 0, st, n, xyz, per, (Top3*)scratch);
+  hipLaunchKernelGGL(knn_merge_kernel, dim3(qb), dim3(256), 0, st, n, splits, (const Top3*)scratch, mean_dist2);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "sknn launch failed");
+}
+
+int se3_exp(const float* tau, int64_t n, float* pose_out, void* stream) { return se3_launch<OP_EXP>(n, tau, nullptr, pose_out, stream); }
+int se3_log(const float* pose, int64_t n, float* tau_out, void* stream) { return se3_launch<OP_LOG>(n, pose, nullptr, tau_out, stream); }
+int se3_inv(const float* pose, int64_t n, float* pose_out, void* stream) { return se3_launch<OP_INV>(n, pose, nullptr, pose_out, stream); }
+int se3_mul(const float* a, const float* b, int64_t n, float* pose_out, void* stream) { return se3_launch<OP_MUL>(n, a, b, pose_out, stream); }
+int se3_act(const float* pose, const float* pts, int64_t n, float* pts_out, void* stream) { return se3_launch<OP_ACT>(n, pose, pts, pts_out, stream); }
+int se3_adjT(const float* pose, const float* a, int64_t n, float* out, void* stream) { return se3_launch<OP_ADJT>(n, pose, a, out, stream); }
+int se3_matrix(const float* pose, int64_t n, float* mat_out, void* stream) { return se3_launch<OP_MATRIX>(n, pose, nullptr, mat_out, stream); }
+
+}  // extern "C"

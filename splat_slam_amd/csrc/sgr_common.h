@@ -1,0 +1,161 @@
+// Internal layout + device helpers shared by the gfx950 rasterizer kernels.
+// Design notes live in DESIGN.md; the public surface is include/splat_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/splat_hip.h"
+
+namespace sgr {
+
+// ---- constants of the rasterization algorithm (3DGS / MonoGS w-pose fork, see oracle/raster_oracle.py)
+constexpr float kNearPlane = 0.001f;   // /root/reference/README.md:88-92 (patched from 0.2)
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kTEps = 1e-4f;
+constexpr float kDilation = 0.3f;
+constexpr float kTouchedT = 0.5f;
+constexpr int kRefTile = 16;           // upstream tile edge: defines which pixels a splat may reach
+constexpr int kTile = 8;               // our binning tile = one wave64 = 8x8 pixels
+constexpr int kWave = 64;
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+// ---- header at the start of the saved block
+struct SavedHeader {
+  uint32_t num_rendered;   // R: total (tile, Gaussian) pairs demanded (may exceed capacity)
+  uint32_t overflow;       // != 0 when R > capacity (pairs were dropped)
+  uint32_t sorted_count;   // number of pairs actually binned = min(R, capacity)
+  uint32_t pad[13];
+};
+
+inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Carves the two workspaces. Pure function of (N, H, W, capacity): forward and backward agree by construction.
+struct Layout {
+  int N, H, W;
+  int64_t cap;
+  int gx, gy, ntiles;      // 8x8 tile grid
+  int sgx, sgy;            // 16x16 super-tile grid (one 256-thread workgroup)
+  int tile_bits;
+  // saved
+  size_t o_hdr, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
+      o_tile_maxc, o_final_T, o_n_contrib, saved_bytes;
+  // scratch (forward)
+  size_t o_keys_in, o_keys_out, o_vals_in, o_scan_tmp, o_sort_tmp, scan_tmp_bytes, sort_tmp_bytes;
+  // scratch (backward) -- aliases the forward scratch
+  size_t o_partials, o_tau_part, scratch_bytes;
+  int pre_blocks;
+
+  __host__ Layout(int N_, int H_, int W_, int64_t cap_, size_t scan_tmp, size_t sort_tmp)
+      : N(N_), H(H_), W(W_), cap(cap_) {
+    gx = (W + kTile - 1) / kTile;
+    gy = (H + kTile - 1) / kTile;
+    ntiles = gx * gy;
+    sgx = (W + kRefTile - 1) / kRefTile;
+    sgy = (H + kRefTile - 1) / kRefTile;
+    tile_bits = 1;
+    while ((1ll << tile_bits) < (long long)ntiles + 1) ++tile_bits;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
+    size_t n = (size_t)(N > 0 ? N : 1), hw = (size_t)H * W, c = (size_t)(cap > 0 ? cap : 1);
+    o_hdr = take(sizeof(SavedHeader));
+    o_xy = take(n * 8);
+    o_conic_o = take(n * 16);
+    o_rgbd = take(n * 16);
+    o_rect = take(n * 8);
+    o_offsets = take(n * 4);
+    o_touched = take(n * 4);
+    o_clamped = take(n);
+    o_point_list = take(c * 4);
+    o_ranges = take((size_t)ntiles * 8);
+    o_tile_maxc = take((size_t)ntiles * 4);
+    o_final_T = take(hw * 4);
+    o_n_contrib = take(hw * 4);
+    saved_bytes = o;
+
+    scan_tmp_bytes = scan_tmp;
+    sort_tmp_bytes = sort_tmp;
+    o = 0;
+    o_keys_in = take(c * 8);
+    o_keys_out = take(c * 8);
+    o_vals_in = take(c * 4);
+    o_scan_tmp = take(scan_tmp);
+    o_sort_tmp = take(sort_tmp);
+    size_t fwd = o;
+    o = 0;
+    pre_blocks = (N + 255) / 256;
+    o_partials = take(c * 48);
+    o_tau_part = take((size_t)(pre_blocks > 0 ? pre_blocks : 1) * 6 * 4);
+    scratch_bytes = fwd > o ? fwd : o;
+  }
+};
+
+// ---- tiny fixed-size linear algebra on registers
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// The one definition of a splat's footprint at a pixel.  Forward and backward MUST agree bit-for-bit on the
+// skip decisions, so both call this and the multiply/add order is pinned with explicit fma's.
+struct AlphaEval { float power, G, alpha; bool ok; };
+__device__ __forceinline__ AlphaEval eval_alpha(float dx, float dy, float A, float B, float C, float opac) {
+  AlphaEval r;
+  float q = __fmaf_rn(A * dx, dx, (C * dy) * dy);
+  r.power = __fmaf_rn(-0.5f, q, -(B * dx) * dy);
+  r.G = __expf(r.power);
+  r.alpha = fminf(kAlphaMax, opac * r.G);
+  r.ok = (r.power <= 0.0f) && (r.alpha >= kAlphaMin);
+  return r;
+}
+
+// ---- wave64 DPP scans (gfx9 DPP: row_shr within 16 lanes, row_bcast across rows)
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                                                BANK_MASK, false));
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+// inclusive prefix sum over lanes 0..63
+__device__ __forceinline__ float wave_scan_add(float v) {
+  v += dpp_f<DPP_ROW_SHR1>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR2>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR4>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR8>(0.f, v);
+  v += dpp_f<DPP_ROW_BCAST15, 0xa>(0.f, v);
+  v += dpp_f<DPP_ROW_BCAST31, 0xc>(0.f, v);
+  return v;
+}
+// inclusive prefix product over lanes 0..63
+__device__ __forceinline__ float wave_scan_mul(float v) {
+  v *= dpp_f<DPP_ROW_SHR1>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR2>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR4>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR8>(1.f, v);
+  v *= dpp_f<DPP_ROW_BCAST15, 0xa>(1.f, v);
+  v *= dpp_f<DPP_ROW_BCAST31, 0xc>(1.f, v);
+  return v;
+}
+// value of lane-1 (lane 0 receives `fill`)
+__device__ __forceinline__ float wave_shr1(float v, float fill) { return dpp_f<DPP_WAVE_SHR1>(fill, v); }
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {   // total in every lane
+  v = wave_scan_add(v);
+  return readlane_f(v, 63);
+}
+
+}  // namespace sgr

@@ -1,0 +1,520 @@
+// Per-Gaussian stages of the rasterizer for gfx950: projection / EWA footprint / tile rectangle (forward) and the
+// whole chain rule from blend gradients back to (mean, scale, rotation, SH, opacity, camera pose) (backward).
+//
+// Replaces preprocessCUDA / computeCov2DCUDA of the un-vendored diff-gaussian-rasterization-w-pose module
+// (/root/reference/.gitmodules:4-6, README.md:88-92) that GaussianRasterizer.forward reaches from
+// /root/reference/thirdparty/gaussian_splatting/gaussian_renderer/__init__.py:130-141.
+//
+// MI355X notes: both kernels are HBM-streaming (one pass over the Gaussian SoA, 64-wide waves, 256-thread blocks).
+// Nothing that can be recomputed from the inputs is stored for the backward (cov3D, cov2D, J, T are rebuilt in
+// registers) -- HBM bytes, not flops, bound these kernels.  Per-Gaussian pose gradients are reduced in-kernel
+// (wave DPP + LDS) to one 6-vector per block, then by a fixed-order second stage: deterministic, no [N,6] buffer.
+#include "sgr_common.h"
+
+namespace sgr {
+
+struct Cam {
+  float vm[16];   // viewmatrix   (transposed layout: W2C[r][c] = vm[c*4+r])
+  float pm[16];   // projmatrix
+};
+
+__device__ __forceinline__ void load16(const float* __restrict__ src, float* dst) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dst[i] = src[i];
+}
+
+__device__ __forceinline__ void quat_to_R(const float q[4], float R[3][3]) {
+  float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+  R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+  R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma (symmetric 3x3 as 6 floats: 00 01 02 11 12 22)
+__device__ __forceinline__ void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], float S6[6]) {
+  float R[3][3];
+  quat_to_R(q, R);
+  float M[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) M[i][k] = R[i][k] * (mod * s[k]);
+  S6[0] = M[0][0] * M[0][0] + M[0][1] * M[0][1] + M[0][2] * M[0][2];
+  S6[1] = M[0][0] * M[1][0] + M[0][1] * M[1][1] + M[0][2] * M[1][2];
+  S6[2] = M[0][0] * M[2][0] + M[0][1] * M[2][1] + M[0][2] * M[2][2];
+  S6[3] = M[1][0] * M[1][0] + M[1][1] * M[1][1] + M[1][2] * M[1][2];
+  S6[4] = M[1][0] * M[2][0] + M[1][1] * M[2][1] + M[1][2] * M[2][2];
+  S6[5] = M[2][0] * M[2][0] + M[2][1] * M[2][1] + M[2][2] * M[2][2];
+}
+
+struct Ewa {
+  float tx, ty, tz;          // clamped view-space mean used by the Jacobian
+  bool clamp_x, clamp_y;
+  float T[2][3];             // J * W
+  float a, b, c;             // dilated 2D covariance
+};
+
+__device__ __forceinline__ void ewa_project(const float pv[3], const float* vm, const float S6[6], float fx, float fy,
+                                            float limx, float limy, Ewa& e) {
+  float tz = pv[2];
+  float txtz = pv[0] / tz, tytz = pv[1] / tz;
+  e.clamp_x = (txtz < -limx) || (txtz > limx);
+  e.clamp_y = (tytz < -limy) || (tytz > limy);
+  e.tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+  e.ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+  e.tz = tz;
+  float itz = 1.f / tz;
+  float J00 = fx * itz, J02 = -fx * e.tx * itz * itz;
+  float J11 = fy * itz, J12 = -fy * e.ty * itz * itz;
+  // W[r][c] = vm[c*4+r]
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    e.T[0][k] = J00 * vm[k * 4 + 0] + J02 * vm[k * 4 + 2];
+    e.T[1][k] = J11 * vm[k * 4 + 1] + J12 * vm[k * 4 + 2];
+  }
+  float S[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
+  float TS[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) TS[i][k] = e.T[i][0] * S[0][k] + e.T[i][1] * S[1][k] + e.T[i][2] * S[2][k];
+  e.a = TS[0][0] * e.T[0][0] + TS[0][1] * e.T[0][1] + TS[0][2] * e.T[0][2] + kDilation;
+  e.b = TS[0][0] * e.T[1][0] + TS[0][1] * e.T[1][1] + TS[0][2] * e.T[1][2];
+  e.c = TS[1][0] * e.T[1][0] + TS[1][1] * e.T[1][1] + TS[1][2] * e.T[1][2] + kDilation;
+}
+
+// SH -> RGB (+0.5, clamp >= 0).  sh: [M,3] of this Gaussian.  Returns clamp bits.
+__device__ __forceinline__ unsigned sh_to_rgb(int deg, const float* __restrict__ sh, const float dir[3], float rgb[3]) {
+  float x = dir[0], y = dir[1], z = dir[2];
+  unsigned clamped = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float r = SH_C0 * sh[c];
+    if (deg > 0) {
+      r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+      if (deg > 1) {
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        r += SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] + SH_C2[2] * (2.f * zz - xx - yy) * sh[18 + c] +
+             SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
+        if (deg > 2) {
+          r += SH_C3[0] * y * (3.f * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+               SH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + c] + SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
+               SH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+               SH_C3[6] * x * (xx - 3.f * yy) * sh[45 + c];
+        }
+      }
+    }
+    r += 0.5f;
+    if (r < 0.f) { clamped |= 1u << c; r = 0.f; }
+    rgb[c] = r;
+  }
+  return clamped;
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(
+    int N, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+    const float* __restrict__ means3D, const float* __restrict__ opacities, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp,
+    int gx, int gy, int sgx, int sgy,
+    int32_t* __restrict__ radii, float2* __restrict__ xy_out, float4* __restrict__ conic_o, float4* __restrict__ rgbd,
+    ushort4* __restrict__ rect_out, uint32_t* __restrict__ touched, uint8_t* __restrict__ clamped_out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float vm[16], pm[16];
+  load16(viewmatrix, vm);
+  load16(projmatrix, pm);
+
+  radii[i] = 0;
+  touched[i] = 0;
+
+  float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+  float pv[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) pv[r] = vm[r] * p[0] + vm[4 + r] * p[1] + vm[8 + r] * p[2] + vm[12 + r];
+  if (!(pv[2] > kNearPlane)) return;
+
+  float ph[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ph[r] = pm[r] * p[0] + pm[4 + r] * p[1] + pm[8 + r] * p[2] + pm[12 + r];
+  float pw = 1.f / (ph[3] + 1e-7f);
+  float ndcx = ph[0] * pw, ndcy = ph[1] * pw;
+
+  float S6[6];
+  if (cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S6[k] = cov3D_precomp[6 * i + k];
+  } else {
+    float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+    cov3d_from_scale_rot(s, mod, q, S6);
+  }
+  float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
+  Ewa e;
+  ewa_project(pv, vm, S6, fx, fy, 1.3f * tanfovx, 1.3f * tanfovy, e);
+  float det = e.a * e.c - e.b * e.b;
+  if (det == 0.f) return;
+  float det_inv = 1.f / det;
+  float A = e.c * det_inv, B = -e.b * det_inv, C = e.a * det_inv;
+  float mid = 0.5f * (e.a + e.c);
+  float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+  float lam = fmaxf(mid + disc, mid - disc);
+  float rad = ceilf(3.f * sqrtf(lam));
+  float px = ((ndcx + 1.f) * W - 1.f) * 0.5f, py = ((ndcy + 1.f) * H - 1.f) * 0.5f;
+  if (!(isfinite(px) && isfinite(py) && isfinite(rad))) return;
+
+  // which pixels this splat may reach is defined by the reference's 16x16 tile rectangle
+  int rx0 = min(sgx, max(0, (int)((px - rad) / (float)kRefTile)));
+  int ry0 = min(sgy, max(0, (int)((py - rad) / (float)kRefTile)));
+  int rx1 = min(sgx, max(0, (int)((px + rad + (kRefTile - 1)) / (float)kRefTile)));
+  int ry1 = min(sgy, max(0, (int)((py + rad + (kRefTile - 1)) / (float)kRefTile)));
+  if ((rx1 - rx0) * (ry1 - ry0) == 0) return;
+
+  float opac = opacities[i];
+  // our bins are 8x8 (one wave): refine the rectangle, then drop bins no pixel of which can pass alpha >= 1/255.
+  int x0 = min(gx, 2 * rx0), x1 = min(gx, 2 * rx1), y0 = min(gy, 2 * ry0), y1 = min(gy, 2 * ry1);
+  {
+    float detc = A * C - B * B;
+    float o255 = 255.f * opac;
+    if (!(o255 >= 1.f)) {
+      x1 = x0;   // alpha = min(.99, o*G) <= o < 1/255 everywhere: contributes to no pixel
+    } else if (A > 0.f && C > 0.f && detc > 0.f) {
+      float tau = 2.f * __logf(o255) * 1.001f + 0.02f;     // q = -2*power <= tau is necessary for alpha >= 1/255
+      float ex = sqrtf(tau * C / detc), ey = sqrtf(tau * A / detc);   // half extents of {q <= tau}
+      float ext = fmaxf(ex, ey) + 2.f * kTile;
+      float err = 4e-7f * (A + C + 2.f * fabsf(B)) * ext * ext;       // fp32 rounding of q near the boundary
+      if (err < 0.005f && isfinite(ex) && isfinite(ey)) {
+        int cx0 = (int)ceilf((px - ex - (kTile - 1)) / (float)kTile - 1e-3f);
+        int cx1 = (int)floorf((px + ex) / (float)kTile + 1e-3f) + 1;
+        int cy0 = (int)ceilf((py - ey - (kTile - 1)) / (float)kTile - 1e-3f);
+        int cy1 = (int)floorf((py + ey) / (float)kTile + 1e-3f) + 1;
+        x0 = max(x0, cx0); x1 = min(x1, cx1); y0 = max(y0, cy0); y1 = min(y1, cy1);
+        if (x1 < x0) x1 = x0;
+        if (y1 < y0) y1 = y0;
+      }
+    }
+  }
+
+  float rgb[3];
+  unsigned clamped = 0;
+  if (colors_precomp) {
+    rgb[0] = colors_precomp[3 * i]; rgb[1] = colors_precomp[3 * i + 1]; rgb[2] = colors_precomp[3 * i + 2];
+  } else {
+    float dir[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
+    float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
+    clamped = sh_to_rgb(deg, shs + (size_t)i * M * 3, dir, rgb);
+  }
+
+  radii[i] = (int32_t)rad;
+  xy_out[i] = make_float2(px, py);
+  conic_o[i] = make_float4(A, B, C, opac);
+  rgbd[i] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
+  rect_out[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+  touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
+  clamped_out[i] = (uint8_t)clamped;
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// Per-entry partials written by blend_bwd (12 floats = 48 B per (tile, Gaussian) pair):
+//   0,1 : dL/d(mean2D) in NDC-scaled pixel units   2,3,4 : dL/dA, dL/dB, dL/dC (true partials of the conic)
+//   5   : dL/dopacity   6,7,8 : dL/drgb   9 : dL/ddepth   10,11 : unused
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(
+    int N, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ projraw,
+    const float* __restrict__ campos,
+    const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ touched,
+    const uint8_t* __restrict__ clamped_in, const float4* __restrict__ partials, int64_t cap,
+    float* __restrict__ dmeans3D, float* __restrict__ dmeans2D, float* __restrict__ dopac, float* __restrict__ dshs,
+    float* __restrict__ dcolors, float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D,
+    float* __restrict__ tau_part) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bool live = (i < N) && (radii[i] > 0);
+
+  float g_m2[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_rgb[3] = {0.f, 0.f, 0.f}, g_dep = 0.f;
+  float g_p[3] = {0.f, 0.f, 0.f};        // dL/dmean3D
+  float g_S6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float g_s[3] = {0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f};
+
+  if (live) {
+    // fixed-order gather of this Gaussian's per-tile partials: deterministic, no atomics
+    uint32_t off = offsets[i], cnt = touched[i];
+    for (uint32_t k = 0; k < cnt; ++k) {
+      uint64_t e = (uint64_t)off + k;
+      if ((int64_t)e >= cap) break;
+      float4 p0 = partials[e * 3 + 0], p1 = partials[e * 3 + 1], p2 = partials[e * 3 + 2];
+      g_m2[0] += p0.x; g_m2[1] += p0.y; g_con[0] += p0.z; g_con[1] += p0.w;
+      g_con[2] += p1.x; g_op += p1.y; g_rgb[0] += p1.z; g_rgb[1] += p1.w;
+      g_rgb[2] += p2.x; g_dep += p2.y;
+    }
+
+    float vm[16], pm[16], pr[16];
+    load16(viewmatrix, vm);
+    load16(projmatrix, pm);
+    load16(projraw, pr);
+    float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float pv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pv[r] = vm[r] * p[0] + vm[4 + r] * p[1] + vm[8 + r] * p[2] + vm[12 + r];
+    float ph[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ph[r] = pm[r] * p[0] + pm[4 + r] * p[1] + pm[8 + r] * p[2] + pm[12 + r];
+    float pw = 1.f / (ph[3] + 1e-7f);
+
+    float s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, S6[6];
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S6[k] = cov3D_precomp[6 * i + k];
+    } else {
+      s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
+      q[0] = rotations[4 * i]; q[1] = rotations[4 * i + 1]; q[2] = rotations[4 * i + 2]; q[3] = rotations[4 * i + 3];
+      cov3d_from_scale_rot(s, mod, q, S6);
+    }
+    float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
+    Ewa e;
+    ewa_project(pv, vm, S6, fx, fy, 1.3f * tanfovx, 1.3f * tanfovy, e);
+
+    // ---- conic -> 2D covariance
+    float a = e.a, b = e.b, c = e.c;
+    float det = a * c - b * b;
+    float d2i = 1.f / (det * det + 1e-7f);   // upstream regulariser
+    float dA = g_con[0], dB = g_con[1], dC = g_con[2];
+    float dL_da = d2i * (-c * c * dA + b * c * dB - b * b * dC);
+    float dL_db = d2i * (2.f * b * c * dA - (det + 2.f * b * b) * dB + 2.f * a * b * dC);
+    float dL_dc = d2i * (-b * b * dA + a * b * dB - a * a * dC);
+    float G2[2][2] = {{dL_da, 0.5f * dL_db}, {0.5f * dL_db, dL_dc}};
+
+    // ---- dL/dSigma = T^T G T (full symmetric matrix), dL/dT = 2 G T Sigma
+    float GT[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) GT[r][k] = G2[r][0] * e.T[0][k] + G2[r][1] * e.T[1][k];
+    float dS[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) dS[k][l] = e.T[0][k] * GT[0][l] + e.T[1][k] * GT[1][l];
+    float S[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
+    float dT[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dT[r][k] = 2.f * (GT[r][0] * S[0][k] + GT[r][1] * S[1][k] + GT[r][2] * S[2][k]);
+
+    // ---- T = J W:  dL/dJ = dT W^T,  dL/dW = J^T dT      (W[r][c] = vm[c*4+r])
+    float itz = 1.f / e.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+    float J00 = fx * itz, J02 = -fx * e.tx * itz2, J11 = fy * itz, J12 = -fy * e.ty * itz2;
+    float dJ00 = dT[0][0] * vm[0] + dT[0][1] * vm[4] + dT[0][2] * vm[8];
+    float dJ02 = dT[0][0] * vm[2] + dT[0][1] * vm[6] + dT[0][2] * vm[10];
+    float dJ11 = dT[1][0] * vm[1] + dT[1][1] * vm[5] + dT[1][2] * vm[9];
+    float dJ12 = dT[1][0] * vm[2] + dT[1][1] * vm[6] + dT[1][2] * vm[10];
+    float dW[3][3];   // dW[r][c]
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      dW[0][k] = J00 * dT[0][k];
+      dW[1][k] = J11 * dT[1][k];
+      dW[2][k] = J02 * dT[0][k] + J12 * dT[1][k];
+    }
+    // v = dL/d(p_view): covariance path (clamped axes carry no gradient), ...
+    float v[3];
+    v[0] = e.clamp_x ? 0.f : (-fx * itz2 * dJ02);
+    v[1] = e.clamp_y ? 0.f : (-fy * itz2 * dJ12);
+    v[2] = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + 2.f * fx * e.tx * itz3 * dJ02 + 2.f * fy * e.ty * itz3 * dJ12;
+    // ... projected-mean path through the raw projection P (P[r][c] = pr[c*4+r]), ...
+    float dph[4] = {g_m2[0] * pw, g_m2[1] * pw, 0.f, -(g_m2[0] * ph[0] + g_m2[1] * ph[1]) * pw * pw};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] += dph[0] * pr[k * 4 + 0] + dph[1] * pr[k * 4 + 1] + dph[3] * pr[k * 4 + 3];
+    // ... and the depth path.
+    v[2] += g_dep;
+
+    // world-space mean: W^T v
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_p[k] = vm[k * 4 + 0] * v[0] + vm[k * 4 + 1] * v[1] + vm[k * 4 + 2] * v[2];
+
+    // camera pose, left perturbation W2C <- exp(tau) W2C, tau = (rho, theta)  (pose_utils.py:66-98)
+    tau[0] = v[0]; tau[1] = v[1]; tau[2] = v[2];
+    V3 pc = cross(V3{pv[0], pv[1], pv[2]}, V3{v[0], v[1], v[2]});
+    tau[3] = pc.x; tau[4] = pc.y; tau[5] = pc.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // columns of W
+      V3 wc = cross(V3{vm[k * 4 + 0], vm[k * 4 + 1], vm[k * 4 + 2]}, V3{dW[0][k], dW[1][k], dW[2][k]});
+      tau[3] += wc.x; tau[4] += wc.y; tau[5] += wc.z;
+    }
+
+    // ---- colour
+    if (colors_precomp) {
+      if (dcolors) { dcolors[3 * i] = g_rgb[0]; dcolors[3 * i + 1] = g_rgb[1]; dcolors[3 * i + 2] = g_rgb[2]; }
+    } else {
+      unsigned cl = clamped_in[i];
+      float dc[3] = {(cl & 1u) ? 0.f : g_rgb[0], (cl & 2u) ? 0.f : g_rgb[1], (cl & 4u) ? 0.f : g_rgb[2]};
+      float* out = dshs ? dshs + (size_t)i * M * 3 : nullptr;
+      if (deg == 0) {
+        if (out) {
+          out[0] = SH_C0 * dc[0]; out[1] = SH_C0 * dc[1]; out[2] = SH_C0 * dc[2];
+          for (int k = 3; k < M * 3; ++k) out[k] = 0.f;
+        }
+      } else {
+        const float* sh = shs + (size_t)i * M * 3;
+        float dir0[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
+        float len2 = dir0[0] * dir0[0] + dir0[1] * dir0[1] + dir0[2] * dir0[2];
+        float inv = 1.f / sqrtf(len2);
+        float x = dir0[0] * inv, y = dir0[1] * inv, z = dir0[2] * inv;
+        float basis[16];
+        float dbx[16], dby[16], dbz[16];   // d(basis)/d(dir)
+        for (int k = 0; k < 16; ++k) { basis[k] = 0.f; dbx[k] = 0.f; dby[k] = 0.f; dbz[k] = 0.f; }
+        basis[0] = SH_C0;
+        basis[1] = -SH_C1 * y; dby[1] = -SH_C1;
+        basis[2] = SH_C1 * z;  dbz[2] = SH_C1;
+        basis[3] = -SH_C1 * x; dbx[3] = -SH_C1;
+        if (deg > 1) {
+          float xx = x * x, yy = y * y, zz = z * z;
+          basis[4] = SH_C2[0] * x * y; dbx[4] = SH_C2[0] * y; dby[4] = SH_C2[0] * x;
+          basis[5] = SH_C2[1] * y * z; dby[5] = SH_C2[1] * z; dbz[5] = SH_C2[1] * y;
+          basis[6] = SH_C2[2] * (2.f * zz - xx - yy); dbx[6] = SH_C2[2] * -2.f * x; dby[6] = SH_C2[2] * -2.f * y; dbz[6] = SH_C2[2] * 4.f * z;
+          basis[7] = SH_C2[3] * x * z; dbx[7] = SH_C2[3] * z; dbz[7] = SH_C2[3] * x;
+          basis[8] = SH_C2[4] * (xx - yy); dbx[8] = SH_C2[4] * 2.f * x; dby[8] = SH_C2[4] * -2.f * y;
+          if (deg > 2) {
+            basis[9] = SH_C3[0] * y * (3.f * xx - yy); dbx[9] = SH_C3[0] * 6.f * x * y; dby[9] = SH_C3[0] * (3.f * xx - 3.f * yy);
+            basis[10] = SH_C3[1] * x * y * z; dbx[10] = SH_C3[1] * y * z; dby[10] = SH_C3[1] * x * z; dbz[10] = SH_C3[1] * x * y;
+            basis[11] = SH_C3[2] * y * (4.f * zz - xx - yy); dbx[11] = SH_C3[2] * -2.f * x * y; dby[11] = SH_C3[2] * (4.f * zz - xx - 3.f * yy); dbz[11] = SH_C3[2] * 8.f * y * z;
+            basis[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); dbx[12] = SH_C3[3] * -6.f * x * z; dby[12] = SH_C3[3] * -6.f * y * z; dbz[12] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+            basis[13] = SH_C3[4] * x * (4.f * zz - xx - yy); dbx[13] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); dby[13] = SH_C3[4] * -2.f * x * y; dbz[13] = SH_C3[4] * 8.f * x * z;
+            basis[14] = SH_C3[5] * z * (xx - yy); dbx[14] = SH_C3[5] * 2.f * x * z; dby[14] = SH_C3[5] * -2.f * y * z; dbz[14] = SH_C3[5] * (xx - yy);
+            basis[15] = SH_C3[6] * x * (xx - 3.f * yy); dbx[15] = SH_C3[6] * (3.f * xx - 3.f * yy); dby[15] = SH_C3[6] * -6.f * x * y;
+          }
+        }
+        int K = (deg + 1) * (deg + 1);
+        float ddir[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < M; ++k) {
+          float bk = k < K ? basis[k] : 0.f;
+          for (int ch = 0; ch < 3; ++ch) {
+            if (out) out[k * 3 + ch] = bk * dc[ch];
+            if (k < K) {
+              float coef = sh[k * 3 + ch] * dc[ch];
+              ddir[0] += dbx[k] * coef; ddir[1] += dby[k] * coef; ddir[2] += dbz[k] * coef;
+            }
+          }
+        }
+        // d(normalised dir)/d(mean): (I - d d^T) / |dir|
+        float dot = x * ddir[0] + y * ddir[1] + z * ddir[2];
+        g_p[0] += (ddir[0] - x * dot) * inv;
+        g_p[1] += (ddir[1] - y * dot) * inv;
+        g_p[2] += (ddir[2] - z * dot) * inv;
+      }
+    }
+
+    // ---- 3D covariance
+    if (cov3D_precomp) {
+      g_S6[0] = dS[0][0]; g_S6[1] = 2.f * dS[0][1]; g_S6[2] = 2.f * dS[0][2];
+      g_S6[3] = dS[1][1]; g_S6[4] = 2.f * dS[1][2]; g_S6[5] = dS[2][2];
+    } else {
+      float R[3][3];
+      quat_to_R(q, R);
+      // Sigma = M M^T, M = R diag(mod*s):  dL/dM = 2 dS M
+      float Mx[3][3], dM[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Mx[r][k] = R[r][k] * (mod * s[k]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dM[r][k] = 2.f * (dS[r][0] * Mx[0][k] + dS[r][1] * Mx[1][k] + dS[r][2] * Mx[2][k]);
+      float dR[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        g_s[k] = mod * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dR[r][k] = dM[r][k] * (mod * s[k]);
+      }
+      float r = q[0], x = q[1], y = q[2], z = q[3];
+      g_q[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+      g_q[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+      g_q[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+      g_q[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+    }
+  } else if (i < N) {
+    if (!colors_precomp && dshs) {
+      float* out = dshs + (size_t)i * M * 3;
+      for (int k = 0; k < M * 3; ++k) out[k] = 0.f;
+    }
+    if (colors_precomp && dcolors) { dcolors[3 * i] = 0.f; dcolors[3 * i + 1] = 0.f; dcolors[3 * i + 2] = 0.f; }
+  }
+
+  if (i < N) {
+    if (dmeans3D) { dmeans3D[3 * i] = g_p[0]; dmeans3D[3 * i + 1] = g_p[1]; dmeans3D[3 * i + 2] = g_p[2]; }
+    if (dmeans2D) { dmeans2D[3 * i] = g_m2[0]; dmeans2D[3 * i + 1] = g_m2[1]; dmeans2D[3 * i + 2] = 0.f; }
+    if (dopac) dopac[i] = g_op;
+    if (dscales) { dscales[3 * i] = g_s[0]; dscales[3 * i + 1] = g_s[1]; dscales[3 * i + 2] = g_s[2]; }
+    if (drots) { drots[4 * i] = g_q[0]; drots[4 * i + 1] = g_q[1]; drots[4 * i + 2] = g_q[2]; drots[4 * i + 3] = g_q[3]; }
+    if (dcov3D) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dcov3D[6 * i + k] = g_S6[k];
+    }
+  }
+
+  // block reduction of the pose gradient: DPP inside each wave, fixed order across the 4 waves
+  __shared__ float red[4][6];
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float t = wave_sum(tau[k]);
+    if (lane == 0) red[wv][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    int k = threadIdx.x;
+    tau_part[(size_t)blockIdx.x * 6 + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+  }
+}
+
+// second stage: one block sums the per-block partials in a fixed order
+__global__ void __launch_bounds__(384) tau_reduce_kernel(const float* __restrict__ tau_part, int nblocks, float* __restrict__ dtau) {
+  __shared__ float red[6][64];
+  int k = threadIdx.x / 64, lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int b = lane; b < nblocks; b += 64) acc += tau_part[(size_t)b * 6 + k];
+  red[k][lane] = acc;
+  __syncthreads();
+  if (lane == 0) {
+    float t = 0.f;
+    for (int l = 0; l < 64; ++l) t += red[k][l];
+    dtau[k] = t;
+  }
+}
+
+void launch_preprocess_fwd(const SgrSettings& s, const SgrInputs& in, const SgrOutputs& out, const Layout& L, char* saved,
+                           hipStream_t st) {
+  if (s.num_gaussians <= 0) return;
+  int blocks = (s.num_gaussians + 255) / 256;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, st, s.num_gaussians, s.image_height,
+                     s.image_width, s.sh_degree, s.sh_coeffs, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix,
+                     s.projmatrix, s.campos, in.means3D, in.opacities, in.shs, in.colors_precomp, in.scales,
+                     in.rotations, in.cov3D_precomp, L.gx, L.gy, L.sgx, L.sgy, out.radii,
+                     (float2*)(saved + L.o_xy), (float4*)(saved + L.o_conic_o), (float4*)(saved + L.o_rgbd),
+                     (ushort4*)(saved + L.o_rect), (uint32_t*)(saved + L.o_touched), (uint8_t*)(saved + L.o_clamped));
+}
+
+void launch_preprocess_bwd(const SgrSettings& s, const SgrInputs& in, const int32_t* radii, const SgrGradInputs& g,
+                           const Layout& L, const char* saved, char* scratch, hipStream_t st) {
+  if (s.num_gaussians <= 0) return;
+  int blocks = L.pre_blocks;
+  float* tau_part = (float*)(scratch + L.o_tau_part);
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(256), 0, st, s.num_gaussians, s.image_height,
+                     s.image_width, s.sh_degree, s.sh_coeffs, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix,
+                     s.projmatrix, s.projmatrix_raw, s.campos, in.means3D, in.shs, in.colors_precomp, in.scales,
+                     in.rotations, in.cov3D_precomp, radii, (const uint32_t*)(saved + L.o_offsets),
+                     (const uint32_t*)(saved + L.o_touched), (const uint8_t*)(saved + L.o_clamped),
+                     (const float4*)(scratch + L.o_partials), L.cap, g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dopacities,
+                     g.dL_dshs, g.dL_dcolors_precomp, g.dL_dscales, g.dL_drotations, g.dL_dcov3D_precomp, tau_part);
+  if (g.dL_dtau)
+    hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(384), 0, st, tau_part, blocks, g.dL_dtau);
+}
+
+}  // namespace sgr
