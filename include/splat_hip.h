@@ -136,6 +136,21 @@ int sgr_backward(const SgrSettings* settings, const SgrInputs* in, const int32_t
 /* Synchronous read-back of (pair count, overflow flag) from a saved block produced by sgr_forward. */
 int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_host, void* stream);
 
+/* Work counters of one forward, read back synchronously (bench / roofline accounting only):
+ *   stats[0] = V  Gaussians with radii > 0          stats[1] = R  (tile, Gaussian) pairs binned
+ *   stats[2] = R_eff = sum over tiles of min(list length, last contributor): pairs the blend kernels walk
+ *   stats[3] = number of non-empty 8x8 tiles */
+int sgr_query_stats(const SgrWorkspace* ws, int32_t num_gaussians, int32_t image_height, int32_t image_width,
+                    const int32_t* radii, int64_t stats_host[4], void* stream);
+
+/* Per-kernel HIP-event timing.  kind: 0 preprocess_fwd, 1 scan, 2 duplicate, 3 sort, 4 ranges, 5 blend_fwd,
+ * 6 zero_partials, 7 blend_bwd, 8 preprocess_bwd.  sgr_profile_enable(mask) arms event pairs around the kinds whose
+ * bit is set (0 disarms); sgr_profile_read() synchronises, returns accumulated milliseconds and launch counts per
+ * kind since the last read, and resets them. Events are recorded on the stream the kernel is launched on. */
+#define SGR_PROFILE_KINDS 9
+int sgr_profile_enable(uint32_t kind_mask);
+int sgr_profile_read(float ms_host[SGR_PROFILE_KINDS], int64_t launches_host[SGR_PROFILE_KINDS]);
+
 /* Fused mapping loss (slam_utils.py:71-105): loss = alpha*mean|m*(e^a*I+b) - m*gt| + (1-alpha)*mean|md*D - md*gtD|
  * with m = (sum_c gt > rgb_boundary_threshold), md = (gtD > 0.01).  Writes loss[1] and the four gradients
  * scaled by `upstream` (dLoss/dloss).  exposure may be NULL (initialization=True branch, :72-73). */

@@ -1,0 +1,115 @@
+"""Camera of the mapping loop -- mirror of /root/reference/thirdparty/monogs/utils/camera_utils.py:13-148 and of the
+matrix helpers in /root/reference/thirdparty/gaussian_splatting/utils/graphics_utils.py:33-46,72-101.
+
+Same attribute names and conventions (W2C as R,T; transposed matrices; tau deltas; exposure a,b).  The reference
+re-inverts a 4x4 twice per property access (graphics_utils.py:41-45, camera_utils.py:94-108: 4 linalg.inv launches per
+render); here the three matrices are cached and rebuilt only by update_RT -- same values, no launches on the hot path.
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def getWorld2View2(R, t):
+    """graphics_utils.py:33-46 with translate=0, scale=1 (the only way the reference calls it): Rt itself."""
+    Rt = torch.zeros((4, 4), device=R.device, dtype=torch.float32)
+    Rt[:3, :3] = R
+    Rt[:3, 3] = t
+    Rt[3, 3] = 1.0
+    return Rt
+
+
+def getProjectionMatrix2(znear, zfar, cx, cy, fx, fy, W, H):
+    """graphics_utils.py:72-93."""
+    left = ((2 * cx - W) / W - 1.0) * W / 2.0
+    right = ((2 * cx - W) / W + 1.0) * W / 2.0
+    top = ((2 * cy - H) / H + 1.0) * H / 2.0
+    bottom = ((2 * cy - H) / H - 1.0) * H / 2.0
+    left = znear / fx * left
+    right = znear / fx * right
+    top = znear / fy * top
+    bottom = znear / fy * bottom
+    P = torch.zeros(4, 4)
+    z_sign = 1.0
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = z_sign
+    P[2, 2] = z_sign * zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def focal2fov(focal, pixels):
+    return 2 * math.atan(pixels / (2 * focal))
+
+
+class Camera(nn.Module):
+    def __init__(self, uid, color, depth, gt_T, projection_matrix, fx, fy, cx, cy, fovx, fovy, image_height,
+                 image_width, device="cuda:0"):
+        super().__init__()
+        self.uid = uid
+        self.device = device
+        T = torch.eye(4, device=device)
+        self.R = T[:3, :3]
+        self.T = T[:3, 3]
+        self.R_gt = gt_T[:3, :3]
+        self.T_gt = gt_T[:3, 3]
+        self.original_image = color
+        self.depth = depth              # reference keeps numpy here (slam_utils.py:87-89); a device tensor also works
+        self.grad_mask = None
+        self.fx, self.fy, self.cx, self.cy = fx, fy, cx, cy
+        self.FoVx, self.FoVy = fovx, fovy
+        self.image_height, self.image_width = image_height, image_width
+        self.cam_rot_delta = nn.Parameter(torch.zeros(3, requires_grad=True, device=device))
+        self.cam_trans_delta = nn.Parameter(torch.zeros(3, requires_grad=True, device=device))
+        self.exposure_a = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
+        self.exposure_b = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
+        self.projection_matrix = projection_matrix.to(device=device)
+        self._cache = None
+
+    @staticmethod
+    def init_from_dataset(dataset, data, projection_matrix):
+        """camera_utils.py:74-92."""
+        return Camera(data["idx"], data["gt_color"], data["glorie_depth"], data["glorie_pose"], projection_matrix,
+                      dataset.fx, dataset.fy, dataset.cx, dataset.cy, dataset.fovx, dataset.fovy, dataset.H_out,
+                      dataset.W_out, device=dataset.device)
+
+    def _matrices(self):
+        if self._cache is None:
+            with torch.no_grad():
+                w2c = getWorld2View2(self.R, self.T)
+                view = w2c.transpose(0, 1).contiguous()
+                full = (view.unsqueeze(0).bmm(self.projection_matrix.unsqueeze(0))).squeeze(0).contiguous()
+                # camera centre = -R^T t  (== world_view_transform.inverse()[3, :3], camera_utils.py:106-108)
+                center = (-(self.R.transpose(0, 1) @ self.T)).contiguous()
+            self._cache = (view, full, center)
+        return self._cache
+
+    @property
+    def world_view_transform(self):
+        return self._matrices()[0]
+
+    @property
+    def full_proj_transform(self):
+        return self._matrices()[1]
+
+    @property
+    def camera_center(self):
+        return self._matrices()[2]
+
+    def update_RT(self, R, t):
+        self.R = R.to(device=self.device)
+        self.T = t.to(device=self.device)
+        self._cache = None
+
+    def clean(self):
+        self.original_image = None
+        self.depth = None
+        self.grad_mask = None
+        self.cam_rot_delta = None
+        self.cam_trans_delta = None
+        self.exposure_a = None
+        self.exposure_b = None

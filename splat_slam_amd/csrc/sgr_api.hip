@@ -103,6 +103,55 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const SavedHeader* __r
   }
 }
 
+// ---- event-pair profiler
+struct ProfState {
+  static constexpr int kRing = 2048;
+  uint32_t mask = 0;
+  hipEvent_t ev[SGR_PROFILE_KINDS][kRing][2];
+  bool created[SGR_PROFILE_KINDS] = {};
+  int used[SGR_PROFILE_KINDS] = {};
+  double ms[SGR_PROFILE_KINDS] = {};
+  int64_t launches[SGR_PROFILE_KINDS] = {};
+};
+static ProfState g_prof;
+static void prof_drain(int k) {
+  for (int i = 0; i < g_prof.used[k]; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_prof.ev[k][i][1]) == hipSuccess &&
+        hipEventElapsedTime(&t, g_prof.ev[k][i][0], g_prof.ev[k][i][1]) == hipSuccess) {
+      g_prof.ms[k] += t;
+      g_prof.launches[k] += 1;
+    }
+  }
+  g_prof.used[k] = 0;
+}
+void prof_begin(int k, hipStream_t st) {
+  if (!(g_prof.mask & (1u << k))) return;
+  if (!g_prof.created[k]) {
+    for (int i = 0; i < ProfState::kRing; ++i) { (void)hipEventCreate(&g_prof.ev[k][i][0]); (void)hipEventCreate(&g_prof.ev[k][i][1]); }
+    g_prof.created[k] = true;
+  }
+  if (g_prof.used[k] == ProfState::kRing) prof_drain(k);
+  (void)hipEventRecord(g_prof.ev[k][g_prof.used[k]][0], st);
+}
+void prof_end(int k, hipStream_t st) {
+  if (!(g_prof.mask & (1u << k))) return;
+  (void)hipEventRecord(g_prof.ev[k][g_prof.used[k]][1], st);
+  g_prof.used[k] += 1;
+}
+
+__global__ void __launch_bounds__(256) stats_kernel(int N, int ntiles, const int32_t* __restrict__ radii,
+                                                     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_maxc,
+                                                     unsigned long long* __restrict__ out) {
+  unsigned long long v = 0, r = 0, re = 0, ne = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) v += radii[i] > 0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+    uint32_t c = ranges[t].y - ranges[t].x;
+    r += c; re += min(c, tile_maxc[t]); ne += c > 0;
+  }
+  atomicAdd(&out[0], v); atomicAdd(&out[1], r); atomicAdd(&out[2], re); atomicAdd(&out[3], ne);
+}
+
 static int check_common(const SgrSettings* s, const SgrWorkspace* ws, const Layout& L) {
   if (!ws->saved || ws->saved_bytes < L.saved_bytes)
     return set_error(SGR_ERR_WORKSPACE, "saved workspace too small: %zu < %zu", ws->saved_bytes, L.saved_bytes);
@@ -159,6 +208,7 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
   if (N > 0) HIP_TRY(hipMemsetAsync(out->n_touched, 0, (size_t)N * 4, st));
   launch_preprocess_fwd(*s, *in, *out, L, saved, st);
   if (N > 0) {
+    ProfScope prof(PK_SCAN, st);
     size_t tb = L.scan_tmp_bytes;
     HIP_TRY(rocprim::exclusive_scan(scratch + L.o_scan_tmp, tb, touched, offsets, 0u, (size_t)N, rocprim::plus<uint32_t>(), st));
   }
@@ -174,13 +224,20 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
     sort_n = R;
   }
   if (N > 0 && sort_n > 0) {
-    hipLaunchKernelGGL(duplicate_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, L.gx, out->radii, offsets,
-                       touched, (const ushort4*)(saved + L.o_rect), (const float4*)(saved + L.o_rgbd), L.cap, keys_in, vals_in);
-    if (!num_rendered_host)
-      hipLaunchKernelGGL(fill_sentinel_kernel, dim3(256), dim3(256), 0, st, hdr, L.cap, keys_in, vals_in);
-    size_t tb = L.sort_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(scratch + L.o_sort_tmp, tb, keys_in, keys_out, vals_in, point_list, (size_t)sort_n, 0u,
-                                      (unsigned)(32 + L.tile_bits), st));
+    {
+      ProfScope prof(PK_DUP, st);
+      hipLaunchKernelGGL(duplicate_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, L.gx, out->radii, offsets,
+                         touched, (const ushort4*)(saved + L.o_rect), (const float4*)(saved + L.o_rgbd), L.cap, keys_in, vals_in);
+      if (!num_rendered_host)
+        hipLaunchKernelGGL(fill_sentinel_kernel, dim3(256), dim3(256), 0, st, hdr, L.cap, keys_in, vals_in);
+    }
+    {
+      ProfScope prof(PK_SORT, st);
+      size_t tb = L.sort_tmp_bytes;
+      HIP_TRY(rocprim::radix_sort_pairs(scratch + L.o_sort_tmp, tb, keys_in, keys_out, vals_in, point_list, (size_t)sort_n, 0u,
+                                        (unsigned)(32 + L.tile_bits), st));
+    }
+    ProfScope prof(PK_RANGES, st);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(256), dim3(256), 0, st, hdr, keys_out, (uint2*)(saved + L.o_ranges));
   }
   launch_blend_fwd(*s, *out, L, saved, st);
@@ -205,6 +262,38 @@ int sgr_backward(const SgrSettings* s, const SgrInputs* in, const int32_t* radii
   launch_blend_bwd(*s, *go, L, (const char*)ws->saved, (char*)ws->scratch, st);
   launch_preprocess_bwd(*s, *in, radii, *gi, L, (const char*)ws->saved, (char*)ws->scratch, st);
   HIP_TRY(hipGetLastError());
+  return SGR_OK;
+}
+
+int sgr_query_stats(const SgrWorkspace* ws, int32_t N, int32_t H, int32_t W, const int32_t* radii, int64_t stats_host[4],
+                    void* stream) {
+  if (!ws || !ws->saved || !ws->scratch || !stats_host) return set_error(SGR_ERR_INVALID, "null argument");
+  Layout L = make_layout(N, H, W, ws->capacity);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* d = (unsigned long long*)ws->scratch;
+  HIP_TRY(hipMemsetAsync(d, 0, 32, st));
+  hipLaunchKernelGGL(stats_kernel, dim3(64), dim3(256), 0, st, N, L.ntiles, radii, (const uint2*)((char*)ws->saved + L.o_ranges),
+                     (const uint32_t*)((char*)ws->saved + L.o_tile_maxc), d);
+  unsigned long long h[4];
+  HIP_TRY(hipMemcpyAsync(h, d, 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < 4; ++i) stats_host[i] = (int64_t)h[i];
+  return SGR_OK;
+}
+
+int sgr_profile_enable(uint32_t kind_mask) {
+  g_prof.mask = kind_mask & ((1u << SGR_PROFILE_KINDS) - 1);
+  return SGR_OK;
+}
+
+int sgr_profile_read(float ms_host[SGR_PROFILE_KINDS], int64_t launches_host[SGR_PROFILE_KINDS]) {
+  for (int k = 0; k < SGR_PROFILE_KINDS; ++k) {
+    prof_drain(k);
+    if (ms_host) ms_host[k] = (float)g_prof.ms[k];
+    if (launches_host) launches_host[k] = g_prof.launches[k];
+    g_prof.ms[k] = 0.0;
+    g_prof.launches[k] = 0;
+  }
   return SGR_OK;
 }
 

@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(256) zero_partials_kernel(float4* __restrict__
 void launch_blend_fwd(const SgrSettings& s, const SgrOutputs& out, const Layout& L, char* saved, hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
+  ProfScope prof(PK_BLEND_FWD, st);
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(grid), dim3(256), 0, st, s.image_height, s.image_width, L.gx, L.gy, L.sgx,
                      L.sgy, (const uint2*)(saved + L.o_ranges), (const uint32_t*)(saved + L.o_point_list),
                      (const float2*)(saved + L.o_xy), (const float4*)(saved + L.o_conic_o),
@@ -243,7 +244,11 @@ void launch_blend_bwd(const SgrSettings& s, const SgrGradOutputs& go, const Layo
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
   float4* partials = (float4*)(scratch + L.o_partials);
-  hipLaunchKernelGGL(zero_partials_kernel, dim3(1024), dim3(256), 0, st, partials, (const SavedHeader*)(saved + L.o_hdr));
+  {
+    ProfScope prof(PK_ZERO, st);
+    hipLaunchKernelGGL(zero_partials_kernel, dim3(1024), dim3(256), 0, st, partials, (const SavedHeader*)(saved + L.o_hdr));
+  }
+  ProfScope prof(PK_BLEND_BWD, st);
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), 0, st, s.image_height, s.image_width, L.gx, L.gy, L.sgx,
                      L.sgy, (const uint2*)(saved + L.o_ranges), (const uint32_t*)(saved + L.o_point_list),
                      (const float2*)(saved + L.o_xy), (const float4*)(saved + L.o_conic_o),

@@ -98,6 +98,16 @@ struct Layout {
   }
 };
 
+// ---- optional per-kernel event timing (sgr_profile_enable / sgr_profile_read)
+enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_DUP, PK_SORT, PK_RANGES, PK_BLEND_FWD, PK_ZERO, PK_BLEND_BWD, PK_PRE_BWD };
+void prof_begin(int kind, hipStream_t st);
+void prof_end(int kind, hipStream_t st);
+struct ProfScope {
+  int kind; hipStream_t st;
+  ProfScope(int k, hipStream_t s) : kind(k), st(s) { prof_begin(kind, st); }
+  ~ProfScope() { prof_end(kind, st); }
+};
+
 // ---- tiny fixed-size linear algebra on registers
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {

@@ -493,6 +493,7 @@ void launch_preprocess_fwd(const SgrSettings& s, const SgrInputs& in, const SgrO
                            hipStream_t st) {
   if (s.num_gaussians <= 0) return;
   int blocks = (s.num_gaussians + 255) / 256;
+  ProfScope prof(PK_PRE_FWD, st);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, st, s.num_gaussians, s.image_height,
                      s.image_width, s.sh_degree, s.sh_coeffs, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix,
                      s.projmatrix, s.campos, in.means3D, in.opacities, in.shs, in.colors_precomp, in.scales,
@@ -506,6 +507,7 @@ void launch_preprocess_bwd(const SgrSettings& s, const SgrInputs& in, const int3
   if (s.num_gaussians <= 0) return;
   int blocks = L.pre_blocks;
   float* tau_part = (float*)(scratch + L.o_tau_part);
+  ProfScope prof(PK_PRE_BWD, st);
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(256), 0, st, s.num_gaussians, s.image_height,
                      s.image_width, s.sh_degree, s.sh_coeffs, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix,
                      s.projmatrix, s.projmatrix_raw, s.campos, in.means3D, in.shs, in.colors_precomp, in.scales,

@@ -1,0 +1,346 @@
+"""Gaussian map store + optimiser surgery -- mirror of
+/root/reference/thirdparty/gaussian_splatting/scene/gaussian_model.py:34-742 (same public names and semantics).
+
+What is identical: the six parameter tensors and their activations (:76-101), the Adam groups and learning rates
+(:264-313), the xyz lr schedule (:315-329, general_utils.py:79-94), new-point seeding from an RGB-D frame (:134-219),
+optimiser-state surgery on cat / prune (:519-593), clone / split / prune rules (:639-736), densification statistics
+(:738-742), opacity resets (:382-395).
+
+What differs, on purpose (MI355X-first, documented in DESIGN.md):
+  * no Open3D: back-projection and random down-sampling are torch ops (torch.randperm instead of Open3D's RNG,
+    SURVEY.md 3.6) and the 3-NN distance comes from the HIP `sknn_dist2` (or an injected function);
+  * `unique_kfIDs` / `n_obs` live on the same device as the parameters (the reference keeps them on the CPU and pays
+    a D2H mask copy per densify, :556-557,666-667).
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+C0 = 0.28209479177387814
+
+
+def RGB2SH(rgb):
+    return (rgb - 0.5) / C0
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def helper(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """general_utils.py:79-94."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    if lr_delay_steps > 0:
+        delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+    else:
+        delay_rate = 1.0
+    t = np.clip(step / max_steps, 0, 1)
+    log_lerp = np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+    return delay_rate * log_lerp
+
+
+def build_rotation(r):
+    """general_utils.py:113-136 (normalises, then (w,x,y,z) -> R)."""
+    q = r / torch.sqrt((r * r).sum(dim=1))[:, None]
+    R = torch.zeros((q.size(0), 3, 3), device=r.device, dtype=r.dtype)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z)
+    R[:, 0, 1] = 2 * (x * y - w * z)
+    R[:, 0, 2] = 2 * (x * z + w * y)
+    R[:, 1, 0] = 2 * (x * y + w * z)
+    R[:, 1, 1] = 1 - 2 * (x * x + z * z)
+    R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y)
+    R[:, 2, 1] = 2 * (y * z + w * x)
+    R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+class OptParams:
+    """opt_params block of /root/reference/configs/splat_slam.yaml:63-79."""
+
+    def __init__(self, d=None):
+        d = d or {}
+        self.position_lr_init = d.get("position_lr_init", 0.00016)
+        self.position_lr_final = d.get("position_lr_final", 0.0000016)
+        self.position_lr_delay_mult = d.get("position_lr_delay_mult", 0.01)
+        self.position_lr_max_steps = d.get("position_lr_max_steps", 30000)
+        self.feature_lr = d.get("feature_lr", 0.0025)
+        self.opacity_lr = d.get("opacity_lr", 0.05)
+        self.scaling_lr = d.get("scaling_lr", 0.001)
+        self.rotation_lr = d.get("rotation_lr", 0.001)
+        self.percent_dense = d.get("percent_dense", 0.01)
+        self.lambda_dssim = d.get("lambda_dssim", 0.2)
+        self.densify_from_iter = d.get("densify_from_iter", 500)
+        self.densify_grad_threshold = d.get("densify_grad_threshold", 0.0002)
+
+
+class GaussianModel:
+    def __init__(self, sh_degree: int, config=None, device="cuda", knn_fn=None):
+        self.device = torch.device(device)
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        e = lambda: torch.empty(0, device=self.device)
+        self._xyz, self._features_dc, self._features_rest = e(), e(), e()
+        self._scaling, self._rotation, self._opacity = e(), e(), e()
+        self.max_radii2D, self.xyz_gradient_accum = e(), e()
+        self.unique_kfIDs = torch.empty(0, device=self.device).int()
+        self.n_obs = torch.empty(0, device=self.device).int()
+        self.optimizer = None
+        self.config = config
+        self.isotropic = False
+        self.spatial_lr_scale = 1.0
+        self._knn_fn = knn_fn
+
+    # ---- activations (gaussian_model.py:53-61,76-101)
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    def _knn(self, pts):
+        if self._knn_fn is not None:
+            return self._knn_fn(pts)
+        from simple_knn._C import distCUDA2
+        return distCUDA2(pts)
+
+    # ---- seeding (gaussian_model.py:134-219)
+    def create_pcd_from_image(self, cam, init=False, scale=2.0, depthmap=None):
+        image_ab = torch.clamp(torch.exp(cam.exposure_a) * cam.original_image + cam.exposure_b, 0.0, 1.0)
+        rgb_u8 = (image_ab * 255).byte().permute(1, 2, 0).contiguous()
+        depth = depthmap if depthmap is not None else cam.depth
+        depth = torch.as_tensor(depth, dtype=torch.float32, device=self.device)
+        return self.create_pcd_from_image_and_depth(cam, rgb_u8, depth, init)
+
+    def create_pcd_from_image_and_depth(self, cam, rgb_u8, depth, init=False):
+        cfg = self.config["mapping"]
+        downsample_factor = cfg["pcd_downsample_init"] if init else cfg["pcd_downsample"]
+        point_size = cfg["point_size"]
+        if cfg.get("adaptive_pointsize", False):
+            point_size = min(0.05, point_size * float(torch.median(depth)))
+        H, W = depth.shape
+        valid = (depth > 0) & (depth < 100.0)              # depth_trunc=100, project_valid_depth_only
+        v, u = torch.nonzero(valid, as_tuple=True)
+        d = depth[v, u]
+        pc = torch.stack([(u.float() - cam.cx) * d / cam.fx, (v.float() - cam.cy) * d / cam.fy, d], dim=1)
+        Rw2c, tw2c = cam.R.float(), cam.T.float()
+        pw = (pc - tw2c[None, :]) @ Rw2c                     # R^T (p - t)
+        cols = rgb_u8[v, u].float() / 255.0
+        n_keep = int(pw.shape[0] * (1.0 / downsample_factor))
+        keep = torch.randperm(pw.shape[0], device=self.device)[:n_keep]
+        keep, _ = torch.sort(keep)
+        new_xyz, new_rgb = pw[keep].contiguous(), cols[keep]
+        fused_color = RGB2SH(new_rgb)
+        features = torch.zeros((fused_color.shape[0], 3, (self.max_sh_degree + 1) ** 2), device=self.device)
+        features[:, :3, 0] = fused_color
+        dist2 = torch.clamp_min(self._knn(new_xyz), 0.0000001) * point_size
+        scales = torch.log(torch.sqrt(dist2))[..., None]
+        if not self.isotropic:
+            scales = scales.repeat(1, 3)
+        rots = torch.zeros((new_xyz.shape[0], 4), device=self.device)
+        rots[:, 0] = 1
+        opacities = inverse_sigmoid(0.5 * torch.ones((new_xyz.shape[0], 1), dtype=torch.float, device=self.device))
+        return new_xyz, features, scales, rots, opacities
+
+    def init_lr(self, spatial_lr_scale):
+        self.spatial_lr_scale = spatial_lr_scale
+
+    def extend_from_pcd(self, fused_point_cloud, features, scales, rots, opacities, kf_id):
+        new_xyz = nn.Parameter(fused_point_cloud.requires_grad_(True))
+        new_features_dc = nn.Parameter(features[:, :, 0:1].transpose(1, 2).contiguous().requires_grad_(True))
+        new_features_rest = nn.Parameter(features[:, :, 1:].transpose(1, 2).contiguous().requires_grad_(True))
+        new_scaling = nn.Parameter(scales.requires_grad_(True))
+        new_rotation = nn.Parameter(rots.requires_grad_(True))
+        new_opacity = nn.Parameter(opacities.requires_grad_(True))
+        new_unique_kfIDs = (torch.ones((new_xyz.shape[0]), device=self.device) * kf_id).int()
+        new_n_obs = torch.zeros((new_xyz.shape[0]), device=self.device).int()
+        self.densification_postfix(new_xyz, new_features_dc, new_features_rest, new_opacity, new_scaling, new_rotation,
+                                   new_kf_ids=new_unique_kfIDs, new_n_obs=new_n_obs)
+
+    def extend_from_pcd_seq(self, cam_info, kf_id=-1, init=False, scale=2.0, depthmap=None):
+        self.extend_from_pcd(*self.create_pcd_from_image(cam_info, init, scale=scale, depthmap=depthmap), kf_id)
+
+    # ---- optimiser (gaussian_model.py:264-329)
+    def training_setup(self, training_args):
+        self.percent_dense = training_args.percent_dense
+        n = self.get_xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
+        self.denom = torch.zeros((n, 1), device=self.device)
+        l = [
+            {"params": [self._xyz], "lr": training_args.position_lr_init * self.spatial_lr_scale, "name": "xyz"},
+            {"params": [self._features_dc], "lr": training_args.feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": training_args.feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": training_args.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": training_args.scaling_lr * self.spatial_lr_scale, "name": "scaling"},
+            {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
+        ]
+        self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
+        self.lr_init = training_args.position_lr_init * self.spatial_lr_scale
+        self.lr_final = training_args.position_lr_final * self.spatial_lr_scale
+        self.lr_delay_mult = training_args.position_lr_delay_mult
+        self.max_steps = training_args.position_lr_max_steps
+
+    def update_learning_rate(self, iteration):
+        for param_group in self.optimizer.param_groups:
+            if param_group["name"] == "xyz":
+                lr = helper(iteration, lr_init=self.lr_init, lr_final=self.lr_final, lr_delay_mult=self.lr_delay_mult,
+                            max_steps=self.max_steps)
+                param_group["lr"] = lr
+                return lr
+
+    # ---- opacity resets (gaussian_model.py:382-395)
+    def reset_opacity(self):
+        opacities_new = inverse_sigmoid(torch.ones_like(self.get_opacity) * 0.01)
+        self._opacity = self.replace_tensor_to_optimizer(opacities_new, "opacity")["opacity"]
+
+    def reset_opacity_nonvisible(self, visibility_filters):
+        opacities_new = inverse_sigmoid(torch.ones_like(self.get_opacity) * 0.4)
+        for filter in visibility_filters:
+            opacities_new[filter] = self.get_opacity[filter]
+        self._opacity = self.replace_tensor_to_optimizer(opacities_new, "opacity")["opacity"]
+
+    # ---- optimiser surgery (gaussian_model.py:488-593)
+    def replace_tensor_to_optimizer(self, tensor, name):
+        optimizable_tensors = {}
+        for group in self.optimizer.param_groups:
+            if group["name"] == name:
+                stored_state = self.optimizer.state.get(group["params"][0], None)
+                stored_state["exp_avg"] = torch.zeros_like(tensor)
+                stored_state["exp_avg_sq"] = torch.zeros_like(tensor)
+                del self.optimizer.state[group["params"][0]]
+                group["params"][0] = nn.Parameter(tensor.requires_grad_(True))
+                self.optimizer.state[group["params"][0]] = stored_state
+                optimizable_tensors[group["name"]] = group["params"][0]
+        return optimizable_tensors
+
+    def _prune_optimizer(self, mask):
+        optimizable_tensors = {}
+        for group in self.optimizer.param_groups:
+            stored_state = self.optimizer.state.get(group["params"][0], None)
+            if stored_state is not None:
+                stored_state["exp_avg"] = stored_state["exp_avg"][mask]
+                stored_state["exp_avg_sq"] = stored_state["exp_avg_sq"][mask]
+                del self.optimizer.state[group["params"][0]]
+                group["params"][0] = nn.Parameter((group["params"][0][mask].requires_grad_(True)))
+                self.optimizer.state[group["params"][0]] = stored_state
+            else:
+                group["params"][0] = nn.Parameter(group["params"][0][mask].requires_grad_(True))
+            optimizable_tensors[group["name"]] = group["params"][0]
+        return optimizable_tensors
+
+    def _adopt(self, t):
+        self._xyz, self._features_dc, self._features_rest = t["xyz"], t["f_dc"], t["f_rest"]
+        self._opacity, self._scaling, self._rotation = t["opacity"], t["scaling"], t["rotation"]
+
+    def prune_points(self, mask):
+        valid = ~mask
+        self._adopt(self._prune_optimizer(valid))
+        self.xyz_gradient_accum = self.xyz_gradient_accum[valid]
+        self.denom = self.denom[valid]
+        self.max_radii2D = self.max_radii2D[valid]
+        self.unique_kfIDs = self.unique_kfIDs[valid]
+        self.n_obs = self.n_obs[valid]
+
+    def cat_tensors_to_optimizer(self, tensors_dict):
+        optimizable_tensors = {}
+        for group in self.optimizer.param_groups:
+            assert len(group["params"]) == 1
+            ext = tensors_dict[group["name"]]
+            stored_state = self.optimizer.state.get(group["params"][0], None)
+            if stored_state is not None:
+                stored_state["exp_avg"] = torch.cat((stored_state["exp_avg"], torch.zeros_like(ext)), dim=0)
+                stored_state["exp_avg_sq"] = torch.cat((stored_state["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+                del self.optimizer.state[group["params"][0]]
+                group["params"][0] = nn.Parameter(torch.cat((group["params"][0], ext), dim=0).requires_grad_(True))
+                self.optimizer.state[group["params"][0]] = stored_state
+            else:
+                group["params"][0] = nn.Parameter(torch.cat((group["params"][0], ext), dim=0).requires_grad_(True))
+            optimizable_tensors[group["name"]] = group["params"][0]
+        return optimizable_tensors
+
+    def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling,
+                              new_rotation, new_kf_ids=None, new_n_obs=None):
+        d = {"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest, "opacity": new_opacities,
+             "scaling": new_scaling, "rotation": new_rotation}
+        if self.optimizer is None:
+            # first extension happens before training_setup in the reference too (mapper.py:959-962): the tensors
+            # simply become the parameters
+            t = {k: (nn.Parameter(torch.cat((getattr(self, a), v), dim=0).requires_grad_(True)) if getattr(self, a).numel()
+                     else nn.Parameter(v.detach().clone().requires_grad_(True)))
+                 for (k, v), a in zip(d.items(), ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"])}
+            self._adopt(t)
+        else:
+            self._adopt(self.cat_tensors_to_optimizer(d))
+        n = self.get_xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
+        self.denom = torch.zeros((n, 1), device=self.device)
+        self.max_radii2D = torch.zeros((n), device=self.device)
+        if new_kf_ids is not None:
+            self.unique_kfIDs = torch.cat((self.unique_kfIDs, new_kf_ids.to(self.device))).int()
+        if new_n_obs is not None:
+            self.n_obs = torch.cat((self.n_obs, new_n_obs.to(self.device))).int()
+
+    # ---- densify / prune (gaussian_model.py:639-742)
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+        n_init_points = self.get_xyz.shape[0]
+        padded_grad = torch.zeros((n_init_points), device=self.device)
+        padded_grad[: grads.shape[0]] = grads.squeeze()
+        selected = padded_grad >= grad_threshold
+        selected = torch.logical_and(selected, torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
+        stds = self.get_scaling[selected].repeat(N, 1)
+        means = torch.zeros((stds.size(0), 3), device=self.device)
+        samples = torch.normal(mean=means, std=stds)
+        rots = build_rotation(self._rotation[selected]).repeat(N, 1, 1)
+        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.get_xyz[selected].repeat(N, 1)
+        new_scaling = torch.log(self.get_scaling[selected].repeat(N, 1) / (0.8 * N))
+        new_rotation = self._rotation[selected].repeat(N, 1)
+        new_features_dc = self._features_dc[selected].repeat(N, 1, 1)
+        new_features_rest = self._features_rest[selected].repeat(N, 1, 1)
+        new_opacity = self._opacity[selected].repeat(N, 1)
+        new_kf_id = self.unique_kfIDs[selected].repeat(N)
+        new_n_obs = self.n_obs[selected].repeat(N)
+        self.densification_postfix(new_xyz, new_features_dc, new_features_rest, new_opacity, new_scaling, new_rotation,
+                                   new_kf_ids=new_kf_id, new_n_obs=new_n_obs)
+        prune_filter = torch.cat((selected, torch.zeros(N * int(selected.sum()), device=self.device, dtype=bool)))
+        self.prune_points(prune_filter)
+
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        selected = torch.norm(grads, dim=-1) >= grad_threshold
+        selected = torch.logical_and(selected, torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
+        self.densification_postfix(self._xyz[selected], self._features_dc[selected], self._features_rest[selected],
+                                   self._opacity[selected], self._scaling[selected], self._rotation[selected],
+                                   new_kf_ids=self.unique_kfIDs[selected], new_n_obs=self.n_obs[selected])
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent)
+        prune_mask = (self.get_opacity < min_opacity).squeeze()
+        if max_screen_size:
+            big_points_vs = self.max_radii2D > max_screen_size
+            big_points_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
+            prune_mask = torch.logical_or(torch.logical_or(prune_mask, big_points_vs), big_points_ws)
+        self.prune_points(prune_mask)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1

@@ -1,0 +1,203 @@
+"""Mapping optimisation loops -- mirror of the three loops of /root/reference/src/mapper.py:
+  initialize_map :303-398,  map :400-614,  final_refine :656-708, and the keyframe-optimiser set-up :1067-1111.
+
+The loop bodies keep the reference's order of operations (and its quirks, SURVEY.md 3.7: the prune pass that returns
+before optimizer.step, no lr update during initialisation, numpy RNG in final_refine vs torch RNG in map).
+Everything that the reference's Mapper does around these loops -- the tracker pipe, DepthVideo, map deformation,
+keyframe selection -- is outside this file; `splat_slam_amd.synthetic` feeds the loops with a mapping-only stream.
+"""
+import numpy as np
+import torch
+
+from splat_slam_amd.camera import Camera, getProjectionMatrix2
+from splat_slam_amd.gaussian_model import GaussianModel, OptParams
+from splat_slam_amd.losses import get_loss_mapping, get_loss_mapping_fused
+from splat_slam_amd.pose import update_pose
+from splat_slam_amd.renderer import render
+
+
+class PipelineParams:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+
+
+class MappingLoop:
+    def __init__(self, config, device="cuda:0", fused_loss=True, knn_fn=None):
+        self.config = config
+        self.device = torch.device(device)
+        tr = config["mapping"]["Training"]
+        self.opt_params = OptParams(config["mapping"].get("opt_params"))
+        self.pipeline_params = PipelineParams()
+        self.iteration_count = 0
+        self.occ_aware_visibility = {}
+        self.viewpoints = {}
+        self.current_window = []
+        self.keyframe_optimizers = None
+        sh_degree = 3 if tr.get("spherical_harmonics", False) else 0        # mapper.py:85
+        self.gaussians = GaussianModel(sh_degree, config=config, device=device, knn_fn=knn_fn)
+        self.gaussians.init_lr(6.0)                                          # mapper.py:87
+        self.gaussians.training_setup(self.opt_params)
+        self.background = torch.tensor([0, 0, 0], dtype=torch.float32, device=self.device)
+        self.cameras_extent = 6.0                                            # mapper.py:93
+        self.init_itr_num = tr["init_itr_num"]
+        self.init_gaussian_update = tr["init_gaussian_update"]
+        self.init_gaussian_reset = tr["init_gaussian_reset"]
+        self.init_gaussian_th = tr["init_gaussian_th"]
+        self.init_gaussian_extent = self.cameras_extent * tr["init_gaussian_extent"]
+        self.mapping_itr_num = tr["mapping_itr_num"]
+        self.gaussian_update_every = tr["gaussian_update_every"]
+        self.gaussian_update_offset = tr["gaussian_update_offset"]
+        self.gaussian_th = tr["gaussian_th"]
+        self.gaussian_extent = self.cameras_extent * tr["gaussian_extent"]
+        self.gaussian_reset = tr["gaussian_reset"]
+        self.size_threshold = tr["size_threshold"]
+        self.window_size = tr["window_size"]
+        self.loss_fn = get_loss_mapping_fused if fused_loss else get_loss_mapping
+        self.grad_sync = None
+
+    # mapper.py:841-850
+    def projection_matrix(self, intr):
+        return getProjectionMatrix2(znear=0.01, zfar=100.0, fx=intr["fx"], fy=intr["fy"], cx=intr["cx"], cy=intr["cy"],
+                                    W=intr["W"], H=intr["H"]).transpose(0, 1).to(device=self.device)
+
+    def add_next_kf(self, frame_idx, viewpoint, init=False, scale=2.0, depth_map=None):
+        self.gaussians.extend_from_pcd_seq(viewpoint, kf_id=frame_idx, init=init, scale=scale, depthmap=depth_map)
+
+    def reset(self):
+        self.iteration_count = 0
+        self.occ_aware_visibility = {}
+        self.viewpoints = {}
+        self.current_window = []
+        self.keyframe_optimizers = None
+        self.gaussians.prune_points(self.gaussians.unique_kfIDs >= 0)
+
+    def build_keyframe_optimizers(self):
+        """mapper.py:1067-1111."""
+        opt_params = []
+        frames_to_optimize = self.config["mapping"]["Training"]["pose_window"]
+        lr = self.config["mapping"]["Training"]["lr"]
+        for cam_idx in range(len(self.current_window)):
+            if self.current_window[cam_idx] == 0:
+                continue
+            viewpoint = self.viewpoints[self.current_window[cam_idx]]
+            if not self.config["mapping"]["Training"].get("gt_camera", False) and self.config["mapping"]["BA"]:
+                if cam_idx < frames_to_optimize:
+                    opt_params.append({"params": [viewpoint.cam_rot_delta], "lr": lr["cam_rot_delta"] * 0.5,
+                                       "name": "rot_{}".format(viewpoint.uid)})
+                    opt_params.append({"params": [viewpoint.cam_trans_delta], "lr": lr["cam_trans_delta"] * 0.5,
+                                       "name": "trans_{}".format(viewpoint.uid)})
+            opt_params.append({"params": [viewpoint.exposure_a], "lr": 0.01, "name": "exposure_a_{}".format(viewpoint.uid)})
+            opt_params.append({"params": [viewpoint.exposure_b], "lr": 0.01, "name": "exposure_b_{}".format(viewpoint.uid)})
+        self.keyframe_optimizers = torch.optim.Adam(opt_params) if opt_params else None
+
+    # ---------------------------------------------------------------------------------- mapper.py:303-353
+    def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
+        n_touched = None
+        for mapping_iteration in range(self.init_itr_num if iters is None else iters):
+            self.iteration_count += 1
+            pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
+            image, vsp, vis, radii, depth, opacity, n_touched = (pkg["render"], pkg["viewspace_points"],
+                                                                 pkg["visibility_filter"], pkg["radii"], pkg["depth"],
+                                                                 pkg["opacity"], pkg["n_touched"])
+            loss_init = self.loss_fn(self.config["mapping"], image, depth, viewpoint, opacity, initialization=True)
+            loss_init.backward()
+            with torch.no_grad():
+                self.gaussians.max_radii2D[vis] = torch.max(self.gaussians.max_radii2D[vis], radii[vis])
+                self.gaussians.add_densification_stats(vsp, vis)
+                if mapping_iteration % self.init_gaussian_update == 0:
+                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.init_gaussian_th,
+                                                     self.init_gaussian_extent, None)
+                if self.iteration_count == self.init_gaussian_reset or (
+                        self.iteration_count == self.opt_params.densify_from_iter):
+                    self.gaussians.reset_opacity()
+                self.gaussians.optimizer.step()
+                self.gaussians.optimizer.zero_grad(set_to_none=True)
+        self.occ_aware_visibility[cur_frame_idx] = (n_touched > 0).long()
+        return pkg
+
+    # ---------------------------------------------------------------------------------- mapper.py:400-568
+    def map(self, current_window, prune=False, iters=1):
+        if len(current_window) == 0:
+            return
+        viewpoint_stack = [self.viewpoints[kf_idx] for kf_idx in current_window]
+        frames_to_optimize = self.config["mapping"]["Training"]["pose_window"]
+        current_window_set = set(current_window)
+        random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in current_window_set]
+        pose_opt = bool(self.config["mapping"]["BA"]) and not self.config["mapping"]["Training"].get("gt_camera", False)
+        gaussian_split = False
+        for _ in range(iters):
+            self.iteration_count += 1
+            loss_mapping = 0
+            vsp_acm, vis_acm, radii_acm, n_touched_acm = [], [], [], []
+            for cam_idx in range(len(current_window)):
+                viewpoint = viewpoint_stack[cam_idx]
+                pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
+                loss_mapping += self.loss_fn(self.config["mapping"], pkg["render"], pkg["depth"], viewpoint, pkg["opacity"])
+                vsp_acm.append(pkg["viewspace_points"])
+                vis_acm.append(pkg["visibility_filter"])
+                radii_acm.append(pkg["radii"])
+                n_touched_acm.append(pkg["n_touched"])
+            for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2]:
+                viewpoint = random_viewpoint_stack[cam_idx]
+                pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
+                loss_mapping += self.loss_fn(self.config["mapping"], pkg["render"], pkg["depth"], viewpoint, pkg["opacity"])
+                vsp_acm.append(pkg["viewspace_points"])
+                vis_acm.append(pkg["visibility_filter"])
+                radii_acm.append(pkg["radii"])
+            scaling = self.gaussians.get_scaling
+            isotropic_loss = torch.abs(scaling - scaling.mean(dim=1).view(-1, 1))
+            loss_mapping += 10 * isotropic_loss.mean()
+            loss_mapping.backward()
+            if self.grad_sync is not None:          # multi-GPU: sum the per-rank view gradients (parallel.py)
+                self.grad_sync.reduce()
+            with torch.no_grad():
+                self.occ_aware_visibility = {}
+                for idx in range(len(current_window)):
+                    self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
+                if prune:
+                    # the reference computes `to_prune` here and drops it (mapper.py:502-520): a pass that only
+                    # refreshes occ_aware_visibility and returns before optimizer.step()/zero_grad()
+                    return False
+                for idx in range(len(vsp_acm)):
+                    self.gaussians.max_radii2D[vis_acm[idx]] = torch.max(self.gaussians.max_radii2D[vis_acm[idx]],
+                                                                         radii_acm[idx][vis_acm[idx]])
+                    self.gaussians.add_densification_stats(vsp_acm[idx], vis_acm[idx])
+                update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
+                if update_gaussian:
+                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
+                                                     self.gaussian_extent, self.size_threshold)
+                    gaussian_split = True
+                if (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian):
+                    self.gaussians.reset_opacity_nonvisible(vis_acm)
+                    gaussian_split = True
+                self.gaussians.optimizer.step()
+                self.gaussians.optimizer.zero_grad(set_to_none=True)
+                self.gaussians.update_learning_rate(self.iteration_count)
+                if self.keyframe_optimizers is not None:
+                    self.keyframe_optimizers.step()
+                    self.keyframe_optimizers.zero_grad(set_to_none=True)
+                if pose_opt:       # with mapping.BA False the deltas are never stepped: update_pose is the identity
+                    for cam_idx in range(min(frames_to_optimize, len(current_window))):
+                        viewpoint = viewpoint_stack[cam_idx]
+                        if viewpoint.uid == 0:
+                            continue
+                        update_pose(viewpoint)
+        return gaussian_split
+
+    # ---------------------------------------------------------------------------------- mapper.py:649-708
+    def final_refine(self, iters=26000):
+        random_viewpoint_stack = list(self.viewpoints.values())
+        for _ in range(iters):
+            self.iteration_count += 1
+            rand_idx = np.random.randint(0, len(random_viewpoint_stack))
+            viewpoint = random_viewpoint_stack[rand_idx]
+            pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
+            loss_mapping = self.loss_fn(self.config["mapping"], pkg["render"], pkg["depth"], viewpoint, pkg["opacity"])
+            loss_mapping.backward()
+            with torch.no_grad():
+                self.gaussians.optimizer.step()
+                self.gaussians.optimizer.zero_grad(set_to_none=True)
+                self.gaussians.update_learning_rate(self.iteration_count)
+                if self.keyframe_optimizers is not None:
+                    self.keyframe_optimizers.step()
+                    self.keyframe_optimizers.zero_grad(set_to_none=True)

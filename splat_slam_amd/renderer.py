@@ -1,0 +1,50 @@
+"""render() of the mapping loop -- mirror of
+/root/reference/thirdparty/gaussian_splatting/gaussian_renderer/__init__.py:24-153 (same arguments, same result dict),
+calling the drop-in `diff_gaussian_rasterization` package (HIP)."""
+import math
+
+import torch
+
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, mask=None):
+    if pc.get_xyz.shape[0] == 0:
+        return None
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        projmatrix_raw=viewpoint_camera.projection_matrix, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    means3D = pc.get_xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+    scales = pc.get_scaling.repeat(1, 3) if pc.get_scaling.shape[-1] == 1 else pc.get_scaling
+    rotations = pc.get_rotation
+    shs, colors_precomp = None, None
+    if override_color is not None:
+        colors_precomp = override_color
+    else:
+        shs = pc.get_features
+    if mask is not None:
+        rendered_image, radii, depth, opacity, n_touched = rasterizer(
+            means3D=means3D[mask], means2D=means2D[mask], shs=shs[mask] if shs is not None else None,
+            colors_precomp=colors_precomp[mask] if colors_precomp is not None else None, opacities=opacity[mask],
+            scales=scales[mask], rotations=rotations[mask], cov3D_precomp=None,
+            theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta)
+    else:
+        rendered_image, radii, depth, opacity, n_touched = rasterizer(
+            means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
+            rotations=rotations, cov3D_precomp=None, theta=viewpoint_camera.cam_rot_delta,
+            rho=viewpoint_camera.cam_trans_delta)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth, "opacity": opacity, "n_touched": n_touched}
