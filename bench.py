@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--camera", default="metric", choices=["metric", "replica", "tiny"])
     ap.add_argument("--views", type=int, default=16, help="keyframes in the map (10 window + pool of random views)")
+    ap.add_argument("--loop", default="fused", choices=["fused", "autograd"],
+                    help="fused: autograd-free C-ABI sequence (product path); autograd: torch.autograd mirror of the reference loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="event-time every kernel kind (adds overhead)")
     return ap.parse_args()
@@ -72,7 +74,8 @@ def main():
     params = syn.room_parameters(N, seed=43, device=dev)
     # every rank maps a different set of views of the same room (weak scaling): rotate the orbit by rank
     cams = syn.make_views(params, args.views, intr, dev, seed=43 + rank)
-    loop = MappingLoop(syn.DEFAULT_CONFIG, device=dev, fused_loss=True)
+    from splat_slam_amd.fused import FusedMappingLoop
+    loop = (FusedMappingLoop if args.loop == "fused" else MappingLoop)(syn.DEFAULT_CONFIG, device=dev)
     loop.gaussians = syn.model_from_parameters(params, device=dev)
     loop.viewpoints = {c.uid: c for c in cams}
     loop.current_window = list(range(min(10, args.views)))
@@ -140,7 +143,7 @@ def main():
     render_fwd_ms = timed(fwd_only)
     render_fwd_bwd_ms = timed(fwd_bwd)
 
-    # work counters of one view
+    # work counters of one view (through the drop-in autograd surface, same kernels)
     stats = (C.c_int64 * 4)()
     pkg = render(cam0, loop.gaussians, PipelineParams(), bg)
     fn = pkg["render"].grad_fn
@@ -173,7 +176,7 @@ def main():
         "config": {"workload": "configs[1]-shaped: synthetic room (SURVEY 8d), %d Gaussians, %dx%d, %d views/step "
                                "(10 window + 2 random) fwd+bwd + loss + isotropy + Adam, 1xMI355X per rank"
                                % (N, intr["W"], intr["H"], views_per_step),
-                   "gaussians": N, "width": intr["W"], "height": intr["H"], "views_per_step": views_per_step,
+                   "gaussians": N, "width": intr["W"], "height": intr["H"], "views_per_step": views_per_step, "loop": args.loop,
                    "parallelism": "view-parallel x%d, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
         "render_ms": {"forward": round(render_fwd_ms, 4), "forward_backward_loss": round(render_fwd_bwd_ms, 4)},
         "work_per_view": {"visible_gaussians": V, "tile_pairs_R": R, "tile_pairs_walked_R_eff": R_eff,

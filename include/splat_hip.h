@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 1
+#define SGR_ABI_VERSION 2
 
 typedef enum SgrStatus {
   SGR_OK = 0,
@@ -113,6 +113,17 @@ typedef struct SgrGradInputs {
   float* dL_drotations;        /* [N,4] */
   float* dL_dcov3D_precomp;    /* [N,6] */
   float* dL_dtau;              /* [6] = (rho[3], theta[3]) summed over Gaussians */
+  /* --- fused mapping-loop extensions (all optional; zero / NULL = plain backward) ------------------------------
+   * accumulate != 0: the per-Gaussian gradients above are ADDED to the buffers (only Gaussians with radii > 0 are
+   * touched), so the <= 12 views of one mapping iteration (src/mapper.py:426-490) sum without autograd.
+   * stat_*: densification statistics of add_densification_stats + the max_radii2D update
+   * (gaussian_model.py:738-742, src/mapper.py:522-529), fused into the same pass:
+   *   stat_grad_accum[i] += |dL_dmeans2D[i, :2]|, stat_denom[i] += 1, stat_max_radii[i] = max(., radii[i])
+   *   for every Gaussian with radii > 0. */
+  int32_t accumulate;
+  float* stat_grad_accum;      /* [N] */
+  float* stat_denom;           /* [N] */
+  float* stat_max_radii;       /* [N] */
 } SgrGradInputs;
 
 int sgr_abi_version(void);
@@ -165,6 +176,31 @@ int sgr_mapping_loss(int32_t H, int32_t W, const float* image, const float* dept
  * increment (1 on the first call).  lr may differ per call (update_learning_rate, gaussian_model.py:315-329). */
 int sgr_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
+/* Activations of the GaussianModel getters (gaussian_model.py:76-101) in one pass:
+ * scales_out = exp(scaling), rot_out = rotation / max(|rotation|, 1e-12), opac_out = sigmoid(opacity). */
+int sgr_activate(int64_t n, const float* scaling, const float* rotation, const float* opacity,
+                 float* scales_out, float* rot_out, float* opac_out, void* stream);
+
+/* One fused optimiser step of the mapping loop for all Gaussian parameter groups (src/mapper.py:487-489,557):
+ * takes the gradients wrt the ACTIVATED rasterizer inputs (as accumulated by sgr_backward), applies the chain rule
+ * through exp / sigmoid / normalize, adds the gradient of the isotropy regulariser
+ * iso_weight * mean|s - mean(s)| (0 disables it: initialize_map / final_refine), then runs torch.optim.Adam's update
+ * (eps as given, no weight decay) in place on the raw parameters and their exp_avg / exp_avg_sq, and zeroes the
+ * gradient accumulators for the next iteration.  lr order: xyz, f_dc, opacity, scaling, rotation.
+ * f_dc is [N,3] (sh_degree 0 layout [N,1,3]). */
+typedef struct SgrAdamGroup {
+  float* param;
+  float* grad;                 /* accumulator wrt the activated input; zeroed on return */
+  float* exp_avg;
+  float* exp_avg_sq;
+  float lr;
+  int32_t skip;                /* != 0: leave param/moments untouched, only zero the accumulator (a group whose
+                                  tensor was just replaced has grad None in the reference: Adam skips it) */
+  int64_t step;                /* this group's Adam step count AFTER increment (>= 1 unless skip) */
+} SgrAdamGroup;
+int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps,
+                           float iso_weight, void* stream);
 
 /* simple_knn distCUDA2: mean squared distance to the 3 nearest neighbours (self excluded). */
 size_t sknn_scratch_bytes(int32_t n);

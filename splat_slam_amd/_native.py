@@ -42,7 +42,13 @@ class SgrGradOutputs(C.Structure):
 class SgrGradInputs(C.Structure):
     _fields_ = [("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dopacities", _fp), ("dL_dshs", _fp),
                 ("dL_dcolors_precomp", _fp), ("dL_dscales", _fp), ("dL_drotations", _fp), ("dL_dcov3D_precomp", _fp),
-                ("dL_dtau", _fp)]
+                ("dL_dtau", _fp), ("accumulate", C.c_int32), ("stat_grad_accum", _fp), ("stat_denom", _fp),
+                ("stat_max_radii", _fp)]
+
+
+class SgrAdamGroup(C.Structure):
+    _fields_ = [("param", _fp), ("grad", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp), ("lr", C.c_float), ("skip", C.c_int32),
+                ("step", C.c_int64)]
 
 
 # name -> (restype, argtypes); must list every symbol include/splat_hip.h declares (tests/test_abi.py checks)
@@ -63,6 +69,8 @@ SIGNATURES = {
                                    C.c_float, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "sgr_adam_step": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int64, _fp]),
+    "sgr_activate": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "sgr_gaussian_adam_step": (C.c_int, [C.c_int64, C.POINTER(SgrAdamGroup), C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
     "sknn_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "sknn_dist2": (C.c_int, [_fp, C.c_int32, _fp, _fp, C.c_size_t, _fp]),
     "se3_exp": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
@@ -90,7 +98,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.sgr_abi_version() != 1:
+        if h.sgr_abi_version() != 2:
             raise ImportError("libsplat_hip.so ABI version mismatch")
         _lib = h
     return _lib

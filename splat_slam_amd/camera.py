@@ -67,7 +67,7 @@ class Camera(nn.Module):
         self.cam_trans_delta = nn.Parameter(torch.zeros(3, requires_grad=True, device=device))
         self.exposure_a = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
         self.exposure_b = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
-        self.projection_matrix = projection_matrix.to(device=device)
+        self.projection_matrix = projection_matrix.to(device=device).contiguous()   # raw pointers are handed to the C ABI
         self._cache = None
 
     @staticmethod

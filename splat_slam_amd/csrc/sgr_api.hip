@@ -252,6 +252,8 @@ int sgr_backward(const SgrSettings* s, const SgrInputs* in, const int32_t* radii
   if (N < 0 || H <= 0 || W <= 0 || ws->capacity <= 0) return set_error(SGR_ERR_INVALID, "bad sizes");
   if (!go->dL_dcolor) return set_error(SGR_ERR_INVALID, "dL_dcolor is required");
   if (N > 0 && !radii) return set_error(SGR_ERR_INVALID, "radii is required");
+  if (gi->stat_grad_accum && (!gi->stat_denom || !gi->stat_max_radii))
+    return set_error(SGR_ERR_INVALID, "stat_grad_accum needs stat_denom and stat_max_radii");
   Layout L = make_layout(N, H, W, ws->capacity);
   if (int rc = check_common(s, ws, L)) return rc;
   hipStream_t st = (hipStream_t)stream;

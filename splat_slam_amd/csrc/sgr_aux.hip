@@ -90,6 +90,111 @@ __global__ void __launch_bounds__(256) adam_kernel(int64_t n, float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused map step
+__global__ void __launch_bounds__(256) activate_kernel(int64_t n, const float* __restrict__ scaling,
+                                                       const float* __restrict__ rotation, const float* __restrict__ opacity,
+                                                       float* __restrict__ s_out, float* __restrict__ r_out,
+                                                       float* __restrict__ o_out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (s_out) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_out[3 * i + k] = expf(scaling[3 * i + k]);
+  }
+  if (r_out) {
+    float4 q = *(const float4*)(rotation + 4 * i);
+    float nn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    *(float4*)(r_out + 4 * i) = make_float4(q.x / nn, q.y / nn, q.z / nn, q.w / nn);
+  }
+  if (o_out) o_out[i] = 1.f / (1.f + expf(-opacity[i]));
+}
+
+struct AdamConst { float b1, b2, eps; float bc2_sqrt[5], step_size[5]; };
+struct AdamGroups { SgrAdamGroup g[5]; };   // xyz, f_dc, opacity, scaling, rotation
+#define adam_update(p, g, m, v, GRP, c)                      \
+  do {                                                       \
+    m = m + (g - m) * (1.f - c.b1);                          \
+    v = v * c.b2 + (1.f - c.b2) * g * g;                     \
+    float denom_ = sqrtf(v) / c.bc2_sqrt[GRP] + c.eps;       \
+    p = p - c.step_size[GRP] * (m / denom_);                 \
+  } while (0)
+
+__global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroups G, AdamConst c, float iso_coef) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // xyz and f_dc: identity activations
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) {
+    const SgrAdamGroup& A = G.g[grp];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int64_t j = 3 * i + k;
+      float g = A.grad[j], p = A.param[j], m = A.exp_avg[j], v = A.exp_avg_sq[j];
+      A.grad[j] = 0.f;
+      if (A.skip) continue;
+      adam_update(p, g, m, v, grp, c);
+      A.param[j] = p; A.exp_avg[j] = m; A.exp_avg_sq[j] = v;
+    }
+  }
+  {   // opacity: sigmoid
+    const SgrAdamGroup& A = G.g[2];
+    float p = A.param[i], m = A.exp_avg[i], v = A.exp_avg_sq[i];
+    float sg = 1.f / (1.f + expf(-p));
+    float g = A.grad[i] * sg * (1.f - sg);
+    A.grad[i] = 0.f;
+    if (!A.skip) {
+      adam_update(p, g, m, v, 2, c);
+      A.param[i] = p; A.exp_avg[i] = m; A.exp_avg_sq[i] = v;
+    }
+  }
+  {   // scaling: exp, plus d/ds of iso_weight * mean_{N,3} |s - mean_3(s)|
+    const SgrAdamGroup& A = G.g[3];
+    float p[3], s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { p[k] = A.param[3 * i + k]; s[k] = expf(p[k]); }
+    float mean = (s[0] + s[1] + s[2]) / 3.f;
+    float sg[3], ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { float d = s[k] - mean; sg[k] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); ssum += sg[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int64_t j = 3 * i + k;
+      float gs = A.grad[j] + iso_coef * (sg[k] - ssum / 3.f);
+      float g = gs * s[k];
+      float pp = p[k], m = A.exp_avg[j], v = A.exp_avg_sq[j];
+      A.grad[j] = 0.f;
+      if (A.skip) continue;
+      adam_update(pp, g, m, v, 3, c);
+      A.param[j] = pp; A.exp_avg[j] = m; A.exp_avg_sq[j] = v;
+    }
+  }
+  {   // rotation: x / max(|x|, 1e-12)
+    const SgrAdamGroup& A = G.g[4];
+    float4 x = *(const float4*)(A.param + 4 * i), gy = *(const float4*)(A.grad + 4 * i);
+    float4 m = *(const float4*)(A.exp_avg + 4 * i), v = *(const float4*)(A.exp_avg_sq + 4 * i);
+    float nrm = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
+    float gx[4];
+    if (nrm > 1e-12f) {
+      float inv = 1.f / nrm;
+      float y[4] = {x.x * inv, x.y * inv, x.z * inv, x.w * inv};
+      float dot = y[0] * gy.x + y[1] * gy.y + y[2] * gy.z + y[3] * gy.w;
+      gx[0] = (gy.x - y[0] * dot) * inv; gx[1] = (gy.y - y[1] * dot) * inv;
+      gx[2] = (gy.z - y[2] * dot) * inv; gx[3] = (gy.w - y[3] * dot) * inv;
+    } else {
+      gx[0] = gy.x * 1e12f; gx[1] = gy.y * 1e12f; gx[2] = gy.z * 1e12f; gx[3] = gy.w * 1e12f;
+    }
+    float pp[4] = {x.x, x.y, x.z, x.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
+    *(float4*)(A.grad + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!A.skip) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) adam_update(pp[k], gx[k], mm[k], vv[k], 4, c);
+      *(float4*)(A.param + 4 * i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      *(float4*)(A.exp_avg + 4 * i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      *(float4*)(A.exp_avg_sq + 4 * i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ 3-NN
 struct Top3 { float a, b, c; };
 __device__ __forceinline__ void top3_push(Top3& t, float d) {
@@ -312,6 +417,37 @@ int sgr_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq,
                      beta1, beta2, eps, step_size, bc2_sqrt);
   return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "adam launch failed");
+}
+
+int sgr_activate(int64_t n, const float* scaling, const float* rotation, const float* opacity, float* scales_out,
+                 float* rot_out, float* opac_out, void* stream) {
+  if (n < 0 || (scales_out && !scaling) || (rot_out && !rotation) || (opac_out && !opacity))
+    return set_error(SGR_ERR_INVALID, "activate: null input for a requested output");
+  if (n == 0) return SGR_OK;
+  hipLaunchKernelGGL(activate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, scaling, rotation,
+                     opacity, scales_out, rot_out, opac_out);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "activate launch failed");
+}
+
+int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight,
+                           void* stream) {
+  if (n < 0 || !groups) return set_error(SGR_ERR_INVALID, "gaussian_adam: bad argument");
+  if (n == 0) return SGR_OK;
+  AdamGroups G;
+  AdamConst c;
+  c.b1 = beta1; c.b2 = beta2; c.eps = eps;
+  for (int k = 0; k < 5; ++k) {
+    G.g[k] = groups[k];
+    if (!G.g[k].grad || (!G.g[k].skip && (!G.g[k].param || !G.g[k].exp_avg || !G.g[k].exp_avg_sq || G.g[k].step < 1)))
+      return set_error(SGR_ERR_INVALID, "gaussian_adam: null pointer / bad step in group %d", k);
+    int64_t st = G.g[k].step < 1 ? 1 : G.g[k].step;
+    double bc1 = 1.0 - std::pow((double)beta1, (double)st), bc2 = 1.0 - std::pow((double)beta2, (double)st);
+    c.bc2_sqrt[k] = (float)std::sqrt(bc2);
+    c.step_size[k] = (float)((double)G.g[k].lr / bc1);
+  }
+  float iso_coef = iso_weight / (3.f * (float)n);
+  hipLaunchKernelGGL(gaussian_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, G, c, iso_coef);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "gaussian_adam launch failed");
 }
 
 size_t sknn_scratch_bytes(int32_t n) { return n <= 0 ? 256 : (size_t)knn_splits(n) * (size_t)n * sizeof(Top3) + 256; }

@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     const uint8_t* __restrict__ clamped_in, const float4* __restrict__ partials, int64_t cap,
     float* __restrict__ dmeans3D, float* __restrict__ dmeans2D, float* __restrict__ dopac, float* __restrict__ dshs,
     float* __restrict__ dcolors, float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D,
-    float* __restrict__ tau_part) {
+    float* __restrict__ tau_part, int accumulate, float* __restrict__ stat_accum, float* __restrict__ stat_denom,
+    float* __restrict__ stat_maxr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   bool live = (i < N) && (radii[i] > 0);
@@ -349,15 +350,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 
     // ---- colour
     if (colors_precomp) {
-      if (dcolors) { dcolors[3 * i] = g_rgb[0]; dcolors[3 * i + 1] = g_rgb[1]; dcolors[3 * i + 2] = g_rgb[2]; }
+      if (dcolors) {
+        if (accumulate) { dcolors[3 * i] += g_rgb[0]; dcolors[3 * i + 1] += g_rgb[1]; dcolors[3 * i + 2] += g_rgb[2]; }
+        else { dcolors[3 * i] = g_rgb[0]; dcolors[3 * i + 1] = g_rgb[1]; dcolors[3 * i + 2] = g_rgb[2]; }
+      }
     } else {
       unsigned cl = clamped_in[i];
       float dc[3] = {(cl & 1u) ? 0.f : g_rgb[0], (cl & 2u) ? 0.f : g_rgb[1], (cl & 4u) ? 0.f : g_rgb[2]};
       float* out = dshs ? dshs + (size_t)i * M * 3 : nullptr;
       if (deg == 0) {
         if (out) {
-          out[0] = SH_C0 * dc[0]; out[1] = SH_C0 * dc[1]; out[2] = SH_C0 * dc[2];
-          for (int k = 3; k < M * 3; ++k) out[k] = 0.f;
+          if (accumulate) {
+            out[0] += SH_C0 * dc[0]; out[1] += SH_C0 * dc[1]; out[2] += SH_C0 * dc[2];
+          } else {
+            out[0] = SH_C0 * dc[0]; out[1] = SH_C0 * dc[1]; out[2] = SH_C0 * dc[2];
+            for (int k = 3; k < M * 3; ++k) out[k] = 0.f;
+          }
         }
       } else {
         const float* sh = shs + (size_t)i * M * 3;
@@ -394,7 +402,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
         for (int k = 0; k < M; ++k) {
           float bk = k < K ? basis[k] : 0.f;
           for (int ch = 0; ch < 3; ++ch) {
-            if (out) out[k * 3 + ch] = bk * dc[ch];
+            if (out) { if (accumulate) out[k * 3 + ch] += bk * dc[ch]; else out[k * 3 + ch] = bk * dc[ch]; }
             if (k < K) {
               float coef = sh[k * 3 + ch] * dc[ch];
               ddir[0] += dbx[k] * coef; ddir[1] += dby[k] * coef; ddir[2] += dbz[k] * coef;
@@ -439,7 +447,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
       g_q[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
       g_q[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
     }
-  } else if (i < N) {
+  } else if (i < N && !accumulate) {
     if (!colors_precomp && dshs) {
       float* out = dshs + (size_t)i * M * 3;
       for (int k = 0; k < M * 3; ++k) out[k] = 0.f;
@@ -447,7 +455,18 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     if (colors_precomp && dcolors) { dcolors[3 * i] = 0.f; dcolors[3 * i + 1] = 0.f; dcolors[3 * i + 2] = 0.f; }
   }
 
-  if (i < N) {
+  if (live && accumulate) {
+    // fused mapping loop: only visible Gaussians are touched, the <= 12 views of an iteration add up in place
+    if (dmeans3D) { dmeans3D[3 * i] += g_p[0]; dmeans3D[3 * i + 1] += g_p[1]; dmeans3D[3 * i + 2] += g_p[2]; }
+    if (dmeans2D) { dmeans2D[3 * i] += g_m2[0]; dmeans2D[3 * i + 1] += g_m2[1]; }
+    if (dopac) dopac[i] += g_op;
+    if (dscales) { dscales[3 * i] += g_s[0]; dscales[3 * i + 1] += g_s[1]; dscales[3 * i + 2] += g_s[2]; }
+    if (drots) { drots[4 * i] += g_q[0]; drots[4 * i + 1] += g_q[1]; drots[4 * i + 2] += g_q[2]; drots[4 * i + 3] += g_q[3]; }
+    if (dcov3D) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dcov3D[6 * i + k] += g_S6[k];
+    }
+  } else if (i < N && !accumulate) {
     if (dmeans3D) { dmeans3D[3 * i] = g_p[0]; dmeans3D[3 * i + 1] = g_p[1]; dmeans3D[3 * i + 2] = g_p[2]; }
     if (dmeans2D) { dmeans2D[3 * i] = g_m2[0]; dmeans2D[3 * i + 1] = g_m2[1]; dmeans2D[3 * i + 2] = 0.f; }
     if (dopac) dopac[i] = g_op;
@@ -457,6 +476,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < 6; ++k) dcov3D[6 * i + k] = g_S6[k];
     }
+  }
+  if (live && stat_accum) {
+    stat_accum[i] += sqrtf(g_m2[0] * g_m2[0] + g_m2[1] * g_m2[1]);
+    stat_denom[i] += 1.f;
+    stat_maxr[i] = fmaxf(stat_maxr[i], (float)radii[i]);
   }
 
   // block reduction of the pose gradient: DPP inside each wave, fixed order across the 4 waves
@@ -514,7 +538,9 @@ void launch_preprocess_bwd(const SgrSettings& s, const SgrInputs& in, const int3
                      in.rotations, in.cov3D_precomp, radii, (const uint32_t*)(saved + L.o_offsets),
                      (const uint32_t*)(saved + L.o_touched), (const uint8_t*)(saved + L.o_clamped),
                      (const float4*)(scratch + L.o_partials), L.cap, g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dopacities,
-                     g.dL_dshs, g.dL_dcolors_precomp, g.dL_dscales, g.dL_drotations, g.dL_dcov3D_precomp, tau_part);
+                     g.dL_dshs, g.dL_dcolors_precomp, g.dL_dscales, g.dL_drotations, g.dL_dcov3D_precomp, tau_part,
+                     g.accumulate, g.stat_grad_accum, (g.stat_grad_accum ? g.stat_denom : nullptr),
+                     (g.stat_grad_accum ? g.stat_max_radii : nullptr));
   if (g.dL_dtau)
     hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(384), 0, st, tau_part, blocks, g.dL_dtau);
 }

@@ -1,0 +1,331 @@
+"""Autograd-free mapping loops for MI355X: the same three loops as splat_slam_amd.mapper.MappingLoop
+(/root/reference/src/mapper.py:303-353, 400-568, 656-708) executed as a flat sequence of C-ABI calls per iteration
+
+    sgr_activate                                    (exp / normalize / sigmoid of the GaussianModel getters, once)
+    per view:  sgr_forward (async) -> sgr_mapping_loss -> sgr_backward(accumulate + densification stats)
+    sgr_gaussian_adam_step                          (activation chain rule + isotropy term + Adam, all groups, one pass)
+
+instead of ~60 eager torch kernels and an autograd graph per view.  Nothing on this path synchronises with the host:
+outputs, saved blocks and gradient accumulators are persistent device buffers sized once per map size (HBM is 288 GB;
+re-allocation only happens when densify/prune changes N), the pair capacity of every camera is learned by one
+synchronous forward and re-checked every `check_every` iterations.
+
+Numerically this is the same computation as the autograd loop (tests/test_gpu_fused.py compares parameter
+trajectories); the order of fp32 additions differs (views are accumulated in place instead of by autograd).
+
+Deliberate deviation: the reference's `map(prune=True)` pass runs a full backward whose only
+lasting effect is a stale `.grad` on the exposure parameters; here the prune pass is forward-only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from splat_slam_amd import _native as nat
+from splat_slam_amd.mapper import MappingLoop, PipelineParams
+from splat_slam_amd.pose import update_pose
+
+_GROUPS = ["xyz", "f_dc", "opacity", "scaling", "rotation"]     # order expected by sgr_gaussian_adam_step
+
+
+class _ViewBuffers:
+    def __init__(self, H, W, N, dev):
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        self.color, self.depth, self.opacity = f(3, H, W), f(1, H, W), f(1, H, W)
+        self.radii = torch.empty(N, dtype=torch.int32, device=dev)
+        self.n_touched = torch.empty(N, dtype=torch.int32, device=dev)
+        self.d_color, self.d_depth = f(3, H, W), f(1, H, W)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.d_exp = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.d_tau = torch.zeros(6, dtype=torch.float32, device=dev)
+        self.loss_scratch = torch.empty(1024 * 16, dtype=torch.uint8, device=dev)
+        self.saved = None
+        self.capacity = 0
+        self.gt_depth = None
+        self.depth_src = None
+
+
+class FusedMappingLoop(MappingLoop):
+    def __init__(self, config, device="cuda:0", knn_fn=None, check_every=50):
+        super().__init__(config, device=device, fused_loss=True, knn_fn=knn_fn)
+        self.lib = nat.lib()
+        self.check_every = check_every
+        self.overflow_events = 0
+        self._views = {}
+        self._acc = None          # gradient accumulators wrt activated inputs + activated copies
+        self._acc_key = None
+        self._scratch = None
+        self._since_check = 0
+        self.last_losses = []
+
+    # ------------------------------------------------------------------------------------------------ state
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ensure_state(self):
+        gm = self.gaussians
+        key = (gm._xyz.data_ptr(), gm._xyz.shape[0])
+        if self._acc_key == key:
+            return
+        N, dev = gm._xyz.shape[0], self.device
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self._acc = {"xyz": z(N, 3), "f_dc": z(N, 1, 3), "opacity": z(N, 1), "scaling": z(N, 3), "rotation": z(N, 4),
+                     "act_scale": z(N, 3), "act_rot": z(N, 4), "act_opac": z(N, 1)}
+        self._acc_key = key
+        self._views = {}           # N changed: per-camera buffers are re-made lazily
+        if gm.active_sh_degree != 0 or gm._features_rest.numel() != 0:
+            raise NotImplementedError("FusedMappingLoop supports the reference's default sh_degree 0 (mapper.py:85)")
+        for g in gm.optimizer.param_groups:          # make sure Adam state exists exactly like torch would create it
+            p = g["params"][0]
+            st = gm.optimizer.state.get(p)
+            if st is None or len(st) == 0:
+                gm.optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(p),
+                                         "exp_avg_sq": torch.zeros_like(p)}
+
+    def _view(self, cam):
+        vb = self._views.get(cam.uid)
+        if vb is None:
+            vb = _ViewBuffers(int(cam.image_height), int(cam.image_width), self.gaussians._xyz.shape[0], self.device)
+            self._views[cam.uid] = vb
+        if vb.gt_depth is None or vb.depth_src is not cam.depth:     # ground-truth depth stays resident on the device
+            d = cam.depth
+            d = torch.as_tensor(d) if not torch.is_tensor(d) else d
+            vb.gt_depth = d.to(device=self.device, dtype=torch.float32).contiguous()
+            vb.depth_src = cam.depth
+        return vb
+
+    def _settings(self, cam, N):
+        import math
+        s = nat.SgrSettings()
+        s.num_gaussians, s.image_height, s.image_width = N, int(cam.image_height), int(cam.image_width)
+        s.sh_degree, s.sh_coeffs = 0, 1
+        s.tanfovx, s.tanfovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        s.scale_modifier, s.prefiltered, s.debug = 1.0, 0, 0
+        view, full, center = cam._matrices()
+        s.bg, s.viewmatrix, s.projmatrix = self.background.data_ptr(), view.data_ptr(), full.data_ptr()
+        if not cam.projection_matrix.is_contiguous():
+            cam.projection_matrix = cam.projection_matrix.contiguous()
+        s.projmatrix_raw, s.campos = cam.projection_matrix.data_ptr(), center.data_ptr()
+        return s
+
+    def _workspace(self, vb, N, H, W, cap):
+        sb, tb = self.lib.sgr_saved_bytes(N, H, W, cap), self.lib.sgr_scratch_bytes(N, H, W, cap)
+        if vb.saved is None or vb.saved.numel() < sb or vb.capacity != cap:
+            vb.saved = torch.empty(sb, dtype=torch.uint8, device=self.device)
+            vb.capacity = cap
+        if self._scratch is None or self._scratch.numel() < tb:
+            self._scratch = torch.empty(tb, dtype=torch.uint8, device=self.device)
+        return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), self._scratch.data_ptr(), self._scratch.numel(), cap)
+
+    # ------------------------------------------------------------------------------------------------ pieces
+    def _activate(self):
+        gm, a = self.gaussians, self._acc
+        nat.check(self.lib.sgr_activate(gm._xyz.shape[0], gm._scaling.data_ptr(), gm._rotation.data_ptr(),
+                                        gm._opacity.data_ptr(), a["act_scale"].data_ptr(), a["act_rot"].data_ptr(),
+                                        a["act_opac"].data_ptr(), self._stream()), "sgr_activate")
+
+    def _forward(self, cam, vb):
+        gm, a = self.gaussians, self._acc
+        N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
+        s = self._settings(cam, N)
+        inp = nat.SgrInputs(gm._xyz.data_ptr(), a["act_opac"].data_ptr(), gm._features_dc.data_ptr(), None,
+                            a["act_scale"].data_ptr(), a["act_rot"].data_ptr(), None)
+        out = nat.SgrOutputs(vb.color.data_ptr(), vb.depth.data_ptr(), vb.opacity.data_ptr(), vb.radii.data_ptr(),
+                             vb.n_touched.data_ptr())
+        if vb.capacity == 0:        # first render of this camera at this map size: learn the pair count (one sync)
+            cap, R = 1 << 16, C.c_int64(0)
+            while True:
+                ws = self._workspace(vb, N, H, W, cap)
+                rc = self.lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(R), self._stream())
+                if rc == nat.SGR_ERR_CAPACITY:
+                    cap = int(R.value * 1.25) + 1024
+                    continue
+                nat.check(rc, "sgr_forward")
+                break
+            want = max(1 << 16, int(R.value * 2))
+            if want != cap:
+                ws = self._workspace(vb, N, H, W, want)   # re-size for the async steady state and render again
+                nat.check(self.lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), None, self._stream()),
+                          "sgr_forward")
+        else:
+            ws = self._workspace(vb, N, H, W, vb.capacity)
+            nat.check(self.lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), None, self._stream()),
+                      "sgr_forward")
+        return s, inp, ws
+
+    def _view_step(self, cam, initialization=False, stats=True):
+        gm, a = self.gaussians, self._acc
+        vb = self._view(cam)
+        s, inp, ws = self._forward(cam, vb)
+        H, W = int(cam.image_height), int(cam.image_width)
+        tr = self.config["mapping"]["Training"]
+        ea = None if initialization else cam.exposure_a.data_ptr()
+        eb = None if initialization else cam.exposure_b.data_ptr()
+        nat.check(self.lib.sgr_mapping_loss(H, W, vb.color.data_ptr(), vb.depth.data_ptr(), cam.original_image.data_ptr(),
+                                            vb.gt_depth.data_ptr(), ea, eb, float(tr.get("alpha", 0.95)),
+                                            float(tr["rgb_boundary_threshold"]), 1.0, vb.loss.data_ptr(),
+                                            vb.d_color.data_ptr(), vb.d_depth.data_ptr(), vb.d_exp.data_ptr(),
+                                            vb.d_exp.data_ptr() + 4, vb.loss_scratch.data_ptr(), vb.loss_scratch.numel(),
+                                            self._stream()), "sgr_mapping_loss")
+        go = nat.SgrGradOutputs(vb.d_color.data_ptr(), vb.d_depth.data_ptr())
+        gi = nat.SgrGradInputs(a["xyz"].data_ptr(), None, a["opacity"].data_ptr(), a["f_dc"].data_ptr(), None,
+                               a["scaling"].data_ptr(), a["rotation"].data_ptr(), None, vb.d_tau.data_ptr(), 1,
+                               gm.xyz_gradient_accum.data_ptr() if stats else None,
+                               gm.denom.data_ptr() if stats else None, gm.max_radii2D.data_ptr() if stats else None)
+        nat.check(self.lib.sgr_backward(C.byref(s), C.byref(inp), vb.radii.data_ptr(), C.byref(go), C.byref(gi), C.byref(ws),
+                                        self._stream()), "sgr_backward")
+        return vb
+
+    def _adam(self, iso_weight, skip=()):
+        gm, a = self.gaussians, self._acc
+        groups = (nat.SgrAdamGroup * 5)()
+        by_name = {g["name"]: g for g in gm.optimizer.param_groups}
+        for k, name in enumerate(_GROUPS):
+            g = by_name[name]
+            p = g["params"][0]
+            st = gm.optimizer.state[p]
+            sk = name in skip
+            if not sk:
+                st["step"] += 1
+            groups[k] = nat.SgrAdamGroup(p.data_ptr(), a[name].data_ptr(), st["exp_avg"].data_ptr(),
+                                         st["exp_avg_sq"].data_ptr(), float(g["lr"]), int(sk), int(st["step"].item()) if not sk else 0)
+        fr = by_name["f_rest"]                      # empty at sh_degree 0: torch would still count its step
+        st = gm.optimizer.state[fr["params"][0]]
+        st["step"] += 1
+        b1, b2 = gm.optimizer.param_groups[0]["betas"]
+        nat.check(self.lib.sgr_gaussian_adam_step(gm._xyz.shape[0], groups, b1, b2, gm.optimizer.param_groups[0]["eps"],
+                                                  float(iso_weight), self._stream()), "sgr_gaussian_adam_step")
+
+    def _exposure_step(self, cams):
+        if self.keyframe_optimizers is None:
+            return
+        in_opt = {id(p) for g in self.keyframe_optimizers.param_groups for p in g["params"]}
+        for cam in cams:
+            vb = self._views[cam.uid]
+            if id(cam.exposure_a) in in_opt:
+                cam.exposure_a.grad = vb.d_exp[0:1].clone()
+                cam.exposure_b.grad = vb.d_exp[1:2].clone()
+            if id(cam.cam_rot_delta) in in_opt:
+                cam.cam_trans_delta.grad = vb.d_tau[:3].clone()
+                cam.cam_rot_delta.grad = vb.d_tau[3:].clone()
+        self.keyframe_optimizers.step()
+        self.keyframe_optimizers.zero_grad(set_to_none=True)
+
+    def check_overflow(self):
+        """One synchronisation: did any camera's forward exceed its pair capacity since the last check?"""
+        self._since_check = 0
+        for uid, vb in self._views.items():
+            if vb.saved is None:
+                continue
+            R, ov = C.c_int64(0), C.c_int32(0)
+            nat.check(self.lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), self._stream()), "sgr_query")
+            if ov.value or R.value * 1.5 > vb.capacity:
+                self.overflow_events += int(bool(ov.value))
+                vb.capacity = max(1 << 16, int(R.value * 2))
+                vb.saved = None
+
+    def _tick(self):
+        self._since_check += 1
+        if self._since_check >= self.check_every:
+            self.check_overflow()
+
+    # ------------------------------------------------------------------------------------------------ loops
+    def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
+        vb = None
+        for mapping_iteration in range(self.init_itr_num if iters is None else iters):
+            self.iteration_count += 1
+            self._ensure_state()
+            self._activate()
+            vb = self._view_step(viewpoint, initialization=True, stats=True)
+            skip, densified = (), False
+            with torch.no_grad():
+                if mapping_iteration % self.init_gaussian_update == 0:
+                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.init_gaussian_th,
+                                                     self.init_gaussian_extent, None)
+                    densified = True
+                if self.iteration_count == self.init_gaussian_reset or (
+                        self.iteration_count == self.opt_params.densify_from_iter):
+                    self.gaussians.reset_opacity()
+                    skip = ("opacity",)
+            if densified:
+                # every parameter tensor was re-created: in the reference their .grad is None and Adam skips them all
+                self._acc_key = None
+                continue
+            self._adam(0.0, skip=skip)
+            self._tick()
+        # like the reference, visibility comes from the LAST iteration's render (mapper.py:355)
+        self.occ_aware_visibility[cur_frame_idx] = (vb.n_touched > 0).long()
+        return {"render": vb.color, "depth": vb.depth, "opacity": vb.opacity, "radii": vb.radii, "n_touched": vb.n_touched}
+
+    def map(self, current_window, prune=False, iters=1):
+        if len(current_window) == 0:
+            return
+        viewpoint_stack = [self.viewpoints[kf_idx] for kf_idx in current_window]
+        frames_to_optimize = self.config["mapping"]["Training"]["pose_window"]
+        cw = set(current_window)
+        random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in cw]
+        pose_opt = bool(self.config["mapping"]["BA"]) and not self.config["mapping"]["Training"].get("gt_camera", False)
+        gaussian_split = False
+        for _ in range(iters):
+            self.iteration_count += 1
+            self._ensure_state()
+            self._activate()
+            if prune:
+                self.occ_aware_visibility = {}
+                for kf_idx, cam in zip(current_window, viewpoint_stack):
+                    vb = self._view(cam)
+                    self._forward(cam, vb)
+                    self.occ_aware_visibility[kf_idx] = (vb.n_touched > 0).long()
+                return False
+            used = []
+            for cam in viewpoint_stack:
+                self._view_step(cam)
+                used.append(cam)
+            for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2]:
+                cam = random_viewpoint_stack[cam_idx]
+                self._view_step(cam)
+                used.append(cam)
+            self.last_losses = [self._views[c.uid].loss for c in used]
+            with torch.no_grad():
+                self.occ_aware_visibility = {}
+                for kf_idx, cam in zip(current_window, viewpoint_stack):
+                    self.occ_aware_visibility[kf_idx] = (self._views[cam.uid].n_touched > 0).long()
+                update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
+                skip = ()
+                if update_gaussian:
+                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
+                                                     self.gaussian_extent, self.size_threshold)
+                    gaussian_split = True
+                    self._acc_key = None
+                if (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian):
+                    self.gaussians.reset_opacity_nonvisible([self._views[c.uid].radii > 0 for c in used])
+                    gaussian_split = True
+                    skip = ("opacity",)
+                if not update_gaussian:
+                    self._adam(10.0, skip=skip)
+                self.gaussians.update_learning_rate(self.iteration_count)
+                self._exposure_step(used)
+                if pose_opt:
+                    for cam_idx in range(min(frames_to_optimize, len(current_window))):
+                        if viewpoint_stack[cam_idx].uid == 0:
+                            continue
+                        update_pose(viewpoint_stack[cam_idx])
+            self._tick()
+        return gaussian_split
+
+    def final_refine(self, iters=26000):
+        stack = list(self.viewpoints.values())
+        for _ in range(iters):
+            self.iteration_count += 1
+            self._ensure_state()
+            self._activate()
+            cam = stack[np.random.randint(0, len(stack))]
+            self._view_step(cam, stats=False)
+            self._adam(0.0)
+            self.gaussians.update_learning_rate(self.iteration_count)
+            self._exposure_step([cam])
+            self._tick()
+
+    # convenience for evaluation / tests
+    def total_loss(self):
+        return torch.stack([l[0] for l in self.last_losses]).sum()

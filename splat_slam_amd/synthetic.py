@@ -95,7 +95,7 @@ def model_from_parameters(params, config=None, device="cuda:0", knn_fn=None):
     gm.training_setup(OptParams(config["mapping"].get("opt_params")))
     n = params["xyz"].shape[0]
     f_rest = torch.zeros((n, 0, 3), device=device)
-    P = lambda t: torch.nn.Parameter(t.to(device).float().contiguous().requires_grad_(True))
+    P = lambda t: torch.nn.Parameter(t.detach().to(device).float().clone().contiguous().requires_grad_(True))
     gm.densification_postfix(P(params["xyz"]), P(params["f_dc"]), P(f_rest), P(params["opacity"]), P(params["scaling"]),
                              P(params["rotation"]), new_kf_ids=torch.zeros(n).int(), new_n_obs=torch.zeros(n).int())
     return gm

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
         assert name in nat.SIGNATURES, f"{name} has no ctypes signature in splat_slam_amd/_native.py"
     assert sorted(nat.SIGNATURES) == declared
     lib = nat.lib()
-    assert lib.sgr_abi_version() == 1
+    assert lib.sgr_abi_version() == 2
     assert isinstance(nat.last_error(), str)
 
 
@@ -39,7 +39,8 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(nat.SgrOutputs) == 5 * 8
     assert ctypes.sizeof(nat.SgrWorkspace) == 5 * 8
     assert ctypes.sizeof(nat.SgrGradOutputs) == 2 * 8
-    assert ctypes.sizeof(nat.SgrGradInputs) == 9 * 8
+    assert ctypes.sizeof(nat.SgrGradInputs) == 9 * 8 + 8 + 3 * 8
+    assert ctypes.sizeof(nat.SgrAdamGroup) == 4 * 8 + 8 + 8
 
 
 def test_product_path_has_no_cpu_fallback_and_never_imports_the_oracle():
