@@ -24,9 +24,14 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-KINDS = ["preprocess_fwd", "scan", "duplicate", "sort", "ranges", "blend_fwd", "zero_partials", "blend_bwd", "preprocess_bwd"]
+KINDS = ["preprocess_fwd", "tile_scan", "scatter", "unused3", "unused4", "blend_fwd_incl_tile_sort", "unused6", "blend_bwd", "preprocess_bwd"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
+
+
+def trace(msg):
+    if os.environ.get("SPLAT_BENCH_TRACE"):
+        print("[trace]", msg, file=sys.stderr, flush=True)
 
 
 def parse():
@@ -80,6 +85,10 @@ def main():
     loop.viewpoints = {c.uid: c for c in cams}
     loop.current_window = list(range(min(10, args.views)))
     loop.build_keyframe_optimizers()
+    # keep the workload stationary: densify_and_prune fires when iteration_count % 150 == 50 (mapper.py:531-541) and
+    # would change N (the metric is quoted AT 300k Gaussians); start right after such a point -> 149 clean iterations
+    loop.iteration_count = 50
+    assert args.warmup + args.steps < 149, "keep warmup+steps < 149 so that no densification changes N mid-benchmark"
     sync = GradientSync(loop.gaussians, world) if world > 1 else None
     if sync is not None:
         loop.grad_sync = sync
@@ -92,16 +101,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace("setup done")
     for _ in range(args.warmup):
         step()
     barrier()
+    trace("warmup done")
     mask = (1 << 7) if not args.profile_all else (1 << len(KINDS)) - 1
     lib.sgr_profile_enable(mask)            # HIP events around blend_bwd only (12 pairs per step) on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_issue = time.perf_counter() - t0          # time the host needed to ENQUEUE the steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
+    trace("timed loop done")
     ms = (C.c_float * len(KINDS))()
     cnt = (C.c_int64 * len(KINDS))()
     lib.sgr_profile_read(ms, cnt)
@@ -139,21 +152,27 @@ def main():
         loss.backward()
         loop.gaussians.optimizer.zero_grad(set_to_none=True)
 
-    fwd_only(); fwd_bwd()
+    trace("profile read")
+    fwd_only(); torch.cuda.synchronize(); trace("fwd_only ok"); fwd_bwd(); torch.cuda.synchronize(); trace("fwd_bwd ok")
     render_fwd_ms = timed(fwd_only)
+    trace("timed fwd ok")
     render_fwd_bwd_ms = timed(fwd_bwd)
+    trace("timed fwd_bwd ok")
 
     # work counters of one view (through the drop-in autograd surface, same kernels)
     stats = (C.c_int64 * 4)()
     pkg = render(cam0, loop.gaussians, PipelineParams(), bg)
+    torch.cuda.synchronize(); trace("stats render ok")
     fn = pkg["render"].grad_fn
     saved = fn.saved_tensors[-1]
     radii = pkg["radii"]
     st = dgr._state(dev)
     ws = nat.SgrWorkspace(saved.data_ptr(), saved.numel(), st.scratch.data_ptr(), st.scratch.numel(), fn.capacity)
+    assert loop.gaussians.get_xyz.shape[0] == N, "N changed during the benchmark"
     nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], radii.data_ptr(), stats,
                                   torch.cuda.current_stream(dev).cuda_stream), "sgr_query_stats")
     V, R, R_eff, tiles_nonempty = [int(x) for x in stats]
+    trace("stats ok")
     HW = intr["H"] * intr["W"]
 
     # ---- roofline of the dominant kernel (tile-blend backward), SURVEY.md 8d algorithmic bytes
@@ -178,6 +197,7 @@ def main():
                                % (N, intr["W"], intr["H"], views_per_step),
                    "gaussians": N, "width": intr["W"], "height": intr["H"], "views_per_step": views_per_step, "loop": args.loop,
                    "parallelism": "view-parallel x%d, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
+        "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4),
         "render_ms": {"forward": round(render_fwd_ms, 4), "forward_backward_loss": round(render_fwd_bwd_ms, 4)},
         "work_per_view": {"visible_gaussians": V, "tile_pairs_R": R, "tile_pairs_walked_R_eff": R_eff,
                           "nonempty_tiles": tiles_nonempty},

@@ -154,8 +154,8 @@ int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_h
 int sgr_query_stats(const SgrWorkspace* ws, int32_t num_gaussians, int32_t image_height, int32_t image_width,
                     const int32_t* radii, int64_t stats_host[4], void* stream);
 
-/* Per-kernel HIP-event timing.  kind: 0 preprocess_fwd, 1 scan, 2 duplicate, 3 sort, 4 ranges, 5 blend_fwd,
- * 6 zero_partials, 7 blend_bwd, 8 preprocess_bwd.  sgr_profile_enable(mask) arms event pairs around the kinds whose
+/* Per-kernel HIP-event timing.  kind: 0 preprocess_fwd (+ per-tile pair counting), 1 tile_scan, 2 scatter,
+ * 3/4/6 unused, 5 blend_fwd (+ in-wave tile sort), 7 blend_bwd, 8 preprocess_bwd (+ pose reduce).  sgr_profile_enable(mask) arms event pairs around the kinds whose
  * bit is set (0 disarms); sgr_profile_read() synchronises, returns accumulated milliseconds and launch counts per
  * kind since the last read, and resets them. Events are recorded on the stream the kernel is launched on. */
 #define SGR_PROFILE_KINDS 9
@@ -201,6 +201,35 @@ typedef struct SgrAdamGroup {
 } SgrAdamGroup;
 int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps,
                            float iso_weight, void* stream);
+
+/* One mapping-loop view: render, mapping loss and its gradient, backward (src/mapper.py:426-456 for one viewpoint).
+ * sgr_map_views runs the sequence  sgr_forward(async) -> sgr_mapping_loss -> sgr_backward  for `num_views` views
+ * that share the Gaussian inputs `in` and the gradient sinks `grads` (use accumulate = 1) with ONE host call, so the
+ * host cost of a mapping iteration is the kernel launches only. */
+typedef struct SgrMapView {
+  SgrSettings settings;
+  SgrOutputs out;
+  SgrWorkspace ws;
+  const float* gt_image;       /* [3,H,W] */
+  const float* gt_depth;       /* [H,W]   */
+  const float* exposure_a;     /* [1] or NULL */
+  const float* exposure_b;     /* [1] or NULL */
+  float* loss;                 /* [1] */
+  float* dL_dimage;            /* [3,H,W] scratch for this view */
+  float* dL_ddepth;            /* [1,H,W] */
+  float* dL_dexposure;         /* [2] = (d/da, d/db) or NULL */
+  float* dL_dtau;              /* [6] or NULL */
+  void* loss_scratch;
+  size_t loss_scratch_bytes;
+} SgrMapView;
+int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* in, const SgrGradInputs* grads,
+                  float alpha, float rgb_boundary_threshold, int32_t forward_only, void* stream);
+
+/* Adam on a small slab with a per-row switch: row r (width `row_width`) is updated iff active[r] != 0, using its own
+ * step counter step[r] (incremented in place).  The exposure parameters of the keyframe optimiser
+ * (src/mapper.py:1096-1111: lr 0.01, default eps 1e-8) live in such a slab. */
+int sgr_masked_adam(int32_t rows, int32_t row_width, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    int32_t* step, const int32_t* active, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* simple_knn distCUDA2: mean squared distance to the 3 nearest neighbours (self excluded). */
 size_t sknn_scratch_bytes(int32_t n);

@@ -46,6 +46,12 @@ class SgrGradInputs(C.Structure):
                 ("stat_max_radii", _fp)]
 
 
+class SgrMapView(C.Structure):
+    _fields_ = [("settings", SgrSettings), ("out", SgrOutputs), ("ws", SgrWorkspace), ("gt_image", _fp), ("gt_depth", _fp),
+                ("exposure_a", _fp), ("exposure_b", _fp), ("loss", _fp), ("dL_dimage", _fp), ("dL_ddepth", _fp),
+                ("dL_dexposure", _fp), ("dL_dtau", _fp), ("loss_scratch", _fp), ("loss_scratch_bytes", C.c_size_t)]
+
+
 class SgrAdamGroup(C.Structure):
     _fields_ = [("param", _fp), ("grad", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp), ("lr", C.c_float), ("skip", C.c_int32),
                 ("step", C.c_int64)]
@@ -71,6 +77,10 @@ SIGNATURES = {
                                 C.c_int64, _fp]),
     "sgr_activate": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sgr_gaussian_adam_step": (C.c_int, [C.c_int64, C.POINTER(SgrAdamGroup), C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
+    "sgr_map_views": (C.c_int, [C.c_int32, C.POINTER(SgrMapView), C.POINTER(SgrInputs), C.POINTER(SgrGradInputs),
+                                C.c_float, C.c_float, C.c_int32, _fp]),
+    "sgr_masked_adam": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, _fp]),
     "sknn_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "sknn_dist2": (C.c_int, [_fp, C.c_int32, _fp, _fp, C.c_size_t, _fp]),
     "se3_exp": (C.c_int, [_fp, C.c_int64, _fp, _fp]),

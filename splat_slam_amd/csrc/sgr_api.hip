@@ -1,12 +1,9 @@
-// C-ABI entry points of the rasterizer + the binning stage (scan / duplicate / sort / ranges).
-// Public contract: include/splat_hip.h.
+// C-ABI entry points of the rasterizer.  Public contract: include/splat_hip.h.
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <string.h>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "sgr_common.h"
 
@@ -15,7 +12,8 @@ namespace sgr {
 void launch_preprocess_fwd(const SgrSettings&, const SgrInputs&, const SgrOutputs&, const Layout&, char*, hipStream_t);
 void launch_preprocess_bwd(const SgrSettings&, const SgrInputs&, const int32_t*, const SgrGradInputs&, const Layout&,
                            const char*, char*, hipStream_t);
-void launch_blend_fwd(const SgrSettings&, const SgrOutputs&, const Layout&, char*, hipStream_t);
+void launch_binning(const SgrSettings&, const SgrOutputs&, const Layout&, char*, char*, hipStream_t);
+void launch_blend_fwd(const SgrSettings&, const SgrOutputs&, const Layout&, char*, char*, hipStream_t);
 void launch_blend_bwd(const SgrSettings&, const SgrGradOutputs&, const Layout&, const char*, char*, hipStream_t);
 
 static thread_local char g_err[512] = "";
@@ -32,76 +30,7 @@ int set_error(int code, const char* fmt, ...) {
     if (_e != hipSuccess) return set_error(SGR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
   } while (0)
 
-// ---- rocprim temp sizes are pure functions of the element count: query once per (N, cap)
-static size_t scan_temp_bytes(int N) {
-  size_t bytes = 0;
-  if (N <= 0) return 256;
-  (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)N,
-                                rocprim::plus<uint32_t>(), (hipStream_t)0);
-  return bytes + 256;
-}
-static size_t sort_temp_bytes(int64_t cap) {
-  size_t bytes = 0;
-  if (cap <= 0) return 256;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, (size_t)cap, 0u, 64u, (hipStream_t)0);
-  return bytes + 256;
-}
-static Layout make_layout(int N, int H, int W, int64_t cap) {
-  return Layout(N, H, W, cap, scan_temp_bytes(N), sort_temp_bytes(cap));
-}
-
-// ---- binning kernels
-__global__ void finalize_count_kernel(int N, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ touched,
-                                      int64_t cap, SavedHeader* __restrict__ hdr) {
-  uint64_t R = N > 0 ? (uint64_t)offsets[N - 1] + touched[N - 1] : 0;
-  hdr->num_rendered = (uint32_t)R;
-  hdr->overflow = (int64_t)R > cap ? 1u : 0u;
-  hdr->sorted_count = (uint32_t)((int64_t)R > cap ? cap : (int64_t)R);
-}
-
-// one thread per Gaussian emits a (tile | depth) key for every bin of its rectangle, at the slot that the backward
-// will later use for that pair's gradient partial
-__global__ void __launch_bounds__(256) duplicate_keys_kernel(int N, int gx, const int32_t* __restrict__ radii,
-                                                             const uint32_t* __restrict__ offsets,
-                                                             const uint32_t* __restrict__ touched,
-                                                             const ushort4* __restrict__ rect,
-                                                             const float4* __restrict__ rgbd, int64_t cap,
-                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N || radii[i] <= 0 || touched[i] == 0) return;
-  ushort4 r = rect[i];
-  uint64_t off = offsets[i];
-  uint32_t dbits = __float_as_uint(rgbd[i].w);
-  for (int y = r.y; y < r.w; ++y)
-    for (int x = r.x; x < r.z; ++x) {
-      if ((int64_t)off < cap) {
-        keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
-        vals[off] = (uint32_t)i;
-      }
-      ++off;
-    }
-}
-
-// async mode sorts the whole capacity: park the unused tail behind every real tile
-__global__ void __launch_bounds__(256) fill_sentinel_kernel(const SavedHeader* __restrict__ hdr, int64_t cap,
-                                                            uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  int64_t first = hdr->sorted_count;
-  for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
-    keys[i] = ~0ull;
-    vals[i] = 0;
-  }
-}
-
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const SavedHeader* __restrict__ hdr,
-                                                          const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
-  int64_t n = hdr->sorted_count;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t t = (uint32_t)(keys[i] >> 32);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[t].x = (uint32_t)i;
-    if (i == n - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
-  }
-}
+static Layout make_layout(int N, int H, int W, int64_t cap) { return Layout(N, H, W, cap); }
 
 // ---- event-pair profiler
 struct ProfState {
@@ -178,7 +107,9 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
                 int64_t* num_rendered_host, void* stream) {
   if (!s || !in || !out || !ws) return set_error(SGR_ERR_INVALID, "null argument");
   const int N = s->num_gaussians, H = s->image_height, W = s->image_width;
-  if (N < 0 || H <= 0 || W <= 0 || ws->capacity <= 0) return set_error(SGR_ERR_INVALID, "bad sizes N=%d H=%d W=%d cap=%lld", N, H, W, (long long)ws->capacity);
+  if (N < 0 || H <= 0 || W <= 0 || ws->capacity <= 0 || ws->capacity > 0xffffffffll)
+    return set_error(SGR_ERR_INVALID, "bad sizes N=%d H=%d W=%d cap=%lld", N, H, W, (long long)ws->capacity);
+  if (H > 65535 * kTile || W > 65535 * kTile) return set_error(SGR_ERR_INVALID, "image too large");
   if (N > 0) {
     if (!in->means3D || !in->opacities) return set_error(SGR_ERR_INVALID, "means3D and opacities are required");
     if ((in->shs != nullptr) == (in->colors_precomp != nullptr))
@@ -197,50 +128,19 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
   char* saved = (char*)ws->saved;
   char* scratch = (char*)ws->scratch;
   SavedHeader* hdr = (SavedHeader*)(saved + L.o_hdr);
-  uint32_t* offsets = (uint32_t*)(saved + L.o_offsets);
-  uint32_t* touched = (uint32_t*)(saved + L.o_touched);
-  uint64_t* keys_in = (uint64_t*)(scratch + L.o_keys_in);
-  uint64_t* keys_out = (uint64_t*)(scratch + L.o_keys_out);
-  uint32_t* vals_in = (uint32_t*)(scratch + L.o_vals_in);
-  uint32_t* point_list = (uint32_t*)(saved + L.o_point_list);
 
-  HIP_TRY(hipMemsetAsync(saved + L.o_ranges, 0, (size_t)L.ntiles * 8, st));
-  if (N > 0) HIP_TRY(hipMemsetAsync(out->n_touched, 0, (size_t)N * 4, st));
-  launch_preprocess_fwd(*s, *in, *out, L, saved, st);
-  if (N > 0) {
-    ProfScope prof(PK_SCAN, st);
-    size_t tb = L.scan_tmp_bytes;
-    HIP_TRY(rocprim::exclusive_scan(scratch + L.o_scan_tmp, tb, touched, offsets, 0u, (size_t)N, rocprim::plus<uint32_t>(), st));
-  }
-  hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, st, N, offsets, touched, L.cap, hdr);
-
-  int64_t sort_n = L.cap;
+  // header + per-tile pair counters: the only memset of the forward
+  HIP_TRY(hipMemsetAsync(saved + L.o_hdr, 0, L.zero_bytes, st));
+  launch_preprocess_fwd(*s, *in, *out, L, saved, st);                 // K1: project, footprint, count pairs per tile
+  launch_binning(*s, *out, L, saved, scratch, st);                    // K2: tile/block scans   K3: scatter keys
   if (num_rendered_host) {
     uint32_t R = 0;
     HIP_TRY(hipMemcpyAsync(&R, &hdr->num_rendered, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *num_rendered_host = R;
     if ((int64_t)R > L.cap) return set_error(SGR_ERR_CAPACITY, "%u (tile, Gaussian) pairs exceed capacity %lld", R, (long long)L.cap);
-    sort_n = R;
   }
-  if (N > 0 && sort_n > 0) {
-    {
-      ProfScope prof(PK_DUP, st);
-      hipLaunchKernelGGL(duplicate_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, L.gx, out->radii, offsets,
-                         touched, (const ushort4*)(saved + L.o_rect), (const float4*)(saved + L.o_rgbd), L.cap, keys_in, vals_in);
-      if (!num_rendered_host)
-        hipLaunchKernelGGL(fill_sentinel_kernel, dim3(256), dim3(256), 0, st, hdr, L.cap, keys_in, vals_in);
-    }
-    {
-      ProfScope prof(PK_SORT, st);
-      size_t tb = L.sort_tmp_bytes;
-      HIP_TRY(rocprim::radix_sort_pairs(scratch + L.o_sort_tmp, tb, keys_in, keys_out, vals_in, point_list, (size_t)sort_n, 0u,
-                                        (unsigned)(32 + L.tile_bits), st));
-    }
-    ProfScope prof(PK_RANGES, st);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(256), dim3(256), 0, st, hdr, keys_out, (uint2*)(saved + L.o_ranges));
-  }
-  launch_blend_fwd(*s, *out, L, saved, st);
+  launch_blend_fwd(*s, *out, L, saved, scratch, st);                  // K4: per-tile sort + compositing
   HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
@@ -264,6 +164,27 @@ int sgr_backward(const SgrSettings* s, const SgrInputs* in, const int32_t* radii
   launch_blend_bwd(*s, *go, L, (const char*)ws->saved, (char*)ws->scratch, st);
   launch_preprocess_bwd(*s, *in, radii, *gi, L, (const char*)ws->saved, (char*)ws->scratch, st);
   HIP_TRY(hipGetLastError());
+  return SGR_OK;
+}
+
+int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* in, const SgrGradInputs* grads, float alpha,
+                  float rgb_boundary_threshold, int32_t forward_only, void* stream) {
+  if (num_views < 0 || (num_views > 0 && (!views || !in)) || (!forward_only && !grads))
+    return set_error(SGR_ERR_INVALID, "map_views: null argument");
+  for (int v = 0; v < num_views; ++v) {
+    const SgrMapView& mv = views[v];
+    if (int rc = sgr_forward(&mv.settings, in, &mv.out, &mv.ws, nullptr, stream)) return rc;
+    if (forward_only) continue;
+    if (int rc = sgr_mapping_loss(mv.settings.image_height, mv.settings.image_width, mv.out.color, mv.out.depth, mv.gt_image,
+                                  mv.gt_depth, mv.exposure_a, mv.exposure_b, alpha, rgb_boundary_threshold, 1.0f, mv.loss,
+                                  mv.dL_dimage, mv.dL_ddepth, mv.dL_dexposure, mv.dL_dexposure ? mv.dL_dexposure + 1 : nullptr,
+                                  mv.loss_scratch, mv.loss_scratch_bytes, stream))
+      return rc;
+    SgrGradOutputs go = {mv.dL_dimage, mv.dL_ddepth};
+    SgrGradInputs gi = *grads;
+    gi.dL_dtau = mv.dL_dtau;
+    if (int rc = sgr_backward(&mv.settings, in, mv.out.radii, &go, &gi, &mv.ws, stream)) return rc;
+  }
   return SGR_OK;
 }
 

@@ -90,6 +90,26 @@ __global__ void __launch_bounds__(256) adam_kernel(int64_t n, float* __restrict_
   }
 }
 
+__global__ void masked_adam_kernel(int rows, int width, float* __restrict__ p, const float* __restrict__ g,
+                                   float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ step,
+                                   const int32_t* __restrict__ active, float lr, float b1, float b2, float eps) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows || !active[r]) return;
+  int st = step[r] + 1;
+  step[r] = st;
+  float bc1 = 1.f - powf(b1, (float)st), bc2 = 1.f - powf(b2, (float)st);
+  float step_size = lr / bc1, bc2s = sqrtf(bc2);
+  for (int k = 0; k < width; ++k) {
+    int i = r * width + k;
+    float gi = g[i], mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ fused map step
 __global__ void __launch_bounds__(256) activate_kernel(int64_t n, const float* __restrict__ scaling,
                                                        const float* __restrict__ rotation, const float* __restrict__ opacity,
@@ -448,6 +468,16 @@ int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1,
   float iso_coef = iso_weight / (3.f * (float)n);
   hipLaunchKernelGGL(gaussian_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, G, c, iso_coef);
   return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "gaussian_adam launch failed");
+}
+
+int sgr_masked_adam(int32_t rows, int32_t row_width, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    int32_t* step, const int32_t* active, float lr, float beta1, float beta2, float eps, void* stream) {
+  if (rows < 0 || row_width <= 0 || (rows > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !step || !active)))
+    return set_error(SGR_ERR_INVALID, "masked_adam: bad argument");
+  if (rows == 0) return SGR_OK;
+  hipLaunchKernelGGL(masked_adam_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, rows, row_width, param, grad,
+                     exp_avg, exp_avg_sq, step, active, lr, beta1, beta2, eps);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "masked_adam launch failed");
 }
 
 size_t sknn_scratch_bytes(int32_t n) { return n <= 0 ? 256 : (size_t)knn_splits(n) * (size_t)n * sizeof(Top3) + 256; }

@@ -1,55 +1,138 @@
-// Tile blending for gfx950: front-to-back alpha compositing (forward) and its gradient (backward).
+// Tile blending for gfx950: per-tile list sort + front-to-back alpha compositing (forward) and its gradient (backward).
 //
-// Replaces renderCUDA (forward/backward) of the un-vendored diff-gaussian-rasterization-w-pose module reached from
+// Replaces renderCUDA (forward/backward) -- and, together with sgr_binning.hip, the global radix sort -- of the
+// un-vendored diff-gaussian-rasterization-w-pose module reached from
 // /root/reference/thirdparty/gaussian_splatting/gaussian_renderer/__init__.py:130-141 and from loss.backward() at
 // /root/reference/src/mapper.py:329,490,699.
 //
 // MI355X design (not the CUDA 16x16-block/atomicAdd scheme):
 //   * a bin is 8x8 pixels = exactly one wave64; a 256-thread workgroup is four independent waves covering one
 //     16x16 reference tile.  Waves never synchronise with each other: no __syncthreads in either kernel.
-//   * FORWARD is pixel-parallel (lane = pixel).  The wave stages 64 sorted splats at a time into its private LDS
-//     slice (coalesced gather -> ds_write_b128), then walks them with broadcast ds_read_b128; per-pixel
-//     accumulators stay in VGPRs.  n_touched is one ballot+popcount+atomic per (wave, splat), not per pixel.
-//   * BACKWARD is splat-parallel (lane = splat, loop over the 64 pixels).  For one pixel the transmittance in front
-//     of every splat is a wave-wide multiplicative DPP scan and the colour behind it an additive DPP scan of ONE
-//     scalar (w_j = dL/dC . rgb_j + dL/dD * depth_j), so per (pixel, 64 splats) there are 2 scans instead of the
-//     10 cross-lane reductions a pixel-parallel backward needs, and the 10 per-splat gradient sums accumulate in
-//     that lane's registers.  Each (tile, splat) pair then writes its 48-byte partial to a slot owned by the
-//     Gaussian: no atomics, bitwise run-to-run deterministic; preprocess_bwd gathers the slots in fixed order.
+//   * FORWARD first sorts its tile's (depth bits | Gaussian) keys: <= 64 keys in registers (bitonic network over
+//     lanes), <= 1024 keys in the wave's LDS slice, longer lists in place in HBM (slow path).  Then it is pixel-parallel
+//     (lane = pixel): 64 sorted splats at a time are staged into LDS (coalesced gather -> ds_write_b128) and walked with
+//     broadcast ds_read_b128; per-pixel accumulators stay in VGPRs.  n_touched is one ballot+popcount+atomic per
+//     (wave, splat), not per pixel.
+//   * BACKWARD is splat-parallel (lane = splat).  For one pixel the transmittance in front of every splat is a
+//     multiplicative DPP scan over lanes and the colour behind it an additive DPP scan of ONE scalar
+//     (w_j = dL/dC . rgb_j + dL/dD * depth_j): 2 scans per (pixel, list) instead of the 10 cross-lane reductions of a
+//     pixel-parallel backward; the 10 per-splat gradient sums accumulate in that lane's registers.  Short lists do not
+//     waste lanes: with <= 16 (<= 32) splats the wave processes 4 (2) pixels at once, one per 16- (32-)lane group.
+//     Each (tile, splat) pair writes its 48-byte partial to a slot owned by the Gaussian: no atomics, bitwise
+//     run-to-run deterministic; preprocess_bwd gathers the slots in fixed order.
 #include "sgr_common.h"
 
 namespace sgr {
+
+// keys sorted inside the wave's LDS slice: two builds of the forward kernel, picked per launch from the expected
+// list length (capacity / tiles): "light" keeps 8 workgroups per CU resident, "heavy" trades occupancy for LDS.
+constexpr int kSortLight = 256, kSortHeavy = 4096;
 
 // workgroup -> 16x16 super tile with an XCD-aware remap: hardware places block b on XCD b%8, we hand every XCD a
 // contiguous run of super tiles so neighbouring tiles (which share Gaussians) hit the same 4 MiB L2.
 __device__ __forceinline__ int super_tile_of_block(int b, int nblocks) {
   int per = (nblocks + 7) >> 3;
-  int t = (b & 7) * per + (b >> 3);
-  return t;   // may be >= nblocks for the tail: caller checks
+  return (b & 7) * per + (b >> 3);   // may be >= nblocks for the tail: caller checks
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// ascending bitonic network over the 64 lanes (one key per lane; idle lanes hold ~0)
+__device__ __forceinline__ uint64_t wave_sort64(uint64_t key, int n, int lane) {
+  for (int k = 2; k <= kWave; k <<= 1) {
+    if ((k >> 1) >= n) break;                       // everything above n is +inf already in place (uniform)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      uint64_t other = shfl_xor_u64(key, j);
+      bool up = (lane & k) == 0;
+      bool lower = (lane & j) == 0;
+      uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  return key;
+}
+
+// Bitonic sort of a[0..n) for ANY n with one wave ("mirror" formulation: every compare-exchange is ascending, so
+// virtual +inf padding behind n never moves).  LOAD/STORE abstract LDS vs. device-coherent global memory.
+template <typename LD, typename ST, typename SYNC>
+__device__ __forceinline__ void wave_sort_any(int n, int lane, LD load, ST store, SYNC sync) {
+  int P = 1;
+  while (P < n) P <<= 1;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const bool first = (j == (k >> 1));
+      for (int t = lane; t < (P >> 1); t += kWave) {
+        int i = ((t / j) * (j << 1)) + (t % j);                     // lower index of the pair
+        int l = first ? (i ^ (k - 1)) : (i ^ j);                    // mirror partner on the first step of a merge
+        if (l < i) { int tmp = i; i = l; l = tmp; }
+        if (l < n) {
+          uint64_t a = load(i), b = load(l);
+          if (b < a) { store(i, b); store(l, a); }
+        }
+      }
+      sync();
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+template <int SORT_MAX>
 __global__ void __launch_bounds__(256) blend_fwd_kernel(
-    int H, int W, int gx, int gy, int sgx, int sgy, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
-    const float4* __restrict__ rgbd, const float* __restrict__ bg, float* __restrict__ out_color,
-    float* __restrict__ out_depth, float* __restrict__ out_opacity, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc, int32_t* __restrict__ n_touched) {
-  __shared__ float4 stage[4][kWave * 3];   // per wave: 64 splats x 48 B
+    int H, int W, int gx, int gy, int sgx, int sgy, int64_t cap, const uint2* __restrict__ ranges,
+    uint64_t* __restrict__ entries, uint32_t* __restrict__ point_list, const float2* __restrict__ xy,
+    const float4* __restrict__ conic_o, const float4* __restrict__ rgbd, const float* __restrict__ bg,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_opacity,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
+    int32_t* __restrict__ n_touched) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // per wave: SORT_MAX keys (8 B) + 64 splats x 48 B
   const int nblocks = sgx * sgy;
   const int st = super_tile_of_block(blockIdx.x, nblocks);
   if (st >= nblocks) return;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int kLdsSortMax = SORT_MAX;
+  char* slice = smem + (size_t)wv * (SORT_MAX * 8 + kWave * 48);
   const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
   if (tx >= gx || ty >= gy) return;          // whole wave outside the image
   const int tile = ty * gx + tx;
   const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  float4* lds = stage[wv];
+  uint64_t* keys = (uint64_t*)slice;
+  float4* lds = (float4*)(slice + SORT_MAX * 8);
 
   const uint2 rng = ranges[tile];
-  const int count = (int)(rng.y - rng.x);
+  const int64_t begin = rng.x;
+  const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
+  const int count = endc > begin ? (int)(endc - begin) : 0;
+
+  // ---- sort this tile's run by (depth bits, Gaussian index) and publish the index list for the backward
+  uint32_t g_first = 0;                       // sorted Gaussian index of list position `lane` (count <= 64 path)
+  int mode = 0;                               // 0: registers, 1: LDS, 2: global
+  if (count <= kWave) {
+    uint64_t key = lane < count ? entries[begin + lane] : ~0ull;
+    key = wave_sort64(key, count, lane);
+    g_first = (uint32_t)key;
+    if (lane < count) point_list[begin + lane] = g_first;
+  } else if (count <= kLdsSortMax) {
+    mode = 1;
+    for (int i = lane; i < count; i += kWave) keys[i] = entries[begin + i];
+    __builtin_amdgcn_wave_barrier();
+    wave_sort_any(count, lane, [&](int i) { return keys[i]; }, [&](int i, uint64_t v) { keys[i] = v; },
+                  [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); });
+    for (int i = lane; i < count; i += kWave) point_list[begin + i] = (uint32_t)keys[i];
+  } else {
+    mode = 2;                                 // slow path: in place in HBM through device-coherent accesses
+    uint64_t* e = entries + begin;
+    wave_sort_any(count, lane,
+                  [&](int i) { return __hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                  [&](int i, uint64_t v) { __hip_atomic_store(e + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                  [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); __builtin_amdgcn_wave_barrier(); });
+    for (int i = lane; i < count; i += kWave)
+      point_list[begin + i] = (uint32_t)__hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   uint32_t last = 0;
@@ -57,9 +140,12 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
 
   for (int base = 0; base < count; base += kWave) {
     const int n = min(kWave, count - base);
-    // gather this chunk: lane j fetches splat j (coalesced index read, then 40 B of geometry)
+    // gather this chunk: lane j fetches splat j (40 B of geometry from the Gaussian SoA)
     if (lane < n) {
-      uint32_t g = point_list[rng.x + base + lane];
+      uint32_t g;
+      if (mode == 0) g = g_first;
+      else if (mode == 1) g = (uint32_t)keys[base + lane];
+      else g = (uint32_t)__hip_atomic_load(entries + begin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       float2 m = xy[g];
       float4 co = conic_o[g];
       float4 cd = rgbd[g];
@@ -67,7 +153,6 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       lds[lane * 3 + 1] = make_float4(co.z, co.w, cd.w, __uint_as_float(g));
       lds[lane * 3 + 2] = make_float4(cd.x, cd.y, cd.z, 0.f);
     }
-    // single wave: LDS writes are visible to the same wave after the implicit lgkmcnt wait; no barrier needed
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < n; ++j) {
@@ -111,13 +196,132 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// inclusive scans restricted to groups of GW lanes (GW = 16: one DPP row, 32: two rows, 64: whole wave)
+template <int GW>
+__device__ __forceinline__ float group_scan_mul(float v) {
+  v *= dpp_f<DPP_ROW_SHR1>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR2>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR4>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR8>(1.f, v);
+  if (GW >= 32) v *= dpp_f<DPP_ROW_BCAST15, 0xa>(1.f, v);
+  if (GW >= 64) v *= dpp_f<DPP_ROW_BCAST31, 0xc>(1.f, v);
+  return v;
+}
+template <int GW>
+__device__ __forceinline__ float group_scan_add(float v) {
+  v += dpp_f<DPP_ROW_SHR1>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR2>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR4>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR8>(0.f, v);
+  if (GW >= 32) v += dpp_f<DPP_ROW_BCAST15, 0xa>(0.f, v);
+  if (GW >= 64) v += dpp_f<DPP_ROW_BCAST31, 0xc>(0.f, v);
+  return v;
+}
+// value of the previous lane inside the group (first lane of a group receives `fill`)
+template <int GW>
+__device__ __forceinline__ float group_shr1(float v, float fill, int lane) {
+  if (GW == 16) return dpp_f<DPP_ROW_SHR1>(fill, v);
+  float r = dpp_f<DPP_WAVE_SHR1>(fill, v);
+  if (GW == 32) r = (lane == 32) ? fill : r;
+  return r;
+}
+
+// One chunk of <= GW splats against the 64 pixels of the tile, 64/GW pixels per iteration.
+// Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix scan.
+template <int GW>
+__device__ __forceinline__ void bwd_chunk(
+    int lane, int c, int eff, int64_t begin, float tx0, float ty0, const float4* pixA /*LDS*/, float4* pixB /*LDS*/,
+    const uint32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
+    const float4* __restrict__ rgbd, const ushort4* __restrict__ rect, const uint32_t* __restrict__ offsets, int tx,
+    int ty, float halfW, float halfH, float4* __restrict__ partials, int64_t cap) {
+  constexpr int PP = kWave / GW;                 // pixels processed per iteration
+  const int sub = lane / GW;                     // which of them this lane works on
+  const int sl = lane % GW;
+  const int idx = c * GW + (GW - 1 - sl);        // list position of this lane's splat
+  const bool valid = idx < eff;
+  uint32_t g = 0;
+  float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
+  if (valid) {
+    g = point_list[begin + idx];
+    float2 m = xy[g];
+    float4 co = conic_o[g];
+    float4 cd = rgbd[g];
+    mx = m.x; my = m.y; A = co.x; B = co.y; Cc = co.z; op = co.w; cr = cd.x; cg = cd.y; cb = cd.z; dep = cd.w;
+  }
+  float s_gx = 0.f, s_gy = 0.f, s_gxx = 0.f, s_gxy = 0.f, s_gyy = 0.f;
+  float a_o = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
+
+  for (int it = 0; it < kWave / PP; ++it) {
+    const int p = it * PP + sub;                 // this lane's pixel (same for the whole group)
+    const float4 pa = pixA[p];                   // dCr, dCg, dCb, dD     (LDS, broadcast inside the group)
+    const float4 pb = pixB[p];                   // T carry, S carry, n_contrib bits, -
+    const int nc = __float_as_int(pb.z);
+    if (GW == kWave && __builtin_amdgcn_readfirstlane(nc) <= c * kWave) continue;   // pixel ended before this chunk
+    const float dx = mx - (tx0 + (float)(p & 7)), dy = my - (ty0 + (float)(p >> 3));
+    AlphaEval a = eval_alpha(dx, dy, A, B, Cc, op);
+    const bool ok = valid && (idx < nc) && a.ok;
+    const float om = ok ? 1.f - a.alpha : 1.f;
+    const float P = group_scan_mul<GW>(om);          // prod over this splat and all behind it (in chunk)
+    const float E = group_shr1<GW>(P, 1.f, lane);    // prod over all strictly behind it
+    const float rP = __builtin_amdgcn_rcpf(P);
+    const float Tj = pb.x * rP;                      // transmittance in front of splat j
+    const float inv1ma = E * rP;                     // 1 / (1 - alpha_j)
+    const float w = __fmaf_rn(pa.x, cr, __fmaf_rn(pa.y, cg, __fmaf_rn(pa.z, cb, pa.w * dep)));
+    const float aT = ok ? a.alpha * Tj : 0.f;
+    const float q = w * aT;
+    const float Qi = group_scan_add<GW>(q);          // inclusive: this splat and all behind it
+    const float Sx = (Qi - q) + pb.y;                // strictly behind (+ carried chunks + background term)
+    const float dL_dalpha = __fmaf_rn(Tj, w, -Sx * inv1ma);
+    if (GW == kWave) {
+      // carry to the next (nearer) chunk: the last lane holds the nearest splat of this chunk
+      if (lane == kWave - 1) pixB[p] = make_float4(Tj, Qi + pb.y, pb.z, 0.f);
+    }
+    if (ok) {
+      a_r = __fmaf_rn(aT, pa.x, a_r);
+      a_g = __fmaf_rn(aT, pa.y, a_g);
+      a_b = __fmaf_rn(aT, pa.z, a_b);
+      a_d = __fmaf_rn(aT, pa.w, a_d);
+      const float gd = a.G * dL_dalpha;              // dL/dopacity contribution; alpha clamp is straight-through
+      a_o += gd;
+      const float gg = gd * op;                      // G * dL/dG
+      const float gxv = gg * dx, gyv = gg * dy;
+      s_gx += gxv; s_gy += gyv;
+      s_gxx = __fmaf_rn(gxv, dx, s_gxx);
+      s_gxy = __fmaf_rn(gxv, dy, s_gxy);
+      s_gyy = __fmaf_rn(gyv, dy, s_gyy);
+    }
+  }
+  if (GW < kWave) {
+    // the PP groups saw disjoint pixels: add them up (fixed order), result valid in every group
+#pragma unroll
+    for (int off = GW; off < kWave; off <<= 1) {
+      s_gx += __shfl_xor(s_gx, off); s_gy += __shfl_xor(s_gy, off); s_gxx += __shfl_xor(s_gxx, off);
+      s_gxy += __shfl_xor(s_gxy, off); s_gyy += __shfl_xor(s_gyy, off); a_o += __shfl_xor(a_o, off);
+      a_r += __shfl_xor(a_r, off); a_g += __shfl_xor(a_g, off); a_b += __shfl_xor(a_b, off); a_d += __shfl_xor(a_d, off);
+    }
+  }
+  if (valid && sub == 0) {
+    // slot of this (tile, Gaussian) pair inside the Gaussian's own run of partials
+    ushort4 r = rect[g];
+    uint64_t slot = (uint64_t)offsets[g] + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
+    if ((int64_t)slot < cap) {
+      float dmx = (-(A * s_gx) - B * s_gy) * halfW;
+      float dmy = (-(Cc * s_gy) - B * s_gx) * halfH;
+      partials[slot * 3 + 0] = make_float4(dmx, dmy, -0.5f * s_gxx, -s_gxy);
+      partials[slot * 3 + 1] = make_float4(-0.5f * s_gyy, a_o, a_r, a_g);
+      partials[slot * 3 + 2] = make_float4(a_b, a_d, 0.f, 0.f);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) blend_bwd_kernel(
-    int H, int W, int gx, int gy, int sgx, int sgy, const uint2* __restrict__ ranges,
+    int H, int W, int gx, int gy, int sgx, int sgy, int64_t cap, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
     const float4* __restrict__ rgbd, const ushort4* __restrict__ rect, const uint32_t* __restrict__ offsets,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ tile_maxc, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    float4* __restrict__ partials, int64_t cap) {
+    float4* __restrict__ partials) {
+  __shared__ float4 pixbuf[4][2][kWave];      // per wave: pixel gradients + running (T, S) carries
   const int nblocks = sgx * sgy;
   const int st = super_tile_of_block(blockIdx.x, nblocks);
   if (st >= nblocks) return;
@@ -126,117 +330,92 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   if (tx >= gx || ty >= gy) return;
   const int tile = ty * gx + tx;
   const uint2 rng = ranges[tile];
-  const int count = (int)(rng.y - rng.x);
+  const int64_t begin = rng.x;
+  const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
+  const int count = endc > begin ? (int)(endc - begin) : 0;
   if (count == 0) return;
   const int eff = min(count, (int)tile_maxc[tile]);
 
-  // pixel state: lane p owns pixel p of the tile; the pixel loop broadcasts it with v_readlane
-  const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
-  float dCr = 0.f, dCg = 0.f, dCb = 0.f, dD = 0.f, Tc = 1.f, Sc = 0.f;
-  int ncont = 0;
-  if (inside) {
-    dCr = dL_dcolor[pix]; dCg = dL_dcolor[hw + pix]; dCb = dL_dcolor[2 * hw + pix];
-    dD = dL_ddepth ? dL_ddepth[pix] : 0.f;
-    Tc = final_T[pix];
-    ncont = (int)n_contrib[pix];
-    // the background term -T_final/(1-alpha_j) * (bg . dL/dC) has the same shape as "colour behind splat j"
-    Sc = Tc * (bg[0] * dCr + bg[1] * dCg + bg[2] * dCb);
+  // pairs the forward never reached (behind every pixel's last contributor) still own a slot: define it as zero
+  for (int idx = eff + lane; idx < count; idx += kWave) {
+    uint32_t g = point_list[begin + idx];
+    ushort4 r = rect[g];
+    uint64_t slot = (uint64_t)offsets[g] + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
+    if ((int64_t)slot < cap) {
+      partials[slot * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      partials[slot * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      partials[slot * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
+  if (eff == 0) return;
+
+  // pixel state into the wave's LDS slice (lane p = pixel p of the tile)
+  float4* pixA = pixbuf[wv][0];
+  float4* pixB = pixbuf[wv][1];
+  {
+    const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+    float dCr = 0.f, dCg = 0.f, dCb = 0.f, dD = 0.f, Tc = 1.f, Sc = 0.f;
+    int ncont = 0;
+    if (inside) {
+      dCr = dL_dcolor[pix]; dCg = dL_dcolor[hw + pix]; dCb = dL_dcolor[2 * hw + pix];
+      dD = dL_ddepth ? dL_ddepth[pix] : 0.f;
+      Tc = final_T[pix];
+      ncont = (int)n_contrib[pix];
+      // the background term -T_final/(1-alpha_j) * (bg . dL/dC) has the same shape as "colour behind splat j"
+      Sc = Tc * (bg[0] * dCr + bg[1] * dCg + bg[2] * dCb);
+    }
+    pixA[lane] = make_float4(dCr, dCg, dCb, dD);
+    pixB[lane] = make_float4(Tc, Sc, __int_as_float(ncont), 0.f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
   const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
 
-  const int nchunks = (eff + kWave - 1) / kWave;
-  for (int c = nchunks - 1; c >= 0; --c) {
-    // lanes are mapped to splats in REVERSE list order so that "everything behind me" is a prefix scan over lanes
-    const int idx = c * kWave + (kWave - 1 - lane);
-    const bool valid = idx < eff;
-    uint32_t g = 0;
-    float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
-    if (valid) {
-      g = point_list[rng.x + idx];
-      float2 m = xy[g];
-      float4 co = conic_o[g];
-      float4 cd = rgbd[g];
-      mx = m.x; my = m.y; A = co.x; B = co.y; Cc = co.z; op = co.w; cr = cd.x; cg = cd.y; cb = cd.z; dep = cd.w;
-    }
-    float s_g = 0.f, s_gx = 0.f, s_gy = 0.f, s_gxx = 0.f, s_gxy = 0.f, s_gyy = 0.f;
-    float a_o = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
-    (void)s_g;
-
-    for (int p = 0; p < kWave; ++p) {
-      const int nc = __builtin_amdgcn_readlane(ncont, p);
-      if (nc <= c * kWave) continue;                       // this pixel stopped before this chunk (uniform)
-      const float pdr = readlane_f(dCr, p), pdg = readlane_f(dCg, p), pdb = readlane_f(dCb, p), pdd = readlane_f(dD, p);
-      const float pT = readlane_f(Tc, p), pS = readlane_f(Sc, p);
-      const float dx = mx - (tx0 + (float)(p & 7)), dy = my - (ty0 + (float)(p >> 3));
-      AlphaEval a = eval_alpha(dx, dy, A, B, Cc, op);
-      const bool ok = valid && (idx < nc) && a.ok;
-      const float om = ok ? 1.f - a.alpha : 1.f;
-      const float P = wave_scan_mul(om);                   // prod over this splat and all behind it (in chunk)
-      const float E = wave_shr1(P, 1.f);                   // prod over all strictly behind it
-      const float rP = __builtin_amdgcn_rcpf(P);
-      const float Tj = pT * rP;                            // transmittance in front of splat j
-      const float inv1ma = E * rP;                         // 1 / (1 - alpha_j)
-      const float w = __fmaf_rn(pdr, cr, __fmaf_rn(pdg, cg, __fmaf_rn(pdb, cb, pdd * dep)));
-      const float aT = ok ? a.alpha * Tj : 0.f;
-      const float q = w * aT;
-      const float Qi = wave_scan_add(q);                   // inclusive: this splat and all behind it
-      const float Sx = (Qi - q) + pS;                      // strictly behind (+ carried chunks + background term)
-      const float dL_dalpha = __fmaf_rn(Tj, w, -Sx * inv1ma);
-      // carry to the next (nearer) chunk: lane 63 holds the nearest splat of this chunk
-      const float nT = readlane_f(Tj, 63), nS = readlane_f(Qi, 63) + pS;
-      if (lane == p) { Tc = nT; Sc = nS; }
-      if (ok) {
-        a_r = __fmaf_rn(aT, pdr, a_r);
-        a_g = __fmaf_rn(aT, pdg, a_g);
-        a_b = __fmaf_rn(aT, pdb, a_b);
-        a_d = __fmaf_rn(aT, pdd, a_d);
-        const float gd = a.G * dL_dalpha;                  // dL/dopacity contribution; alpha clamp is straight-through
-        a_o += gd;
-        const float gg = gd * op;                          // G * dL/dG
-        const float gxv = gg * dx, gyv = gg * dy;
-        s_gx += gxv; s_gy += gyv;
-        s_gxx = __fmaf_rn(gxv, dx, s_gxx);
-        s_gxy = __fmaf_rn(gxv, dy, s_gxy);
-        s_gyy = __fmaf_rn(gyv, dy, s_gyy);
-      }
-    }
-
-    if (valid) {
-      // slot of this (tile, Gaussian) pair inside the Gaussian's own run of partials
-      ushort4 r = rect[g];
-      uint64_t slot = (uint64_t)offsets[g] + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
-      if ((int64_t)slot < cap) {
-        float dmx = (-(A * s_gx) - B * s_gy) * halfW;
-        float dmy = (-(Cc * s_gy) - B * s_gx) * halfH;
-        partials[slot * 3 + 0] = make_float4(dmx, dmy, -0.5f * s_gxx, -s_gxy);
-        partials[slot * 3 + 1] = make_float4(-0.5f * s_gyy, a_o, a_r, a_g);
-        partials[slot * 3 + 2] = make_float4(a_b, a_d, 0.f, 0.f);
-      }
+  if (eff <= 16) {
+    bwd_chunk<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, offsets, tx, ty, halfW,
+                  halfH, partials, cap);
+  } else if (eff <= 32) {
+    bwd_chunk<32>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, offsets, tx, ty, halfW,
+                  halfH, partials, cap);
+  } else {
+    const int nchunks = (eff + kWave - 1) / kWave;
+    for (int c = nchunks - 1; c >= 0; --c) {
+      bwd_chunk<64>(lane, c, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, offsets, tx, ty,
+                    halfW, halfH, partials, cap);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-// (tile, Gaussian) pairs that the forward never reached (beyond every pixel's last contributor, or in tiles whose
-// pixels all terminated early) still own a slot: zero them so the gather in preprocess_bwd reads defined data.
-__global__ void __launch_bounds__(256) zero_partials_kernel(float4* __restrict__ partials, const SavedHeader* __restrict__ hdr) {
-  size_t n = (size_t)hdr->sorted_count * 3;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    partials[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-void launch_blend_fwd(const SgrSettings& s, const SgrOutputs& out, const Layout& L, char* saved, hipStream_t st) {
+template <int SORT_MAX>
+static void launch_blend_fwd_t(const SgrSettings& s, const SgrOutputs& out, const Layout& L, char* saved, char* scratch,
+                               hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
-  ProfScope prof(PK_BLEND_FWD, st);
-  hipLaunchKernelGGL(blend_fwd_kernel, dim3(grid), dim3(256), 0, st, s.image_height, s.image_width, L.gx, L.gy, L.sgx,
-                     L.sgy, (const uint2*)(saved + L.o_ranges), (const uint32_t*)(saved + L.o_point_list),
-                     (const float2*)(saved + L.o_xy), (const float4*)(saved + L.o_conic_o),
-                     (const float4*)(saved + L.o_rgbd), s.bg, out.color, out.depth, out.opacity,
-                     (float*)(saved + L.o_final_T), (uint32_t*)(saved + L.o_n_contrib),
+  constexpr size_t lds = 4 * (size_t)(SORT_MAX * 8 + kWave * 48);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(blend_fwd_kernel<SORT_MAX>, dim3(grid), dim3(256), lds, st, s.image_height, s.image_width, L.gx, L.gy,
+                     L.sgx, L.sgy, L.cap, (const uint2*)(saved + L.o_ranges), (uint64_t*)(scratch + L.o_entries),
+                     (uint32_t*)(saved + L.o_point_list), (const float2*)(saved + L.o_xy),
+                     (const float4*)(saved + L.o_conic_o), (const float4*)(saved + L.o_rgbd), s.bg, out.color, out.depth,
+                     out.opacity, (float*)(saved + L.o_final_T), (uint32_t*)(saved + L.o_n_contrib),
                      (uint32_t*)(saved + L.o_tile_maxc), out.n_touched);
+}
+
+void launch_blend_fwd(const SgrSettings& s, const SgrOutputs& out, const Layout& L, char* saved, char* scratch, hipStream_t st) {
+  ProfScope prof(PK_BLEND_FWD, st);
+  // the caller sizes `capacity` at ~2x the pair count it has seen: capacity / tiles / 2 estimates the mean list length
+  const int64_t mean_len = L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
+  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy>(s, out, L, saved, scratch, st);
+  else launch_blend_fwd_t<kSortLight>(s, out, L, saved, scratch, st);
 }
 
 void launch_blend_bwd(const SgrSettings& s, const SgrGradOutputs& go, const Layout& L, const char* saved, char* scratch,
@@ -244,18 +423,14 @@ void launch_blend_bwd(const SgrSettings& s, const SgrGradOutputs& go, const Layo
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
   float4* partials = (float4*)(scratch + L.o_partials);
-  {
-    ProfScope prof(PK_ZERO, st);
-    hipLaunchKernelGGL(zero_partials_kernel, dim3(1024), dim3(256), 0, st, partials, (const SavedHeader*)(saved + L.o_hdr));
-  }
   ProfScope prof(PK_BLEND_BWD, st);
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), 0, st, s.image_height, s.image_width, L.gx, L.gy, L.sgx,
-                     L.sgy, (const uint2*)(saved + L.o_ranges), (const uint32_t*)(saved + L.o_point_list),
+                     L.sgy, L.cap, (const uint2*)(saved + L.o_ranges), (const uint32_t*)(saved + L.o_point_list),
                      (const float2*)(saved + L.o_xy), (const float4*)(saved + L.o_conic_o),
                      (const float4*)(saved + L.o_rgbd), (const ushort4*)(saved + L.o_rect),
                      (const uint32_t*)(saved + L.o_offsets), s.bg, (const float*)(saved + L.o_final_T),
                      (const uint32_t*)(saved + L.o_n_contrib), (const uint32_t*)(saved + L.o_tile_maxc), go.dL_dcolor,
-                     go.dL_ddepth, partials, L.cap);
+                     go.dL_ddepth, partials);
 }
 
 }  // namespace sgr

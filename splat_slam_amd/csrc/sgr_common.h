@@ -33,7 +33,8 @@ struct SavedHeader {
   uint32_t num_rendered;   // R: total (tile, Gaussian) pairs demanded (may exceed capacity)
   uint32_t overflow;       // != 0 when R > capacity (pairs were dropped)
   uint32_t sorted_count;   // number of pairs actually binned = min(R, capacity)
-  uint32_t pad[13];
+  uint32_t num_visible;    // V: Gaussians with radii > 0
+  uint32_t pad[12];
 };
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -46,16 +47,16 @@ struct Layout {
   int sgx, sgy;            // 16x16 super-tile grid (one 256-thread workgroup)
   int tile_bits;
   // saved
-  size_t o_hdr, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
-      o_tile_maxc, o_final_T, o_n_contrib, saved_bytes;
+  size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
+      o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
+      saved_bytes, zero_bytes;
   // scratch (forward)
-  size_t o_keys_in, o_keys_out, o_vals_in, o_scan_tmp, o_sort_tmp, scan_tmp_bytes, sort_tmp_bytes;
+  size_t o_entries;
   // scratch (backward) -- aliases the forward scratch
   size_t o_partials, o_tau_part, scratch_bytes;
   int pre_blocks;
 
-  __host__ Layout(int N_, int H_, int W_, int64_t cap_, size_t scan_tmp, size_t sort_tmp)
-      : N(N_), H(H_), W(W_), cap(cap_) {
+  __host__ Layout(int N_, int H_, int W_, int64_t cap_) : N(N_), H(H_), W(W_), cap(cap_) {
     gx = (W + kTile - 1) / kTile;
     gy = (H + kTile - 1) / kTile;
     ntiles = gx * gy;
@@ -66,7 +67,11 @@ struct Layout {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
     size_t n = (size_t)(N > 0 ? N : 1), hw = (size_t)H * W, c = (size_t)(cap > 0 ? cap : 1);
+    pre_blocks = (N + 255) / 256;
+    size_t nb = (size_t)(pre_blocks > 0 ? pre_blocks : 1);
     o_hdr = take(sizeof(SavedHeader));
+    o_tile_count = take((size_t)ntiles * 4);     // hdr + tile_count are zeroed by ONE memset per forward
+    zero_bytes = o;
     o_xy = take(n * 8);
     o_conic_o = take(n * 16);
     o_rgbd = take(n * 16);
@@ -79,19 +84,17 @@ struct Layout {
     o_tile_maxc = take((size_t)ntiles * 4);
     o_final_T = take(hw * 4);
     o_n_contrib = take(hw * 4);
+    o_block_touched = take(nb * 4);
+    o_block_vis = take(nb * 4);
+    o_block_base_t = take(nb * 4);
+    o_block_base_v = take(nb * 4);
+    o_vis_list = take(n * 4);
     saved_bytes = o;
 
-    scan_tmp_bytes = scan_tmp;
-    sort_tmp_bytes = sort_tmp;
     o = 0;
-    o_keys_in = take(c * 8);
-    o_keys_out = take(c * 8);
-    o_vals_in = take(c * 4);
-    o_scan_tmp = take(scan_tmp);
-    o_sort_tmp = take(sort_tmp);
+    o_entries = take(c * 8);
     size_t fwd = o;
     o = 0;
-    pre_blocks = (N + 255) / 256;
     o_partials = take(c * 48);
     o_tau_part = take((size_t)(pre_blocks > 0 ? pre_blocks : 1) * 6 * 4);
     scratch_bytes = fwd > o ? fwd : o;
@@ -99,7 +102,7 @@ struct Layout {
 };
 
 // ---- optional per-kernel event timing (sgr_profile_enable / sgr_profile_read)
-enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_DUP, PK_SORT, PK_RANGES, PK_BLEND_FWD, PK_ZERO, PK_BLEND_BWD, PK_PRE_BWD };
+enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_SCATTER, PK_UNUSED3, PK_UNUSED4, PK_BLEND_FWD, PK_UNUSED6, PK_BLEND_BWD, PK_PRE_BWD };
 void prof_begin(int kind, hipStream_t st);
 void prof_end(int kind, hipStream_t st);
 struct ProfScope {
@@ -157,6 +160,33 @@ __device__ __forceinline__ float wave_scan_mul(float v) {
   v *= dpp_f<DPP_ROW_BCAST31, 0xc>(1.f, v);
   return v;
 }
+// inclusive prefix sum of unsigned ints over lanes 0..63
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+  v += dpp_u<DPP_ROW_SHR1>(v);
+  v += dpp_u<DPP_ROW_SHR2>(v);
+  v += dpp_u<DPP_ROW_SHR4>(v);
+  v += dpp_u<DPP_ROW_SHR8>(v);
+  v += dpp_u<DPP_ROW_BCAST15, 0xa>(v);
+  v += dpp_u<DPP_ROW_BCAST31, 0xc>(v);
+  return v;
+}
+// exclusive prefix of `v` inside a 256-thread block (4 waves) + block total; `red` = 4 uints of LDS
+__device__ __forceinline__ uint32_t block256_exclusive_scan(uint32_t v, uint32_t* red, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t inc = wave_scan_add_u32(v);
+  if (lane == 63) red[wv] = inc;
+  __syncthreads();
+  uint32_t w0 = red[0], w1 = red[1], w2 = red[2], w3 = red[3];
+  __syncthreads();
+  total = w0 + w1 + w2 + w3;
+  uint32_t base = (wv > 0 ? w0 : 0u) + (wv > 1 ? w1 : 0u) + (wv > 2 ? w2 : 0u);
+  return base + inc - v;
+}
+
 // value of lane-1 (lane 0 receives `fill`)
 __device__ __forceinline__ float wave_shr1(float v, float fill) { return dpp_f<DPP_WAVE_SHR1>(fill, v); }
 

@@ -112,25 +112,35 @@ __device__ __forceinline__ unsigned sh_to_rgb(int deg, const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------- forward
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(
-    int N, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod,
-    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    const float* __restrict__ means3D, const float* __restrict__ opacities, const float* __restrict__ shs,
-    const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ cov3D_precomp,
-    int gx, int gy, int sgx, int sgy,
-    int32_t* __restrict__ radii, float2* __restrict__ xy_out, float4* __restrict__ conic_o, float4* __restrict__ rgbd,
-    ushort4* __restrict__ rect_out, uint32_t* __restrict__ touched, uint8_t* __restrict__ clamped_out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  float vm[16], pm[16];
-  load16(viewmatrix, vm);
-  load16(projmatrix, pm);
+struct PreOut {
+  bool visible;      // radii > 0
+  float rad, px, py, A, B, C, opac, depth, rgb[3];
+  int x0, y0, x1, y1;
+  unsigned clamped;
+};
 
-  radii[i] = 0;
-  touched[i] = 0;
-
+__device__ __forceinline__ void preprocess_one(
+    int i, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod, const float* vm, const float* pm,
+    const float* __restrict__ campos, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int gx, int gy, int sgx, int sgy,
+    PreOut& o) {
+  o.visible = false;
+  o.x0 = o.x1 = o.y0 = o.y1 = 0;
+  // issue every per-Gaussian load before the first dependent branch: one HBM round trip instead of four
   float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+  const float opac = opacities[i];
+  float S6[6], s_in[3] = {0.f, 0.f, 0.f}, q_in[4] = {1.f, 0.f, 0.f, 0.f};
+  if (cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S6[k] = cov3D_precomp[6 * i + k];
+  } else {
+    s_in[0] = scales[3 * i]; s_in[1] = scales[3 * i + 1]; s_in[2] = scales[3 * i + 2];
+    q_in[0] = rotations[4 * i]; q_in[1] = rotations[4 * i + 1]; q_in[2] = rotations[4 * i + 2]; q_in[3] = rotations[4 * i + 3];
+  }
+  float c_in[3] = {0.f, 0.f, 0.f};
+  if (colors_precomp) { c_in[0] = colors_precomp[3 * i]; c_in[1] = colors_precomp[3 * i + 1]; c_in[2] = colors_precomp[3 * i + 2]; }
+  else if (deg == 0) { c_in[0] = shs[(size_t)i * M * 3]; c_in[1] = shs[(size_t)i * M * 3 + 1]; c_in[2] = shs[(size_t)i * M * 3 + 2]; }
   float pv[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) pv[r] = vm[r] * p[0] + vm[4 + r] * p[1] + vm[8 + r] * p[2] + vm[12 + r];
@@ -142,15 +152,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   float pw = 1.f / (ph[3] + 1e-7f);
   float ndcx = ph[0] * pw, ndcy = ph[1] * pw;
 
-  float S6[6];
-  if (cov3D_precomp) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) S6[k] = cov3D_precomp[6 * i + k];
-  } else {
-    float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-    float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
-    cov3d_from_scale_rot(s, mod, q, S6);
-  }
+  if (!cov3D_precomp) cov3d_from_scale_rot(s_in, mod, q_in, S6);
   float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
   Ewa e;
   ewa_project(pv, vm, S6, fx, fy, 1.3f * tanfovx, 1.3f * tanfovy, e);
@@ -172,7 +174,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   int ry1 = min(sgy, max(0, (int)((py + rad + (kRefTile - 1)) / (float)kRefTile)));
   if ((rx1 - rx0) * (ry1 - ry0) == 0) return;
 
-  float opac = opacities[i];
   // our bins are 8x8 (one wave): refine the rectangle, then drop bins no pixel of which can pass alpha >= 1/255.
   int x0 = min(gx, 2 * rx0), x1 = min(gx, 2 * rx1), y0 = min(gy, 2 * ry0), y1 = min(gy, 2 * ry1);
   {
@@ -197,24 +198,74 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     }
   }
 
-  float rgb[3];
-  unsigned clamped = 0;
+  o.clamped = 0;
   if (colors_precomp) {
-    rgb[0] = colors_precomp[3 * i]; rgb[1] = colors_precomp[3 * i + 1]; rgb[2] = colors_precomp[3 * i + 2];
+    o.rgb[0] = c_in[0]; o.rgb[1] = c_in[1]; o.rgb[2] = c_in[2];
+  } else if (deg == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float r = SH_C0 * c_in[c] + 0.5f;
+      if (r < 0.f) { o.clamped |= 1u << c; r = 0.f; }
+      o.rgb[c] = r;
+    }
   } else {
     float dir[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
     float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
     dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
-    clamped = sh_to_rgb(deg, shs + (size_t)i * M * 3, dir, rgb);
+    o.clamped = sh_to_rgb(deg, shs + (size_t)i * M * 3, dir, o.rgb);
   }
+  o.visible = true;
+  o.rad = rad; o.px = px; o.py = py; o.A = A; o.B = B; o.C = C; o.opac = opac; o.depth = pv[2];
+  o.x0 = x0; o.y0 = y0; o.x1 = x1; o.y1 = y1;
+}
 
-  radii[i] = (int32_t)rad;
-  xy_out[i] = make_float2(px, py);
-  conic_o[i] = make_float4(A, B, C, opac);
-  rgbd[i] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
-  rect_out[i] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
-  touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
-  clamped_out[i] = (uint8_t)clamped;
+// K1: per-Gaussian projection + footprint + 8x8 bin rectangle, and the first half of the binning:
+//   * per-tile pair counts (one fire-and-forget atomic per (tile, Gaussian) pair),
+//   * in-block exclusive prefix of `touched` / `visible` + the block totals (finished by tile_scan_kernel: a
+//     deterministic two-level scan instead of a device-wide scan library call).
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(
+    int N, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+    const float* __restrict__ means3D, const float* __restrict__ opacities, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp,
+    int gx, int gy, int sgx, int sgy,
+    int32_t* __restrict__ radii, int32_t* __restrict__ n_touched, float2* __restrict__ xy_out,
+    float4* __restrict__ conic_o, float4* __restrict__ rgbd, ushort4* __restrict__ rect_out,
+    uint32_t* __restrict__ touched, uint32_t* __restrict__ offsets_rel, uint8_t* __restrict__ clamped_out,
+    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ block_touched, uint32_t* __restrict__ block_vis) {
+  __shared__ uint32_t red[4];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  PreOut o;
+  o.visible = false;
+  o.x0 = o.x1 = o.y0 = o.y1 = 0;
+  if (i < N) {
+    float vm[16], pm[16];
+    load16(viewmatrix, vm);
+    load16(projmatrix, pm);
+    preprocess_one(i, H, W, deg, M, tanfovx, tanfovy, mod, vm, pm, campos, means3D, opacities, shs, colors_precomp,
+                   scales, rotations, cov3D_precomp, gx, gy, sgx, sgy, o);
+  }
+  uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
+  if (i < N) {
+    radii[i] = o.visible ? (int32_t)o.rad : 0;
+    n_touched[i] = 0;
+    touched[i] = cnt;
+    if (o.visible) {
+      xy_out[i] = make_float2(o.px, o.py);
+      conic_o[i] = make_float4(o.A, o.B, o.C, o.opac);
+      rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+      rect_out[i] = make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
+      clamped_out[i] = (uint8_t)o.clamped;
+      for (int y = o.y0; y < o.y1; ++y)
+        for (int x = o.x0; x < o.x1; ++x) atomicAdd(&tile_count[y * gx + x], 1u);
+    }
+  }
+  uint32_t tot_t, tot_v;
+  uint32_t ex = block256_exclusive_scan(cnt, red, tot_t);
+  (void)block256_exclusive_scan(o.visible ? 1u : 0u, red, tot_v);
+  if (i < N) offsets_rel[i] = ex;
+  if (threadIdx.x == 0) { block_touched[blockIdx.x] = tot_t; block_vis[blockIdx.x] = tot_v; }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -232,10 +283,20 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     float* __restrict__ dmeans3D, float* __restrict__ dmeans2D, float* __restrict__ dopac, float* __restrict__ dshs,
     float* __restrict__ dcolors, float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D,
     float* __restrict__ tau_part, int accumulate, float* __restrict__ stat_accum, float* __restrict__ stat_denom,
-    float* __restrict__ stat_maxr) {
+    float* __restrict__ stat_maxr, const uint32_t* __restrict__ vis_list, const SavedHeader* __restrict__ hdr) {
+  // write mode: thread = Gaussian (all N are written).  accumulate mode: thread = entry of the compact visible list
+  // built by the forward, so the launch does V (not N) Gaussians' worth of work and touches nothing else.
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live;
+  if (vis_list) {
+    const int V = (int)hdr->num_visible;
+    if ((int)(blockIdx.x * blockDim.x) >= V) return;          // whole block beyond the list (uniform)
+    live = i < V;
+    i = live ? (int)vis_list[i] : N;
+  } else {
+    live = (i < N) && (radii[i] > 0);
+  }
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  bool live = (i < N) && (radii[i] > 0);
 
   float g_m2[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_rgb[3] = {0.f, 0.f, 0.f}, g_dep = 0.f;
   float g_p[3] = {0.f, 0.f, 0.f};        // dL/dmean3D
@@ -499,9 +560,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 }
 
 // second stage: one block sums the per-block partials in a fixed order
-__global__ void __launch_bounds__(384) tau_reduce_kernel(const float* __restrict__ tau_part, int nblocks, float* __restrict__ dtau) {
+__global__ void __launch_bounds__(384) tau_reduce_kernel(const float* __restrict__ tau_part, int nblocks, float* __restrict__ dtau,
+                                                         const SavedHeader* __restrict__ hdr) {
   __shared__ float red[6][64];
   int k = threadIdx.x / 64, lane = threadIdx.x & 63;
+  if (hdr) nblocks = ((int)hdr->num_visible + 255) / 256;     // accumulate mode: only these blocks wrote a partial
   float acc = 0.f;
   for (int b = lane; b < nblocks; b += 64) acc += tau_part[(size_t)b * 6 + k];
   red[k][lane] = acc;
@@ -516,14 +579,16 @@ __global__ void __launch_bounds__(384) tau_reduce_kernel(const float* __restrict
 void launch_preprocess_fwd(const SgrSettings& s, const SgrInputs& in, const SgrOutputs& out, const Layout& L, char* saved,
                            hipStream_t st) {
   if (s.num_gaussians <= 0) return;
-  int blocks = (s.num_gaussians + 255) / 256;
+  int blocks = L.pre_blocks;
   ProfScope prof(PK_PRE_FWD, st);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, st, s.num_gaussians, s.image_height,
                      s.image_width, s.sh_degree, s.sh_coeffs, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix,
                      s.projmatrix, s.campos, in.means3D, in.opacities, in.shs, in.colors_precomp, in.scales,
-                     in.rotations, in.cov3D_precomp, L.gx, L.gy, L.sgx, L.sgy, out.radii,
+                     in.rotations, in.cov3D_precomp, L.gx, L.gy, L.sgx, L.sgy, out.radii, out.n_touched,
                      (float2*)(saved + L.o_xy), (float4*)(saved + L.o_conic_o), (float4*)(saved + L.o_rgbd),
-                     (ushort4*)(saved + L.o_rect), (uint32_t*)(saved + L.o_touched), (uint8_t*)(saved + L.o_clamped));
+                     (ushort4*)(saved + L.o_rect), (uint32_t*)(saved + L.o_touched), (uint32_t*)(saved + L.o_offsets),
+                     (uint8_t*)(saved + L.o_clamped), (uint32_t*)(saved + L.o_tile_count),
+                     (uint32_t*)(saved + L.o_block_touched), (uint32_t*)(saved + L.o_block_vis));
 }
 
 void launch_preprocess_bwd(const SgrSettings& s, const SgrInputs& in, const int32_t* radii, const SgrGradInputs& g,
@@ -540,9 +605,11 @@ void launch_preprocess_bwd(const SgrSettings& s, const SgrInputs& in, const int3
                      (const float4*)(scratch + L.o_partials), L.cap, g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dopacities,
                      g.dL_dshs, g.dL_dcolors_precomp, g.dL_dscales, g.dL_drotations, g.dL_dcov3D_precomp, tau_part,
                      g.accumulate, g.stat_grad_accum, (g.stat_grad_accum ? g.stat_denom : nullptr),
-                     (g.stat_grad_accum ? g.stat_max_radii : nullptr));
+                     (g.stat_grad_accum ? g.stat_max_radii : nullptr),
+                     g.accumulate ? (const uint32_t*)(saved + L.o_vis_list) : nullptr, (const SavedHeader*)(saved + L.o_hdr));
   if (g.dL_dtau)
-    hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(384), 0, st, tau_part, blocks, g.dL_dtau);
+    hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(384), 0, st, tau_part, blocks, g.dL_dtau,
+                       g.accumulate ? (const SavedHeader*)(saved + L.o_hdr) : nullptr);
 }
 
 }  // namespace sgr

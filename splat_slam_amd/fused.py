@@ -43,6 +43,59 @@ class _ViewBuffers:
         self.capacity = 0
         self.gt_depth = None
         self.depth_src = None
+        self.mv = None
+        self.mv_key = None
+
+
+class _ExposureSlab:
+    """Exposure parameters (a, b) of every camera in one device slab + Adam moments, so the keyframe optimiser step
+    (src/mapper.py:561, lr 0.01, torch defaults betas (0.9, 0.999), eps 1e-8) is ONE masked launch."""
+
+    def __init__(self, device, capacity=4096):
+        z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=device)
+        self.param, self.grad, self.m, self.v = z(capacity, 2), z(capacity, 2), z(capacity, 2), z(capacity, 2)
+        self.step = z(capacity, dt=torch.int32)
+        self.active = z(capacity, dt=torch.int32)
+        self.ones = torch.ones(capacity, dtype=torch.int32, device=device)
+        self.rows = {}
+
+    def row_of(self, cam):
+        return self.rows.get(id(cam))
+
+    def attach(self, cam):
+        r = self.rows.get(id(cam))
+        if r is None:
+            r = len(self.rows)
+            if r >= self.param.shape[0]:
+                raise RuntimeError("exposure slab full")
+            self.rows[id(cam)] = r
+            with torch.no_grad():
+                self.param[r, 0] = cam.exposure_a.detach()[0]
+                self.param[r, 1] = cam.exposure_b.detach()[0]
+            cam.exposure_a = torch.nn.Parameter(self.param[r, 0:1])     # views: the slab IS the parameter storage
+            cam.exposure_b = torch.nn.Parameter(self.param[r, 1:2])
+        return r
+
+    def reset(self, rows):
+        self.active.zero_()
+        if rows:
+            idx = torch.tensor(rows, dtype=torch.long, device=self.param.device)
+            self.m[idx] = 0
+            self.v[idx] = 0
+            self.step[idx] = 0
+            self.active[idx] = 1
+
+    def step_mask(self, lib, rows, stream):
+        n = max(rows) + 1
+        nat.check(lib.sgr_masked_adam(n, 2, self.param.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                      self.step.data_ptr(), self.active.data_ptr(), 0.01, 0.9, 0.999, 1e-8, stream),
+                  "sgr_masked_adam")
+
+    def step_rows(self, lib, row, n, stream):
+        o = 8 * row
+        nat.check(lib.sgr_masked_adam(n, 2, self.param.data_ptr() + o, self.grad.data_ptr() + o, self.m.data_ptr() + o,
+                                      self.v.data_ptr() + o, self.step.data_ptr() + 4 * row, self.ones.data_ptr(), 0.01, 0.9,
+                                      0.999, 1e-8, stream), "sgr_masked_adam")
 
 
 class FusedMappingLoop(MappingLoop):
@@ -57,6 +110,9 @@ class FusedMappingLoop(MappingLoop):
         self._scratch = None
         self._since_check = 0
         self.last_losses = []
+        self._exp = None
+        self._exp_rows = []
+        self._scratch_gen = 0
 
     # ------------------------------------------------------------------------------------------------ state
     def _stream(self):
@@ -115,6 +171,8 @@ class FusedMappingLoop(MappingLoop):
             vb.capacity = cap
         if self._scratch is None or self._scratch.numel() < tb:
             self._scratch = torch.empty(tb, dtype=torch.uint8, device=self.device)
+            self._scratch_gen += 1
+            self._views_dirty()                       # cached SgrMapViews point into the old scratch block
         return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), self._scratch.data_ptr(), self._scratch.numel(), cap)
 
     # ------------------------------------------------------------------------------------------------ pieces
@@ -124,15 +182,34 @@ class FusedMappingLoop(MappingLoop):
                                         gm._opacity.data_ptr(), a["act_scale"].data_ptr(), a["act_rot"].data_ptr(),
                                         a["act_opac"].data_ptr(), self._stream()), "sgr_activate")
 
-    def _forward(self, cam, vb):
+    def _inputs(self):
         gm, a = self.gaussians, self._acc
+        return nat.SgrInputs(gm._xyz.data_ptr(), a["act_opac"].data_ptr(), gm._features_dc.data_ptr(), None,
+                             a["act_scale"].data_ptr(), a["act_rot"].data_ptr(), None)
+
+    def _grad_sinks(self, stats):
+        gm, a = self.gaussians, self._acc
+        return nat.SgrGradInputs(a["xyz"].data_ptr(), None, a["opacity"].data_ptr(), a["f_dc"].data_ptr(), None,
+                                 a["scaling"].data_ptr(), a["rotation"].data_ptr(), None, None, 1,
+                                 gm.xyz_gradient_accum.data_ptr() if stats else None,
+                                 gm.denom.data_ptr() if stats else None, gm.max_radii2D.data_ptr() if stats else None)
+
+    def _map_view(self, cam, initialization=False):
+        """The cached SgrMapView of a camera (pointers into persistent buffers).  The first use at a new map size
+        renders once synchronously to learn the camera's pair count and sizes its saved block at 2x."""
+        vb = self._view(cam)
+        gm = self.gaussians
         N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
+        view, full, center = cam._matrices()
+        key = (view.data_ptr(), full.data_ptr(), vb.capacity, vb.gt_depth.data_ptr(), cam.original_image.data_ptr(),
+               cam.exposure_a.data_ptr(), bool(initialization))
+        if vb.mv is not None and vb.mv_key == key and vb.capacity > 0:
+            return vb.mv
         s = self._settings(cam, N)
-        inp = nat.SgrInputs(gm._xyz.data_ptr(), a["act_opac"].data_ptr(), gm._features_dc.data_ptr(), None,
-                            a["act_scale"].data_ptr(), a["act_rot"].data_ptr(), None)
         out = nat.SgrOutputs(vb.color.data_ptr(), vb.depth.data_ptr(), vb.opacity.data_ptr(), vb.radii.data_ptr(),
                              vb.n_touched.data_ptr())
-        if vb.capacity == 0:        # first render of this camera at this map size: learn the pair count (one sync)
+        if vb.capacity == 0:
+            inp = self._inputs()
             cap, R = 1 << 16, C.c_int64(0)
             while True:
                 ws = self._workspace(vb, N, H, W, cap)
@@ -142,39 +219,47 @@ class FusedMappingLoop(MappingLoop):
                     continue
                 nat.check(rc, "sgr_forward")
                 break
-            want = max(1 << 16, int(R.value * 2))
-            if want != cap:
-                ws = self._workspace(vb, N, H, W, want)   # re-size for the async steady state and render again
-                nat.check(self.lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), None, self._stream()),
-                          "sgr_forward")
+            cap = max(1 << 16, int(R.value * 2))
         else:
-            ws = self._workspace(vb, N, H, W, vb.capacity)
-            nat.check(self.lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), None, self._stream()),
-                      "sgr_forward")
-        return s, inp, ws
+            cap = vb.capacity
+        ws = self._workspace(vb, N, H, W, cap)
+        mv = nat.SgrMapView()
+        mv.settings, mv.out, mv.ws = s, out, ws
+        mv.gt_image, mv.gt_depth = cam.original_image.data_ptr(), vb.gt_depth.data_ptr()
+        mv.exposure_a = None if initialization else cam.exposure_a.data_ptr()
+        mv.exposure_b = None if initialization else cam.exposure_b.data_ptr()
+        mv.loss, mv.dL_dimage, mv.dL_ddepth = vb.loss.data_ptr(), vb.d_color.data_ptr(), vb.d_depth.data_ptr()
+        row = self._exp.row_of(cam) if self._exp is not None else None
+        mv.dL_dexposure = vb.d_exp.data_ptr() if row is None else self._exp.grad.data_ptr() + 8 * row
+        mv.dL_dtau = vb.d_tau.data_ptr()
+        mv.loss_scratch, mv.loss_scratch_bytes = vb.loss_scratch.data_ptr(), vb.loss_scratch.numel()
+        vb.mv, vb.mv_key = mv, (view.data_ptr(), full.data_ptr(), cap, vb.gt_depth.data_ptr(),
+                                cam.original_image.data_ptr(), cam.exposure_a.data_ptr(), bool(initialization))
+        return mv
+
+    def _run_views(self, cams, initialization=False, stats=True, forward_only=False):
+        """ONE host call for all views of the iteration: forward -> loss -> backward(accumulate) each."""
+        n = len(cams)
+        while True:                                   # a growing shared scratch block invalidates earlier structs
+            gen = self._scratch_gen
+            mvs = [self._map_view(c, initialization) for c in cams]
+            if gen == self._scratch_gen:
+                break
+        arr = (nat.SgrMapView * n)(*mvs)
+        inp = self._inputs()
+        gi = self._grad_sinks(stats)
+        tr = self.config["mapping"]["Training"]
+        # the scratch block is shared: size it for the largest capacity among these views
+        nat.check(self.lib.sgr_map_views(n, arr, C.byref(inp), C.byref(gi), float(tr.get("alpha", 0.95)),
+                                         float(tr["rgb_boundary_threshold"]), int(forward_only), self._stream()),
+                  "sgr_map_views")
 
     def _view_step(self, cam, initialization=False, stats=True):
-        gm, a = self.gaussians, self._acc
-        vb = self._view(cam)
-        s, inp, ws = self._forward(cam, vb)
-        H, W = int(cam.image_height), int(cam.image_width)
-        tr = self.config["mapping"]["Training"]
-        ea = None if initialization else cam.exposure_a.data_ptr()
-        eb = None if initialization else cam.exposure_b.data_ptr()
-        nat.check(self.lib.sgr_mapping_loss(H, W, vb.color.data_ptr(), vb.depth.data_ptr(), cam.original_image.data_ptr(),
-                                            vb.gt_depth.data_ptr(), ea, eb, float(tr.get("alpha", 0.95)),
-                                            float(tr["rgb_boundary_threshold"]), 1.0, vb.loss.data_ptr(),
-                                            vb.d_color.data_ptr(), vb.d_depth.data_ptr(), vb.d_exp.data_ptr(),
-                                            vb.d_exp.data_ptr() + 4, vb.loss_scratch.data_ptr(), vb.loss_scratch.numel(),
-                                            self._stream()), "sgr_mapping_loss")
-        go = nat.SgrGradOutputs(vb.d_color.data_ptr(), vb.d_depth.data_ptr())
-        gi = nat.SgrGradInputs(a["xyz"].data_ptr(), None, a["opacity"].data_ptr(), a["f_dc"].data_ptr(), None,
-                               a["scaling"].data_ptr(), a["rotation"].data_ptr(), None, vb.d_tau.data_ptr(), 1,
-                               gm.xyz_gradient_accum.data_ptr() if stats else None,
-                               gm.denom.data_ptr() if stats else None, gm.max_radii2D.data_ptr() if stats else None)
-        nat.check(self.lib.sgr_backward(C.byref(s), C.byref(inp), vb.radii.data_ptr(), C.byref(go), C.byref(gi), C.byref(ws),
-                                        self._stream()), "sgr_backward")
-        return vb
+        self._run_views([cam], initialization=initialization, stats=stats)
+        return self._views[cam.uid]
+
+    def _forward(self, cam, vb=None):
+        self._run_views([cam], forward_only=True)
 
     def _adam(self, iso_weight, skip=()):
         gm, a = self.gaussians, self._acc
@@ -196,20 +281,59 @@ class FusedMappingLoop(MappingLoop):
         nat.check(self.lib.sgr_gaussian_adam_step(gm._xyz.shape[0], groups, b1, b2, gm.optimizer.param_groups[0]["eps"],
                                                   float(iso_weight), self._stream()), "sgr_gaussian_adam_step")
 
-    def _exposure_step(self, cams):
-        if self.keyframe_optimizers is None:
-            return
-        in_opt = {id(p) for g in self.keyframe_optimizers.param_groups for p in g["params"]}
-        for cam in cams:
-            vb = self._views[cam.uid]
-            if id(cam.exposure_a) in in_opt:
-                cam.exposure_a.grad = vb.d_exp[0:1].clone()
-                cam.exposure_b.grad = vb.d_exp[1:2].clone()
-            if id(cam.cam_rot_delta) in in_opt:
-                cam.cam_trans_delta.grad = vb.d_tau[:3].clone()
-                cam.cam_rot_delta.grad = vb.d_tau[3:].clone()
-        self.keyframe_optimizers.step()
-        self.keyframe_optimizers.zero_grad(set_to_none=True)
+    # ---- exposure (keyframe) optimiser: slab-resident parameters + one masked Adam launch
+    def build_keyframe_optimizers(self):
+        """mapper.py:1067-1111.  Exposure parameters live in a device slab (Camera.exposure_a/b are views of their
+        row); a fresh optimiser per keyframe = moments and step counters of the window rows reset."""
+        if self._exp is None:
+            self._exp = _ExposureSlab(self.device)
+        rows = []
+        for cam_idx in range(len(self.current_window)):
+            if self.current_window[cam_idx] == 0:
+                continue
+            cam = self.viewpoints[self.current_window[cam_idx]]
+            rows.append(self._exp.attach(cam))
+        for cam in self.viewpoints.values():
+            self._exp.attach(cam)                      # every camera writes its exposure gradient into its slab row
+        self._exp.reset(rows)
+        self._exp_rows = rows
+        self._views_dirty()
+        pose_opt = bool(self.config["mapping"]["BA"]) and not self.config["mapping"]["Training"].get("gt_camera", False)
+        self.keyframe_optimizers = None
+        if pose_opt:                                   # pose deltas (off by default) stay on torch.optim.Adam
+            lr = self.config["mapping"]["Training"]["lr"]
+            frames_to_optimize = self.config["mapping"]["Training"]["pose_window"]
+            groups = []
+            for cam_idx in range(min(frames_to_optimize, len(self.current_window))):
+                if self.current_window[cam_idx] == 0:
+                    continue
+                cam = self.viewpoints[self.current_window[cam_idx]]
+                groups.append({"params": [cam.cam_rot_delta], "lr": lr["cam_rot_delta"] * 0.5})
+                groups.append({"params": [cam.cam_trans_delta], "lr": lr["cam_trans_delta"] * 0.5})
+            self.keyframe_optimizers = torch.optim.Adam(groups) if groups else None
+
+    def _views_dirty(self):
+        for vb in self._views.values():
+            vb.mv = None
+
+    def _exposure_step(self, cams, only_rendered=False):
+        if self._exp is None or not self._exp_rows:
+            pass
+        elif only_rendered:       # final_refine: torch's Adam only touches parameters that received a gradient
+            for cam in cams:
+                row = self._exp.row_of(cam)
+                if row in self._exp_rows:
+                    self._exp.step_rows(self.lib, row, 1, self._stream())
+        else:
+            self._exp.step_mask(self.lib, self._exp_rows, self._stream())
+        if self.keyframe_optimizers is not None:
+            for cam in cams:
+                vb = self._views[cam.uid]
+                if cam.cam_rot_delta.requires_grad:
+                    cam.cam_trans_delta.grad = vb.d_tau[:3].clone()
+                    cam.cam_rot_delta.grad = vb.d_tau[3:].clone()
+            self.keyframe_optimizers.step()
+            self.keyframe_optimizers.zero_grad(set_to_none=True)
 
     def check_overflow(self):
         """One synchronisation: did any camera's forward exceed its pair capacity since the last check?"""
@@ -222,7 +346,7 @@ class FusedMappingLoop(MappingLoop):
             if ov.value or R.value * 1.5 > vb.capacity:
                 self.overflow_events += int(bool(ov.value))
                 vb.capacity = max(1 << 16, int(R.value * 2))
-                vb.saved = None
+                vb.saved, vb.mv = None, None
 
     def _tick(self):
         self._since_check += 1
@@ -249,13 +373,15 @@ class FusedMappingLoop(MappingLoop):
                     skip = ("opacity",)
             if densified:
                 # every parameter tensor was re-created: in the reference their .grad is None and Adam skips them all
+                nt = vb.n_touched
                 self._acc_key = None
                 continue
+            nt = vb.n_touched
             self._adam(0.0, skip=skip)
             self._tick()
         # like the reference, visibility comes from the LAST iteration's render (mapper.py:355)
-        self.occ_aware_visibility[cur_frame_idx] = (vb.n_touched > 0).long()
-        return {"render": vb.color, "depth": vb.depth, "opacity": vb.opacity, "radii": vb.radii, "n_touched": vb.n_touched}
+        self.occ_aware_visibility[cur_frame_idx] = (nt > 0).long()
+        return {"render": vb.color, "depth": vb.depth, "opacity": vb.opacity, "radii": vb.radii, "n_touched": nt}
 
     def map(self, current_window, prune=False, iters=1):
         if len(current_window) == 0:
@@ -264,40 +390,37 @@ class FusedMappingLoop(MappingLoop):
         frames_to_optimize = self.config["mapping"]["Training"]["pose_window"]
         cw = set(current_window)
         random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in cw]
-        pose_opt = bool(self.config["mapping"]["BA"]) and not self.config["mapping"]["Training"].get("gt_camera", False)
+        pose_opt = self.keyframe_optimizers is not None
         gaussian_split = False
-        for _ in range(iters):
+        for it in range(iters):
             self.iteration_count += 1
             self._ensure_state()
             self._activate()
             if prune:
-                self.occ_aware_visibility = {}
-                for kf_idx, cam in zip(current_window, viewpoint_stack):
-                    vb = self._view(cam)
-                    self._forward(cam, vb)
-                    self.occ_aware_visibility[kf_idx] = (vb.n_touched > 0).long()
+                self._run_views(viewpoint_stack, forward_only=True)
+                self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
+                                             for kf, c in zip(current_window, viewpoint_stack)}
                 return False
-            used = []
-            for cam in viewpoint_stack:
-                self._view_step(cam)
-                used.append(cam)
+            used = list(viewpoint_stack)
             for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2]:
-                cam = random_viewpoint_stack[cam_idx]
-                self._view_step(cam)
-                used.append(cam)
+                used.append(random_viewpoint_stack[cam_idx])
+            self._run_views(used)
             self.last_losses = [self._views[c.uid].loss for c in used]
             with torch.no_grad():
-                self.occ_aware_visibility = {}
-                for kf_idx, cam in zip(current_window, viewpoint_stack):
-                    self.occ_aware_visibility[kf_idx] = (self._views[cam.uid].n_touched > 0).long()
                 update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
+                reset = (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian)
+                if it == iters - 1 or update_gaussian:
+                    # the reference rebuilds this dict every iteration (mapper.py:494-498); only the value that
+                    # survives the call (or a change of N) is observable
+                    self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
+                                                 for kf, c in zip(current_window, viewpoint_stack)}
                 skip = ()
                 if update_gaussian:
                     self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
                                                      self.gaussian_extent, self.size_threshold)
                     gaussian_split = True
                     self._acc_key = None
-                if (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian):
+                if reset:
                     self.gaussians.reset_opacity_nonvisible([self._views[c.uid].radii > 0 for c in used])
                     gaussian_split = True
                     skip = ("opacity",)
@@ -320,10 +443,10 @@ class FusedMappingLoop(MappingLoop):
             self._ensure_state()
             self._activate()
             cam = stack[np.random.randint(0, len(stack))]
-            self._view_step(cam, stats=False)
+            self._run_views([cam], stats=False)
             self._adam(0.0)
             self.gaussians.update_learning_rate(self.iteration_count)
-            self._exposure_step([cam])
+            self._exposure_step([cam], only_rendered=True)
             self._tick()
 
     # convenience for evaluation / tests

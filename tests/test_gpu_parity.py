@@ -24,6 +24,10 @@ CASES = [
     ("dense", 1000, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, scale_range=(0.01, 0.12))),
     ("bg", 200, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, bg=torch.tensor([0.3, 0.6, 0.1]).double())),
     ("wide", 300, 96, 64, dict(fx=40.0, fy=40.0, cx=47.5, cy=31.5, spread=2.0, scale_range=(0.02, 0.6))),
+    # long per-tile lists: 'skewed' keeps the light forward build (256-key LDS sort) and pushes the central tiles onto
+    # the in-HBM sort path; 'heavy' selects the 4096-key build and the multi-chunk (64-lane) backward
+    ("skewed", 2500, 256, 256, dict(fx=220.0, fy=220.0, cx=127.5, cy=127.5, spread=0.12, scale_range=(0.004, 0.03))),
+    ("heavy", 3000, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, scale_range=(0.05, 0.3))),
     ("sh2", 150, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, sh_degree=2)),
     ("sh3", 150, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, sh_degree=3)),
 ]
