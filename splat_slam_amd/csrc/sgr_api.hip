@@ -1,4 +1,6 @@
 // C-ABI entry points of the rasterizer.  Public contract: include/splat_hip.h.
+// Every stage is ONE launch for a whole batch of views (ViewTab by value, blockIdx.y = view); the single-view entry
+// points are batches of one.
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -9,12 +11,11 @@
 
 namespace sgr {
 
-void launch_preprocess_fwd(const SgrSettings&, const SgrInputs&, const SgrOutputs&, const Layout&, char*, hipStream_t);
-void launch_preprocess_bwd(const SgrSettings&, const SgrInputs&, const int32_t*, const SgrGradInputs&, const Layout&,
-                           const char*, char*, hipStream_t);
-void launch_binning(const SgrSettings&, const SgrOutputs&, const Layout&, char*, char*, hipStream_t);
-void launch_blend_fwd(const SgrSettings&, const SgrOutputs&, const Layout&, char*, char*, hipStream_t);
-void launch_blend_bwd(const SgrSettings&, const SgrGradOutputs&, const Layout&, const char*, char*, hipStream_t);
+void launch_preprocess_fwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, hipStream_t);
+void launch_preprocess_bwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, const SgrGradInputs&, hipStream_t);
+void launch_binning(const ViewTab&, int, const LOff&, hipStream_t);
+void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, hipStream_t);
+void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, hipStream_t);
 
 static thread_local char g_err[512] = "";
 int set_error(int code, const char* fmt, ...) {
@@ -81,13 +82,58 @@ __global__ void __launch_bounds__(256) stats_kernel(int N, int ntiles, const int
   atomicAdd(&out[0], v); atomicAdd(&out[1], r); atomicAdd(&out[2], re); atomicAdd(&out[3], ne);
 }
 
-static int check_common(const SgrSettings* s, const SgrWorkspace* ws, const Layout& L) {
+
+static int check_settings(const SgrSettings* s, const SgrInputs* in) {
+  const int N = s->num_gaussians, H = s->image_height, W = s->image_width;
+  if (N < 0 || H <= 0 || W <= 0) return set_error(SGR_ERR_INVALID, "bad sizes N=%d H=%d W=%d", N, H, W);
+  if (H > 65535 * kTile || W > 65535 * kTile) return set_error(SGR_ERR_INVALID, "image too large");
+  if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->projmatrix_raw || !s->campos)
+    return set_error(SGR_ERR_INVALID, "settings: bg/viewmatrix/projmatrix/projmatrix_raw/campos must be device pointers");
+  if (N > 0) {
+    if (!in->means3D || !in->opacities) return set_error(SGR_ERR_INVALID, "means3D and opacities are required");
+    if ((in->shs != nullptr) == (in->colors_precomp != nullptr))
+      return set_error(SGR_ERR_INVALID, "Please provide excatly one of either SHs or precomputed colors!");
+    if (((in->scales != nullptr) && (in->rotations != nullptr)) == (in->cov3D_precomp != nullptr) ||
+        ((in->scales != nullptr) != (in->rotations != nullptr)))
+      return set_error(SGR_ERR_INVALID, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (in->shs && (s->sh_degree < 0 || s->sh_degree > 3 || s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)))
+      return set_error(SGR_ERR_INVALID, "sh_degree %d needs %d coefficients, shs has %d", s->sh_degree,
+                       (s->sh_degree + 1) * (s->sh_degree + 1), s->sh_coeffs);
+  }
+  return SGR_OK;
+}
+
+static int check_workspace(const SgrWorkspace* ws, const Layout& L) {
+  if (ws->capacity <= 0 || ws->capacity > 0xffffffffll) return set_error(SGR_ERR_INVALID, "bad capacity %lld", (long long)ws->capacity);
   if (!ws->saved || ws->saved_bytes < L.saved_bytes)
     return set_error(SGR_ERR_WORKSPACE, "saved workspace too small: %zu < %zu", ws->saved_bytes, L.saved_bytes);
   if (!ws->scratch || ws->scratch_bytes < L.scratch_bytes)
     return set_error(SGR_ERR_WORKSPACE, "scratch workspace too small: %zu < %zu", ws->scratch_bytes, L.scratch_bytes);
-  if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->projmatrix_raw || !s->campos)
-    return set_error(SGR_ERR_INVALID, "settings: bg/viewmatrix/projmatrix/projmatrix_raw/campos must be device pointers");
+  return SGR_OK;
+}
+
+static Common make_common(const SgrSettings* s) {
+  Common c;
+  c.deg = s->sh_degree; c.M = s->sh_coeffs; c.tanfovx = s->tanfovx; c.tanfovy = s->tanfovy; c.mod = s->scale_modifier;
+  c.bg = s->bg; c.projraw = s->projmatrix_raw;
+  return c;
+}
+
+static void tab_set_view(ViewTab& t, int v, const SgrSettings* s, const SgrOutputs* out, const SgrWorkspace* ws) {
+  t.viewmatrix[v] = s->viewmatrix; t.projmatrix[v] = s->projmatrix; t.campos[v] = s->campos;
+  t.saved[v] = (char*)ws->saved; t.scratch[v] = (char*)ws->scratch;
+  if (out) {
+    t.color[v] = out->color; t.depth[v] = out->depth; t.opacity[v] = out->opacity; t.radii[v] = out->radii;
+    t.n_touched[v] = out->n_touched;
+  }
+}
+
+// forward of a batch that shares N, H, W, capacity and the view-independent settings
+static int forward_batch(const ViewTab& tab, int nviews, const Layout& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
+  LOff d = L.dev();
+  for (int v = 0; v < nviews; ++v) HIP_TRY(hipMemsetAsync(tab.saved[v] + L.o_hdr, 0, L.zero_bytes, st));
+  launch_preprocess_fwd(tab, nviews, d, cm, in, st);     // K1: project, footprint, count pairs per tile
+  launch_binning(tab, nviews, d, st);                    // K2: tile/block scans   K3: scatter keys
   return SGR_OK;
 }
 
@@ -106,41 +152,25 @@ size_t sgr_scratch_bytes(int32_t N, int32_t H, int32_t W, int64_t cap) { return 
 int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out, const SgrWorkspace* ws,
                 int64_t* num_rendered_host, void* stream) {
   if (!s || !in || !out || !ws) return set_error(SGR_ERR_INVALID, "null argument");
-  const int N = s->num_gaussians, H = s->image_height, W = s->image_width;
-  if (N < 0 || H <= 0 || W <= 0 || ws->capacity <= 0 || ws->capacity > 0xffffffffll)
-    return set_error(SGR_ERR_INVALID, "bad sizes N=%d H=%d W=%d cap=%lld", N, H, W, (long long)ws->capacity);
-  if (H > 65535 * kTile || W > 65535 * kTile) return set_error(SGR_ERR_INVALID, "image too large");
-  if (N > 0) {
-    if (!in->means3D || !in->opacities) return set_error(SGR_ERR_INVALID, "means3D and opacities are required");
-    if ((in->shs != nullptr) == (in->colors_precomp != nullptr))
-      return set_error(SGR_ERR_INVALID, "Please provide excatly one of either SHs or precomputed colors!");
-    if (((in->scales != nullptr) && (in->rotations != nullptr)) == (in->cov3D_precomp != nullptr) ||
-        ((in->scales != nullptr) != (in->rotations != nullptr)))
-      return set_error(SGR_ERR_INVALID, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
-    if (in->shs && (s->sh_degree < 0 || s->sh_degree > 3 || s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)))
-      return set_error(SGR_ERR_INVALID, "sh_degree %d needs %d coefficients, shs has %d", s->sh_degree, (s->sh_degree + 1) * (s->sh_degree + 1), s->sh_coeffs);
-  }
+  if (int rc = check_settings(s, in)) return rc;
+  const int N = s->num_gaussians;
   if (!out->color || !out->depth || !out->opacity || (N > 0 && (!out->radii || !out->n_touched)))
     return set_error(SGR_ERR_INVALID, "null output pointer");
-  Layout L = make_layout(N, H, W, ws->capacity);
-  if (int rc = check_common(s, ws, L)) return rc;
+  Layout L = make_layout(N, s->image_height, s->image_width, ws->capacity);
+  if (int rc = check_workspace(ws, L)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  char* saved = (char*)ws->saved;
-  char* scratch = (char*)ws->scratch;
-  SavedHeader* hdr = (SavedHeader*)(saved + L.o_hdr);
-
-  // header + per-tile pair counters: the only memset of the forward
-  HIP_TRY(hipMemsetAsync(saved + L.o_hdr, 0, L.zero_bytes, st));
-  launch_preprocess_fwd(*s, *in, *out, L, saved, st);                 // K1: project, footprint, count pairs per tile
-  launch_binning(*s, *out, L, saved, scratch, st);                    // K2: tile/block scans   K3: scatter keys
+  ViewTab tab = {};
+  tab_set_view(tab, 0, s, out, ws);
+  Common cm = make_common(s);
+  if (int rc = forward_batch(tab, 1, L, cm, *in, st)) return rc;
   if (num_rendered_host) {
     uint32_t R = 0;
-    HIP_TRY(hipMemcpyAsync(&R, &hdr->num_rendered, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&R, &((SavedHeader*)((char*)ws->saved + L.o_hdr))->num_rendered, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *num_rendered_host = R;
     if ((int64_t)R > L.cap) return set_error(SGR_ERR_CAPACITY, "%u (tile, Gaussian) pairs exceed capacity %lld", R, (long long)L.cap);
   }
-  launch_blend_fwd(*s, *out, L, saved, scratch, st);                  // K4: per-tile sort + compositing
+  launch_blend_fwd(tab, 1, L.dev(), s->bg, st);          // K4: per-tile sort + compositing
   HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
@@ -148,21 +178,27 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
 int sgr_backward(const SgrSettings* s, const SgrInputs* in, const int32_t* radii, const SgrGradOutputs* go,
                  const SgrGradInputs* gi, const SgrWorkspace* ws, void* stream) {
   if (!s || !in || !go || !gi || !ws) return set_error(SGR_ERR_INVALID, "null argument");
-  const int N = s->num_gaussians, H = s->image_height, W = s->image_width;
-  if (N < 0 || H <= 0 || W <= 0 || ws->capacity <= 0) return set_error(SGR_ERR_INVALID, "bad sizes");
+  if (int rc = check_settings(s, in)) return rc;
+  const int N = s->num_gaussians;
   if (!go->dL_dcolor) return set_error(SGR_ERR_INVALID, "dL_dcolor is required");
   if (N > 0 && !radii) return set_error(SGR_ERR_INVALID, "radii is required");
   if (gi->stat_grad_accum && (!gi->stat_denom || !gi->stat_max_radii))
     return set_error(SGR_ERR_INVALID, "stat_grad_accum needs stat_denom and stat_max_radii");
-  Layout L = make_layout(N, H, W, ws->capacity);
-  if (int rc = check_common(s, ws, L)) return rc;
+  Layout L = make_layout(N, s->image_height, s->image_width, ws->capacity);
+  if (int rc = check_workspace(ws, L)) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) {
     if (gi->dL_dtau) HIP_TRY(hipMemsetAsync(gi->dL_dtau, 0, 24, st));
     return SGR_OK;
   }
-  launch_blend_bwd(*s, *go, L, (const char*)ws->saved, (char*)ws->scratch, st);
-  launch_preprocess_bwd(*s, *in, radii, *gi, L, (const char*)ws->saved, (char*)ws->scratch, st);
+  ViewTab tab = {};
+  tab_set_view(tab, 0, s, nullptr, ws);
+  tab.radii[0] = const_cast<int32_t*>(radii);
+  tab.dL_dcolor[0] = go->dL_dcolor; tab.dL_ddepth[0] = go->dL_ddepth; tab.dL_dtau[0] = gi->dL_dtau;
+  LOff d = L.dev();
+  Common cm = make_common(s);
+  launch_blend_bwd(tab, 1, d, s->bg, st);
+  launch_preprocess_bwd(tab, 1, d, cm, *in, *gi, st);
   HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
@@ -171,20 +207,75 @@ int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* i
                   float rgb_boundary_threshold, int32_t forward_only, void* stream) {
   if (num_views < 0 || (num_views > 0 && (!views || !in)) || (!forward_only && !grads))
     return set_error(SGR_ERR_INVALID, "map_views: null argument");
+  if (num_views == 0) return SGR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // batched execution needs one Layout (same N, H, W, capacity), the same view-independent settings and private scratch
+  bool uniform = true;
+  const SgrMapView& f = views[0];
   for (int v = 0; v < num_views; ++v) {
-    const SgrMapView& mv = views[v];
-    if (int rc = sgr_forward(&mv.settings, in, &mv.out, &mv.ws, nullptr, stream)) return rc;
-    if (forward_only) continue;
-    if (int rc = sgr_mapping_loss(mv.settings.image_height, mv.settings.image_width, mv.out.color, mv.out.depth, mv.gt_image,
-                                  mv.gt_depth, mv.exposure_a, mv.exposure_b, alpha, rgb_boundary_threshold, 1.0f, mv.loss,
-                                  mv.dL_dimage, mv.dL_ddepth, mv.dL_dexposure, mv.dL_dexposure ? mv.dL_dexposure + 1 : nullptr,
-                                  mv.loss_scratch, mv.loss_scratch_bytes, stream))
-      return rc;
-    SgrGradOutputs go = {mv.dL_dimage, mv.dL_ddepth};
-    SgrGradInputs gi = *grads;
-    gi.dL_dtau = mv.dL_dtau;
-    if (int rc = sgr_backward(&mv.settings, in, mv.out.radii, &go, &gi, &mv.ws, stream)) return rc;
+    const SgrMapView& m = views[v];
+    if (int rc = check_settings(&m.settings, in)) return rc;
+    uniform = uniform && m.settings.num_gaussians == f.settings.num_gaussians && m.settings.image_height == f.settings.image_height &&
+              m.settings.image_width == f.settings.image_width && m.settings.tanfovx == f.settings.tanfovx &&
+              m.settings.tanfovy == f.settings.tanfovy && m.settings.scale_modifier == f.settings.scale_modifier &&
+              m.settings.sh_degree == f.settings.sh_degree && m.settings.sh_coeffs == f.settings.sh_coeffs &&
+              m.settings.bg == f.settings.bg && m.settings.projmatrix_raw == f.settings.projmatrix_raw &&
+              m.ws.capacity == f.ws.capacity;
+    // several views accumulate through fixed-size gradient records: the reference's default inputs only
+    if (num_views > 1) uniform = uniform && in->shs && m.settings.sh_degree == 0 && in->scales && in->rotations;
+    for (int u = 0; u < v; ++u) uniform = uniform && views[u].ws.scratch != m.ws.scratch && views[u].ws.saved != m.ws.saved;
+    if (!forward_only && grads && !grads->accumulate && num_views > 1)
+      return set_error(SGR_ERR_INVALID, "map_views: several views need accumulate != 0");
   }
+  if (!uniform || f.settings.num_gaussians == 0) {       // heterogeneous views: one after the other (shared scratch is fine)
+    for (int v = 0; v < num_views; ++v) {
+      const SgrMapView& mv = views[v];
+      if (int rc = sgr_forward(&mv.settings, in, &mv.out, &mv.ws, nullptr, stream)) return rc;
+      if (forward_only) continue;
+      if (int rc = sgr_mapping_loss(mv.settings.image_height, mv.settings.image_width, mv.out.color, mv.out.depth, mv.gt_image,
+                                    mv.gt_depth, mv.exposure_a, mv.exposure_b, alpha, rgb_boundary_threshold, 1.0f, mv.loss,
+                                    mv.dL_dimage, mv.dL_ddepth, mv.dL_dexposure, mv.dL_dexposure ? mv.dL_dexposure + 1 : nullptr,
+                                    mv.loss_scratch, mv.loss_scratch_bytes, stream))
+        return rc;
+      SgrGradOutputs go = {mv.dL_dimage, mv.dL_ddepth};
+      SgrGradInputs gi = *grads;
+      gi.dL_dtau = mv.dL_dtau;
+      if (int rc = sgr_backward(&mv.settings, in, mv.out.radii, &go, &gi, &mv.ws, stream)) return rc;
+    }
+    return SGR_OK;
+  }
+  Layout L = make_layout(f.settings.num_gaussians, f.settings.image_height, f.settings.image_width, f.ws.capacity);
+  LOff d = L.dev();
+  Common cm = make_common(&f.settings);
+  const int HW = f.settings.image_height * f.settings.image_width;
+  for (int base = 0; base < num_views; base += kMaxViews) {
+    const int nv = num_views - base < kMaxViews ? num_views - base : kMaxViews;
+    ViewTab tab = {};
+    LossTab lt = {};
+    for (int v = 0; v < nv; ++v) {
+      const SgrMapView& m = views[base + v];
+      if (int rc = check_workspace(&m.ws, L)) return rc;
+      if (!m.out.color || !m.out.depth || !m.out.opacity || !m.out.radii || !m.out.n_touched)
+        return set_error(SGR_ERR_INVALID, "map_views: null output pointer");
+      tab_set_view(tab, v, &m.settings, &m.out, &m.ws);
+      if (!forward_only) {
+        if (!m.gt_image || !m.gt_depth || !m.dL_dimage || !m.dL_ddepth || !m.loss_scratch || m.loss_scratch_bytes < 1024 * 16)
+          return set_error(SGR_ERR_INVALID, "map_views: loss buffers missing");
+        tab.dL_dcolor[v] = m.dL_dimage; tab.dL_ddepth[v] = m.dL_ddepth; tab.dL_dtau[v] = m.dL_dtau;
+        lt.image[v] = m.out.color; lt.depth[v] = m.out.depth; lt.gt_image[v] = m.gt_image; lt.gt_depth[v] = m.gt_depth;
+        lt.exp_a[v] = m.exposure_a; lt.exp_b[v] = m.exposure_b; lt.loss[v] = m.loss; lt.dimage[v] = m.dL_dimage;
+        lt.ddepth[v] = m.dL_ddepth; lt.da[v] = m.dL_dexposure; lt.db[v] = m.dL_dexposure ? m.dL_dexposure + 1 : nullptr;
+        lt.parts[v] = m.loss_scratch;
+      }
+    }
+    if (int rc = forward_batch(tab, nv, L, cm, *in, st)) return rc;
+    launch_blend_fwd(tab, nv, d, f.settings.bg, st);
+    if (forward_only) continue;
+    launch_mapping_loss(lt, nv, HW, alpha, rgb_boundary_threshold, 1.0f, st);
+    launch_blend_bwd(tab, nv, d, f.settings.bg, st);
+    launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, st);
+  }
+  HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
 

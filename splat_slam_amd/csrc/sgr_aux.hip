@@ -14,12 +14,17 @@ int set_error(int code, const char* fmt, ...);
 // ------------------------------------------------------------------------------------------------ mapping loss
 struct LossPart { float rgb, dep, da, db; };
 
-__global__ void __launch_bounds__(256) mapping_loss_kernel(
-    int HW, const float* __restrict__ image, const float* __restrict__ depth, const float* __restrict__ gt_image,
-    const float* __restrict__ gt_depth, const float* __restrict__ exp_a, const float* __restrict__ exp_b, float w_rgb,
-    float w_dep, float thr, float* __restrict__ dimage, float* __restrict__ ddepth, LossPart* __restrict__ parts) {
-  const float ea = exp_a ? __expf(exp_a[0]) : 1.f;
-  const float eb = exp_b ? exp_b[0] : 0.f;
+__global__ void __launch_bounds__(256) mapping_loss_kernel(LossTab tab, int HW, float w_rgb, float w_dep, float thr) {
+  const int vw = blockIdx.y;
+  const float* __restrict__ image = tab.image[vw];
+  const float* __restrict__ depth = tab.depth[vw];
+  const float* __restrict__ gt_image = tab.gt_image[vw];
+  const float* __restrict__ gt_depth = tab.gt_depth[vw];
+  float* __restrict__ dimage = tab.dimage[vw];
+  float* __restrict__ ddepth = tab.ddepth[vw];
+  LossPart* __restrict__ parts = (LossPart*)tab.parts[vw];
+  const float ea = tab.exp_a[vw] ? __expf(tab.exp_a[vw][0]) : 1.f;
+  const float eb = tab.exp_b[vw] ? tab.exp_b[vw][0] : 0.f;
   LossPart acc = {0.f, 0.f, 0.f, 0.f};
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
     float g0 = gt_image[p], g1 = gt_image[HW + p], g2 = gt_image[2 * HW + p];
@@ -56,10 +61,10 @@ __global__ void __launch_bounds__(256) mapping_loss_kernel(
   }
 }
 
-__global__ void mapping_loss_final_kernel(int nparts, const LossPart* __restrict__ parts, float inv_rgb, float inv_dep,
-                                          float alpha, float* __restrict__ loss, float* __restrict__ da,
-                                          float* __restrict__ db) {
+__global__ void mapping_loss_final_kernel(LossTab tab, int nparts, float inv_rgb, float inv_dep, float alpha) {
   __shared__ LossPart red[64];
+  const int vw = blockIdx.x;
+  const LossPart* __restrict__ parts = (const LossPart*)tab.parts[vw];
   int lane = threadIdx.x;
   LossPart t = {0.f, 0.f, 0.f, 0.f};
   for (int i = lane; i < nparts; i += 64) { t.rgb += parts[i].rgb; t.dep += parts[i].dep; t.da += parts[i].da; t.db += parts[i].db; }
@@ -68,10 +73,23 @@ __global__ void mapping_loss_final_kernel(int nparts, const LossPart* __restrict
   if (lane == 0) {
     LossPart s = {0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < 64; ++i) { s.rgb += red[i].rgb; s.dep += red[i].dep; s.da += red[i].da; s.db += red[i].db; }
-    if (loss) loss[0] = alpha * (s.rgb * inv_rgb) + (1.f - alpha) * (s.dep * inv_dep);
-    if (da) da[0] = s.da;
-    if (db) db[0] = s.db;
+    if (tab.loss[vw]) tab.loss[vw][0] = alpha * (s.rgb * inv_rgb) + (1.f - alpha) * (s.dep * inv_dep);
+    if (tab.da[vw]) tab.da[vw][0] = s.da;
+    if (tab.db[vw]) tab.db[vw][0] = s.db;
   }
+}
+
+static int loss_blocks(int HW) {
+  int blocks = (HW + 255) / 256;
+  return blocks > 1024 ? 1024 : blocks;
+}
+
+void launch_mapping_loss(const LossTab& tab, int nviews, int HW, float alpha, float thr, float upstream, hipStream_t st) {
+  int blocks = loss_blocks(HW);
+  float inv_rgb = 1.f / (3.f * (float)HW), inv_dep = 1.f / (float)HW;
+  hipLaunchKernelGGL(mapping_loss_kernel, dim3(blocks, nviews), dim3(256), 0, st, tab, HW, upstream * alpha * inv_rgb,
+                     upstream * (1.f - alpha) * inv_dep, thr);
+  hipLaunchKernelGGL(mapping_loss_final_kernel, dim3(nviews), dim3(64), 0, st, tab, blocks, inv_rgb, inv_dep, alpha);
 }
 
 // ------------------------------------------------------------------------------------------------ Adam
@@ -410,17 +428,13 @@ int sgr_mapping_loss(int32_t H, int32_t W, const float* image, const float* dept
                      float* dL_dexp_a, float* dL_dexp_b, void* scratch, size_t scratch_bytes, void* stream) {
   if (H <= 0 || W <= 0 || !image || !depth || !gt_image || !gt_depth) return set_error(SGR_ERR_INVALID, "mapping_loss: null/size");
   const int HW = H * W;
-  int blocks = (HW + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  if (!scratch || scratch_bytes < (size_t)blocks * sizeof(LossPart))
+  if (!scratch || scratch_bytes < (size_t)loss_blocks(HW) * sizeof(LossPart))
     return set_error(SGR_ERR_WORKSPACE, "mapping_loss scratch too small (need %zu)", (size_t)1024 * sizeof(LossPart));
-  float inv_rgb = 1.f / (3.f * (float)HW), inv_dep = 1.f / (float)HW;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mapping_loss_kernel, dim3(blocks), dim3(256), 0, st, HW, image, depth, gt_image, gt_depth, exposure_a,
-                     exposure_b, upstream * alpha * inv_rgb, upstream * (1.f - alpha) * inv_dep, rgb_boundary_threshold,
-                     dL_dimage, dL_ddepth, (LossPart*)scratch);
-  hipLaunchKernelGGL(mapping_loss_final_kernel, dim3(1), dim3(64), 0, st, blocks, (const LossPart*)scratch, inv_rgb, inv_dep,
-                     alpha, loss, dL_dexp_a, dL_dexp_b);
+  LossTab tab = {};
+  tab.image[0] = image; tab.depth[0] = depth; tab.gt_image[0] = gt_image; tab.gt_depth[0] = gt_depth;
+  tab.exp_a[0] = exposure_a; tab.exp_b[0] = exposure_b; tab.loss[0] = loss; tab.dimage[0] = dL_dimage;
+  tab.ddepth[0] = dL_ddepth; tab.da[0] = dL_dexp_a; tab.db[0] = dL_dexp_b; tab.parts[0] = scratch;
+  launch_mapping_loss(tab, 1, HW, alpha, rgb_boundary_threshold, upstream, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "mapping_loss launch failed");
 }
 

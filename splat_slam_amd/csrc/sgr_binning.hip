@@ -36,54 +36,57 @@ __device__ uint32_t block1024_scan(const uint32_t* __restrict__ in, uint32_t* __
   return carry;
 }
 
-// K2: three independent scans, one 1024-thread block each: (0) tile starts, (1) block bases of the partial-slot
-// offsets, (2) block bases of the visible list.  ranges[t] = (start, start): scatter uses .y as the fill cursor, so
-// after K3 it is the end of the tile's run.
-__global__ void __launch_bounds__(1024) tile_scan_kernel(int ntiles, int nblocks, int64_t cap,
-                                                         const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
-                                                         const uint32_t* __restrict__ block_touched, uint32_t* __restrict__ block_base_t,
-                                                         const uint32_t* __restrict__ block_vis, uint32_t* __restrict__ block_base_v,
-                                                         uint32_t* __restrict__ tmp, SavedHeader* __restrict__ hdr) {
+// K2: three independent scans per view, one 1024-thread block each (grid = (3, views)): (0) tile starts, (1) block
+// bases of the partial-slot offsets, (2) block bases of the visible list.  ranges[t] = (start, start): scatter uses .y
+// as the fill cursor, so after K3 it is the end of the tile's run.
+__global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   __shared__ uint32_t red[16];
+  char* saved = tab.saved[blockIdx.y];
+  SavedHeader* hdr = (SavedHeader*)(saved + L.o_hdr);
   if (blockIdx.x == 0) {
-    uint32_t R = block1024_scan(tile_count, tmp, ntiles, red);
+    uint32_t* tmp = (uint32_t*)(saved + L.o_tile_maxc);      // free until blend_fwd overwrites it
+    uint2* ranges = (uint2*)(saved + L.o_ranges);
+    uint32_t R = block1024_scan((const uint32_t*)(saved + L.o_tile_count), tmp, L.ntiles, red);
     __syncthreads();
-    for (int t = threadIdx.x; t < ntiles; t += 1024) { uint32_t s0 = tmp[t]; ranges[t] = make_uint2(s0, s0); }
+    for (int t = threadIdx.x; t < L.ntiles; t += 1024) { uint32_t s0 = tmp[t]; ranges[t] = make_uint2(s0, s0); }
     if (threadIdx.x == 0) {
       hdr->num_rendered = R;
-      hdr->overflow = (int64_t)R > cap ? 1u : 0u;
-      hdr->sorted_count = (uint32_t)((int64_t)R > cap ? cap : (int64_t)R);
+      hdr->overflow = (int64_t)R > L.cap ? 1u : 0u;
+      hdr->sorted_count = (uint32_t)((int64_t)R > L.cap ? L.cap : (int64_t)R);
     }
   } else if (blockIdx.x == 1) {
-    (void)block1024_scan(block_touched, block_base_t, nblocks, red);
+    (void)block1024_scan((const uint32_t*)(saved + L.o_block_touched), (uint32_t*)(saved + L.o_block_base_t), L.pre_blocks, red);
   } else {
-    uint32_t V = block1024_scan(block_vis, block_base_v, nblocks, red);
+    uint32_t V = block1024_scan((const uint32_t*)(saved + L.o_block_vis), (uint32_t*)(saved + L.o_block_base_v), L.pre_blocks, red);
     if (threadIdx.x == 0) hdr->num_visible = V;
   }
 }
 
 // K3: finishes the two-level scans (absolute partial-slot offsets, compact visible list) and scatters one
 // (depth bits | Gaussian) key per pair into its tile's run.  Order inside a run is arbitrary here; K4 sorts it.
-__global__ void __launch_bounds__(256) scatter_kernel(int N, int gx, int64_t cap, const int32_t* __restrict__ radii,
-                                                      const uint32_t* __restrict__ touched, uint32_t* __restrict__ offsets,
-                                                      const ushort4* __restrict__ rect, const float4* __restrict__ rgbd,
-                                                      const uint32_t* __restrict__ block_base_t,
-                                                      const uint32_t* __restrict__ block_base_v, uint32_t* __restrict__ vis_list,
-                                                      uint2* __restrict__ ranges, uint64_t* __restrict__ entries) {
+__global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
   __shared__ uint32_t red[4];
+  const int v = blockIdx.y, N = L.N;
+  char* saved = tab.saved[v];
+  const int32_t* __restrict__ radii = tab.radii[v];
+  uint32_t* __restrict__ offsets = (uint32_t*)(saved + L.o_offsets);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool vis = i < N && radii[i] > 0;
   uint32_t tot;
   uint32_t vpos = block256_exclusive_scan(vis ? 1u : 0u, red, tot);
   if (tot == 0) return;                                   // nothing visible in this block (uniform)
   if (i >= N) return;
-  uint32_t off = offsets[i] + block_base_t[blockIdx.x];
+  uint32_t off = offsets[i] + ((const uint32_t*)(saved + L.o_block_base_t))[blockIdx.x];
   offsets[i] = off;
   if (!vis) return;
-  vis_list[block_base_v[blockIdx.x] + vpos] = (uint32_t)i;
-  if (touched[i] == 0) return;
-  ushort4 r = rect[i];
-  uint64_t key = ((uint64_t)__float_as_uint(rgbd[i].w) << 32) | (uint32_t)i;
+  const uint32_t vp = ((const uint32_t*)(saved + L.o_block_base_v))[blockIdx.x] + vpos;
+  ((uint32_t*)(saved + L.o_vis_list))[vp] = (uint32_t)i;
+  ((uint32_t*)(saved + L.o_vis_pos))[i] = vp;
+  if (((const uint32_t*)(saved + L.o_touched))[i] == 0) return;
+  ushort4 r = ((const ushort4*)(saved + L.o_rect))[i];
+  uint64_t key = ((uint64_t)__float_as_uint(((const float4*)(saved + L.o_rgbd))[i].w) << 32) | (uint32_t)i;
+  uint2* ranges = (uint2*)(saved + L.o_ranges);
+  uint64_t* entries = (uint64_t*)(tab.scratch[v] + L.o_entries);
   const int w = (int)r.z - (int)r.x, cnt = w * ((int)r.w - (int)r.y);
   // returning atomics are latency-bound: keep 4 in flight per thread (most splats cover <= 4 bins)
   for (int k0 = 0; k0 < cnt; k0 += 4) {
@@ -91,31 +94,22 @@ __global__ void __launch_bounds__(256) scatter_kernel(int N, int gx, int64_t cap
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int kk = k0 + k;
-      if (kk < cnt) pos[k] = atomicAdd(&ranges[((int)r.y + kk / w) * gx + (int)r.x + kk % w].y, 1u);
+      if (kk < cnt) pos[k] = atomicAdd(&ranges[((int)r.y + kk / w) * L.gx + (int)r.x + kk % w].y, 1u);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (k0 + k < cnt && (int64_t)pos[k] < cap) entries[pos[k]] = key;
+      if (k0 + k < cnt && (int64_t)pos[k] < L.cap) entries[pos[k]] = key;
   }
 }
 
-void launch_binning(const SgrSettings& s, const SgrOutputs& out, const Layout& L, char* saved, char* scratch, hipStream_t st) {
-  const int N = s.num_gaussians;
+void launch_binning(const ViewTab& tab, int nviews, const LOff& L, hipStream_t st) {
   {
     ProfScope prof(PK_SCAN, st);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(3), dim3(1024), 0, st, L.ntiles, L.pre_blocks, L.cap,
-                       (const uint32_t*)(saved + L.o_tile_count), (uint2*)(saved + L.o_ranges),
-                       (const uint32_t*)(saved + L.o_block_touched), (uint32_t*)(saved + L.o_block_base_t),
-                       (const uint32_t*)(saved + L.o_block_vis), (uint32_t*)(saved + L.o_block_base_v),
-                       (uint32_t*)(saved + L.o_tile_maxc), (SavedHeader*)(saved + L.o_hdr));
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(3, nviews), dim3(1024), 0, st, tab, L);
   }
-  if (N > 0) {
+  if (L.N > 0) {
     ProfScope prof(PK_SCATTER, st);
-    hipLaunchKernelGGL(scatter_kernel, dim3(L.pre_blocks), dim3(256), 0, st, N, L.gx, L.cap, out.radii,
-                       (const uint32_t*)(saved + L.o_touched), (uint32_t*)(saved + L.o_offsets),
-                       (const ushort4*)(saved + L.o_rect), (const float4*)(saved + L.o_rgbd),
-                       (const uint32_t*)(saved + L.o_block_base_t), (const uint32_t*)(saved + L.o_block_base_v),
-                       (uint32_t*)(saved + L.o_vis_list), (uint2*)(saved + L.o_ranges), (uint64_t*)(scratch + L.o_entries));
+    hipLaunchKernelGGL(scatter_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L);
   }
 }
 

@@ -80,13 +80,24 @@ __device__ __forceinline__ void wave_sort_any(int n, int lane, LD load, ST store
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int SORT_MAX>
-__global__ void __launch_bounds__(256) blend_fwd_kernel(
-    int H, int W, int gx, int gy, int sgx, int sgy, int64_t cap, const uint2* __restrict__ ranges,
-    uint64_t* __restrict__ entries, uint32_t* __restrict__ point_list, const float2* __restrict__ xy,
-    const float4* __restrict__ conic_o, const float4* __restrict__ rgbd, const float* __restrict__ bg,
-    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_opacity,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
-    int32_t* __restrict__ n_touched) {
+__global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg) {
+  const int vw = blockIdx.y;
+  char* saved = tab.saved[vw];
+  const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
+  const int64_t cap = L.cap;
+  const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
+  uint64_t* __restrict__ entries = (uint64_t*)(tab.scratch[vw] + L.o_entries);
+  uint32_t* __restrict__ point_list = (uint32_t*)(saved + L.o_point_list);
+  const float2* __restrict__ xy = (const float2*)(saved + L.o_xy);
+  const float4* __restrict__ conic_o = (const float4*)(saved + L.o_conic_o);
+  const float4* __restrict__ rgbd = (const float4*)(saved + L.o_rgbd);
+  float* __restrict__ out_color = tab.color[vw];
+  float* __restrict__ out_depth = tab.depth[vw];
+  float* __restrict__ out_opacity = tab.opacity[vw];
+  float* __restrict__ final_T = (float*)(saved + L.o_final_T);
+  uint32_t* __restrict__ n_contrib = (uint32_t*)(saved + L.o_n_contrib);
+  uint32_t* __restrict__ tile_maxc = (uint32_t*)(saved + L.o_tile_maxc);
+  int32_t* __restrict__ n_touched = tab.n_touched[vw];
   extern __shared__ __attribute__((aligned(16))) char smem[];   // per wave: SORT_MAX keys (8 B) + 64 splats x 48 B
   const int nblocks = sgx * sgy;
   const int st = super_tile_of_block(blockIdx.x, nblocks);
@@ -314,13 +325,24 @@ __device__ __forceinline__ void bwd_chunk(
   }
 }
 
-__global__ void __launch_bounds__(256) blend_bwd_kernel(
-    int H, int W, int gx, int gy, int sgx, int sgy, int64_t cap, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
-    const float4* __restrict__ rgbd, const ushort4* __restrict__ rect, const uint32_t* __restrict__ offsets,
-    const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const uint32_t* __restrict__ tile_maxc, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    float4* __restrict__ partials) {
+__global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg) {
+  const int vw = blockIdx.y;
+  const char* saved = tab.saved[vw];
+  const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
+  const int64_t cap = L.cap;
+  const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
+  const uint32_t* __restrict__ point_list = (const uint32_t*)(saved + L.o_point_list);
+  const float2* __restrict__ xy = (const float2*)(saved + L.o_xy);
+  const float4* __restrict__ conic_o = (const float4*)(saved + L.o_conic_o);
+  const float4* __restrict__ rgbd = (const float4*)(saved + L.o_rgbd);
+  const ushort4* __restrict__ rect = (const ushort4*)(saved + L.o_rect);
+  const uint32_t* __restrict__ offsets = (const uint32_t*)(saved + L.o_offsets);
+  const float* __restrict__ final_T = (const float*)(saved + L.o_final_T);
+  const uint32_t* __restrict__ n_contrib = (const uint32_t*)(saved + L.o_n_contrib);
+  const uint32_t* __restrict__ tile_maxc = (const uint32_t*)(saved + L.o_tile_maxc);
+  const float* __restrict__ dL_dcolor = tab.dL_dcolor[vw];
+  const float* __restrict__ dL_ddepth = tab.dL_ddepth[vw];
+  float4* __restrict__ partials = (float4*)(tab.scratch[vw] + L.o_partials);
   __shared__ float4 pixbuf[4][2][kWave];      // per wave: pixel gradients + running (T, S) carries
   const int nblocks = sgx * sgy;
   const int st = super_tile_of_block(blockIdx.x, nblocks);
@@ -392,8 +414,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
 }
 
 template <int SORT_MAX>
-static void launch_blend_fwd_t(const SgrSettings& s, const SgrOutputs& out, const Layout& L, char* saved, char* scratch,
-                               hipStream_t st) {
+static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, const float* bg, hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
   constexpr size_t lds = 4 * (size_t)(SORT_MAX * 8 + kWave * 48);
@@ -402,35 +423,22 @@ static void launch_blend_fwd_t(const SgrSettings& s, const SgrOutputs& out, cons
     (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(blend_fwd_kernel<SORT_MAX>, dim3(grid), dim3(256), lds, st, s.image_height, s.image_width, L.gx, L.gy,
-                     L.sgx, L.sgy, L.cap, (const uint2*)(saved + L.o_ranges), (uint64_t*)(scratch + L.o_entries),
-                     (uint32_t*)(saved + L.o_point_list), (const float2*)(saved + L.o_xy),
-                     (const float4*)(saved + L.o_conic_o), (const float4*)(saved + L.o_rgbd), s.bg, out.color, out.depth,
-                     out.opacity, (float*)(saved + L.o_final_T), (uint32_t*)(saved + L.o_n_contrib),
-                     (uint32_t*)(saved + L.o_tile_maxc), out.n_touched);
+  hipLaunchKernelGGL(blend_fwd_kernel<SORT_MAX>, dim3(grid, nviews), dim3(256), lds, st, tab, L, bg);
 }
 
-void launch_blend_fwd(const SgrSettings& s, const SgrOutputs& out, const Layout& L, char* saved, char* scratch, hipStream_t st) {
+void launch_blend_fwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, hipStream_t st) {
   ProfScope prof(PK_BLEND_FWD, st);
   // the caller sizes `capacity` at ~2x the pair count it has seen: capacity / tiles / 2 estimates the mean list length
   const int64_t mean_len = L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
-  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy>(s, out, L, saved, scratch, st);
-  else launch_blend_fwd_t<kSortLight>(s, out, L, saved, scratch, st);
+  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy>(tab, nviews, L, bg, st);
+  else launch_blend_fwd_t<kSortLight>(tab, nviews, L, bg, st);
 }
 
-void launch_blend_bwd(const SgrSettings& s, const SgrGradOutputs& go, const Layout& L, const char* saved, char* scratch,
-                      hipStream_t st) {
+void launch_blend_bwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
-  float4* partials = (float4*)(scratch + L.o_partials);
   ProfScope prof(PK_BLEND_BWD, st);
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), 0, st, s.image_height, s.image_width, L.gx, L.gy, L.sgx,
-                     L.sgy, L.cap, (const uint2*)(saved + L.o_ranges), (const uint32_t*)(saved + L.o_point_list),
-                     (const float2*)(saved + L.o_xy), (const float4*)(saved + L.o_conic_o),
-                     (const float4*)(saved + L.o_rgbd), (const ushort4*)(saved + L.o_rect),
-                     (const uint32_t*)(saved + L.o_offsets), s.bg, (const float*)(saved + L.o_final_T),
-                     (const uint32_t*)(saved + L.o_n_contrib), (const uint32_t*)(saved + L.o_tile_maxc), go.dL_dcolor,
-                     go.dL_ddepth, partials);
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid, nviews), dim3(256), 0, st, tab, L, bg);
 }
 
 }  // namespace sgr

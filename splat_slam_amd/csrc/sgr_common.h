@@ -39,6 +39,40 @@ struct SavedHeader {
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// ---- batched launches: every kernel takes the per-view pointers of up to kMaxViews views BY VALUE (kernarg) and picks
+// its view with blockIdx.y, so the <= 12 views of a mapping iteration (src/mapper.py:426-485) are ONE launch per stage.
+constexpr int kMaxViews = 16;
+struct ViewTab {
+  const float* viewmatrix[kMaxViews];
+  const float* projmatrix[kMaxViews];
+  const float* campos[kMaxViews];
+  char* saved[kMaxViews];
+  char* scratch[kMaxViews];
+  float* color[kMaxViews];
+  float* depth[kMaxViews];
+  float* opacity[kMaxViews];
+  int32_t* radii[kMaxViews];
+  int32_t* n_touched[kMaxViews];
+  const float* dL_dcolor[kMaxViews];
+  const float* dL_ddepth[kMaxViews];
+  float* dL_dtau[kMaxViews];
+};
+// device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
+struct LOff {
+  int N, H, W, gx, gy, sgx, sgy, ntiles, pre_blocks;
+  int64_t cap;
+  size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
+      o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
+      o_vis_pos, o_entries, o_partials, o_tau_part, o_gradrec;
+};
+// shared (view independent) scalars of a batch
+struct Common {
+  int deg, M;
+  float tanfovx, tanfovy, mod;
+  const float* bg;
+  const float* projraw;
+};
+
 // Carves the two workspaces. Pure function of (N, H, W, capacity): forward and backward agree by construction.
 struct Layout {
   int N, H, W;
@@ -49,11 +83,11 @@ struct Layout {
   // saved
   size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      saved_bytes, zero_bytes;
+      o_vis_pos, saved_bytes, zero_bytes;
   // scratch (forward)
   size_t o_entries;
   // scratch (backward) -- aliases the forward scratch
-  size_t o_partials, o_tau_part, scratch_bytes;
+  size_t o_partials, o_tau_part, o_gradrec, scratch_bytes;
   int pre_blocks;
 
   __host__ Layout(int N_, int H_, int W_, int64_t cap_) : N(N_), H(H_), W(W_), cap(cap_) {
@@ -89,6 +123,7 @@ struct Layout {
     o_block_base_t = take(nb * 4);
     o_block_base_v = take(nb * 4);
     o_vis_list = take(n * 4);
+    o_vis_pos = take(n * 4);
     saved_bytes = o;
 
     o = 0;
@@ -97,9 +132,40 @@ struct Layout {
     o = 0;
     o_partials = take(c * 48);
     o_tau_part = take((size_t)(pre_blocks > 0 ? pre_blocks : 1) * 6 * 4);
+    o_gradrec = take(n * 64);          // per visible Gaussian: 16-float gradient record of this view
     scratch_bytes = fwd > o ? fwd : o;
   }
+  __host__ LOff dev() const {
+    LOff d;
+    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks;
+    d.cap = cap;
+    d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_xy = o_xy; d.o_conic_o = o_conic_o; d.o_rgbd = o_rgbd;
+    d.o_rect = o_rect; d.o_offsets = o_offsets; d.o_touched = o_touched; d.o_clamped = o_clamped;
+    d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;
+    d.o_n_contrib = o_n_contrib; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
+    d.o_block_base_t = o_block_base_t; d.o_block_base_v = o_block_base_v; d.o_vis_list = o_vis_list;
+    d.o_vis_pos = o_vis_pos; d.o_entries = o_entries; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
+    d.o_gradrec = o_gradrec;
+    return d;
+  }
 };
+
+// per-view pointers of the fused mapping loss (sgr_mapping_loss / sgr_map_views)
+struct LossTab {
+  const float* image[kMaxViews];
+  const float* depth[kMaxViews];
+  const float* gt_image[kMaxViews];
+  const float* gt_depth[kMaxViews];
+  const float* exp_a[kMaxViews];
+  const float* exp_b[kMaxViews];
+  float* loss[kMaxViews];
+  float* dimage[kMaxViews];
+  float* ddepth[kMaxViews];
+  float* da[kMaxViews];
+  float* db[kMaxViews];
+  void* parts[kMaxViews];
+};
+void launch_mapping_loss(const LossTab& tab, int nviews, int HW, float alpha, float thr, float upstream, hipStream_t st);
 
 // ---- optional per-kernel event timing (sgr_profile_enable / sgr_profile_read)
 enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_SCATTER, PK_UNUSED3, PK_UNUSED4, PK_BLEND_FWD, PK_UNUSED6, PK_BLEND_BWD, PK_PRE_BWD };

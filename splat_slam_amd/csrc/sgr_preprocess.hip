@@ -223,87 +223,80 @@ __device__ __forceinline__ void preprocess_one(
 //   * per-tile pair counts (one fire-and-forget atomic per (tile, Gaussian) pair),
 //   * in-block exclusive prefix of `touched` / `visible` + the block totals (finished by tile_scan_kernel: a
 //     deterministic two-level scan instead of a device-wide scan library call).
+// grid = (ceil(N/256), views): blockIdx.y selects the view of the batch.
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
-    int N, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod,
-    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    const float* __restrict__ means3D, const float* __restrict__ opacities, const float* __restrict__ shs,
-    const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ cov3D_precomp,
-    int gx, int gy, int sgx, int sgy,
-    int32_t* __restrict__ radii, int32_t* __restrict__ n_touched, float2* __restrict__ xy_out,
-    float4* __restrict__ conic_o, float4* __restrict__ rgbd, ushort4* __restrict__ rect_out,
-    uint32_t* __restrict__ touched, uint32_t* __restrict__ offsets_rel, uint8_t* __restrict__ clamped_out,
-    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ block_touched, uint32_t* __restrict__ block_vis) {
+    ViewTab tab, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp) {
   __shared__ uint32_t red[4];
+  const int v = blockIdx.y, N = L.N;
+  char* saved = tab.saved[v];
+  int32_t* __restrict__ radii = tab.radii[v];
+  int32_t* __restrict__ n_touched = tab.n_touched[v];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   PreOut o;
   o.visible = false;
   o.x0 = o.x1 = o.y0 = o.y1 = 0;
   if (i < N) {
     float vm[16], pm[16];
-    load16(viewmatrix, vm);
-    load16(projmatrix, pm);
-    preprocess_one(i, H, W, deg, M, tanfovx, tanfovy, mod, vm, pm, campos, means3D, opacities, shs, colors_precomp,
-                   scales, rotations, cov3D_precomp, gx, gy, sgx, sgy, o);
+    load16(tab.viewmatrix[v], vm);
+    load16(tab.projmatrix[v], pm);
+    preprocess_one(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, vm, pm, tab.campos[v], means3D, opacities, shs,
+                   colors_precomp, scales, rotations, cov3D_precomp, L.gx, L.gy, L.sgx, L.sgy, o);
   }
   uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
   if (i < N) {
     radii[i] = o.visible ? (int32_t)o.rad : 0;
     n_touched[i] = 0;
-    touched[i] = cnt;
+    ((uint32_t*)(saved + L.o_touched))[i] = cnt;
     if (o.visible) {
-      xy_out[i] = make_float2(o.px, o.py);
-      conic_o[i] = make_float4(o.A, o.B, o.C, o.opac);
-      rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
-      rect_out[i] = make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
-      clamped_out[i] = (uint8_t)o.clamped;
+      ((float2*)(saved + L.o_xy))[i] = make_float2(o.px, o.py);
+      ((float4*)(saved + L.o_conic_o))[i] = make_float4(o.A, o.B, o.C, o.opac);
+      ((float4*)(saved + L.o_rgbd))[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+      ((ushort4*)(saved + L.o_rect))[i] =
+          make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
+      ((uint8_t*)(saved + L.o_clamped))[i] = (uint8_t)o.clamped;
+      uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
       for (int y = o.y0; y < o.y1; ++y)
-        for (int x = o.x0; x < o.x1; ++x) atomicAdd(&tile_count[y * gx + x], 1u);
+        for (int x = o.x0; x < o.x1; ++x) atomicAdd(&tile_count[y * L.gx + x], 1u);
     }
   }
   uint32_t tot_t, tot_v;
   uint32_t ex = block256_exclusive_scan(cnt, red, tot_t);
   (void)block256_exclusive_scan(o.visible ? 1u : 0u, red, tot_v);
-  if (i < N) offsets_rel[i] = ex;
-  if (threadIdx.x == 0) { block_touched[blockIdx.x] = tot_t; block_vis[blockIdx.x] = tot_v; }
+  if (i < N) ((uint32_t*)(saved + L.o_offsets))[i] = ex;
+  if (threadIdx.x == 0) {
+    ((uint32_t*)(saved + L.o_block_touched))[blockIdx.x] = tot_t;
+    ((uint32_t*)(saved + L.o_block_vis))[blockIdx.x] = tot_v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
 // Per-entry partials written by blend_bwd (12 floats = 48 B per (tile, Gaussian) pair):
 //   0,1 : dL/d(mean2D) in NDC-scaled pixel units   2,3,4 : dL/dA, dL/dB, dL/dC (true partials of the conic)
 //   5   : dL/dopacity   6,7,8 : dL/drgb   9 : dL/ddepth   10,11 : unused
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(
-    int N, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod,
-    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ projraw,
-    const float* __restrict__ campos,
+struct GaussGrad {
+  float p[3], s[3], q[4], S6[6], op, m2[2], rgb_or_sh0[3];
+};
+
+// chain rule of ONE view for Gaussian i; adds into `acc`, returns the view's pose gradient in tau[6]; SH / precomputed
+// colour gradients of degree > 0 are accumulated straight into the output arrays (dshs / dcolors)
+__device__ __forceinline__ void preprocess_bwd_one_view(
+    int i, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod, const float* __restrict__ viewmatrix,
+    const float* __restrict__ projmatrix, const float* __restrict__ projraw, const float* __restrict__ campos,
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-    const int32_t* __restrict__ radii, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ touched,
-    const uint8_t* __restrict__ clamped_in, const float4* __restrict__ partials, int64_t cap,
-    float* __restrict__ dmeans3D, float* __restrict__ dmeans2D, float* __restrict__ dopac, float* __restrict__ dshs,
-    float* __restrict__ dcolors, float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D,
-    float* __restrict__ tau_part, int accumulate, float* __restrict__ stat_accum, float* __restrict__ stat_denom,
-    float* __restrict__ stat_maxr, const uint32_t* __restrict__ vis_list, const SavedHeader* __restrict__ hdr) {
-  // write mode: thread = Gaussian (all N are written).  accumulate mode: thread = entry of the compact visible list
-  // built by the forward, so the launch does V (not N) Gaussians' worth of work and touches nothing else.
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool live;
-  if (vis_list) {
-    const int V = (int)hdr->num_visible;
-    if ((int)(blockIdx.x * blockDim.x) >= V) return;          // whole block beyond the list (uniform)
-    live = i < V;
-    i = live ? (int)vis_list[i] : N;
-  } else {
-    live = (i < N) && (radii[i] > 0);
-  }
-  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ touched, const uint8_t* __restrict__ clamped_in,
+    const float4* __restrict__ partials, int64_t cap, float* __restrict__ dshs, int sh_accumulate, GaussGrad& acc,
+    float tau[6]) {
   float g_m2[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_rgb[3] = {0.f, 0.f, 0.f}, g_dep = 0.f;
-  float g_p[3] = {0.f, 0.f, 0.f};        // dL/dmean3D
+  float g_p[3] = {0.f, 0.f, 0.f};
   float g_S6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float g_s[3] = {0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f};
-
-  if (live) {
+  float sh0[3] = {0.f, 0.f, 0.f};
+  const int accumulate = sh_accumulate;
+  float* dcolors = nullptr;   // precomputed-colour gradient is returned through acc.rgb_or_sh0
+  {
     // fixed-order gather of this Gaussian's per-tile partials: deterministic, no atomics
     uint32_t off = offsets[i], cnt = touched[i];
     for (uint32_t k = 0; k < cnt; ++k) {
@@ -411,23 +404,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 
     // ---- colour
     if (colors_precomp) {
-      if (dcolors) {
-        if (accumulate) { dcolors[3 * i] += g_rgb[0]; dcolors[3 * i + 1] += g_rgb[1]; dcolors[3 * i + 2] += g_rgb[2]; }
-        else { dcolors[3 * i] = g_rgb[0]; dcolors[3 * i + 1] = g_rgb[1]; dcolors[3 * i + 2] = g_rgb[2]; }
-      }
+      sh0[0] = g_rgb[0]; sh0[1] = g_rgb[1]; sh0[2] = g_rgb[2];
     } else {
       unsigned cl = clamped_in[i];
       float dc[3] = {(cl & 1u) ? 0.f : g_rgb[0], (cl & 2u) ? 0.f : g_rgb[1], (cl & 4u) ? 0.f : g_rgb[2]};
       float* out = dshs ? dshs + (size_t)i * M * 3 : nullptr;
       if (deg == 0) {
-        if (out) {
-          if (accumulate) {
-            out[0] += SH_C0 * dc[0]; out[1] += SH_C0 * dc[1]; out[2] += SH_C0 * dc[2];
-          } else {
-            out[0] = SH_C0 * dc[0]; out[1] = SH_C0 * dc[1]; out[2] = SH_C0 * dc[2];
-            for (int k = 3; k < M * 3; ++k) out[k] = 0.f;
-          }
-        }
+        sh0[0] = SH_C0 * dc[0]; sh0[1] = SH_C0 * dc[1]; sh0[2] = SH_C0 * dc[2];
+        (void)out;
       } else {
         const float* sh = shs + (size_t)i * M * 3;
         float dir0[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
@@ -508,65 +492,146 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
       g_q[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
       g_q[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
     }
-  } else if (i < N && !accumulate) {
-    if (!colors_precomp && dshs) {
-      float* out = dshs + (size_t)i * M * 3;
-      for (int k = 0; k < M * 3; ++k) out[k] = 0.f;
-    }
-    if (colors_precomp && dcolors) { dcolors[3 * i] = 0.f; dcolors[3 * i + 1] = 0.f; dcolors[3 * i + 2] = 0.f; }
   }
-
-  if (live && accumulate) {
-    // fused mapping loop: only visible Gaussians are touched, the <= 12 views of an iteration add up in place
-    if (dmeans3D) { dmeans3D[3 * i] += g_p[0]; dmeans3D[3 * i + 1] += g_p[1]; dmeans3D[3 * i + 2] += g_p[2]; }
-    if (dmeans2D) { dmeans2D[3 * i] += g_m2[0]; dmeans2D[3 * i + 1] += g_m2[1]; }
-    if (dopac) dopac[i] += g_op;
-    if (dscales) { dscales[3 * i] += g_s[0]; dscales[3 * i + 1] += g_s[1]; dscales[3 * i + 2] += g_s[2]; }
-    if (drots) { drots[4 * i] += g_q[0]; drots[4 * i + 1] += g_q[1]; drots[4 * i + 2] += g_q[2]; drots[4 * i + 3] += g_q[3]; }
-    if (dcov3D) {
+  (void)dcolors;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) dcov3D[6 * i + k] += g_S6[k];
-    }
-  } else if (i < N && !accumulate) {
-    if (dmeans3D) { dmeans3D[3 * i] = g_p[0]; dmeans3D[3 * i + 1] = g_p[1]; dmeans3D[3 * i + 2] = g_p[2]; }
-    if (dmeans2D) { dmeans2D[3 * i] = g_m2[0]; dmeans2D[3 * i + 1] = g_m2[1]; dmeans2D[3 * i + 2] = 0.f; }
-    if (dopac) dopac[i] = g_op;
-    if (dscales) { dscales[3 * i] = g_s[0]; dscales[3 * i + 1] = g_s[1]; dscales[3 * i + 2] = g_s[2]; }
-    if (drots) { drots[4 * i] = g_q[0]; drots[4 * i + 1] = g_q[1]; drots[4 * i + 2] = g_q[2]; drots[4 * i + 3] = g_q[3]; }
-    if (dcov3D) {
+  for (int k = 0; k < 3; ++k) { acc.p[k] += g_p[k]; acc.s[k] += g_s[k]; acc.rgb_or_sh0[k] += sh0[k]; }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) dcov3D[6 * i + k] = g_S6[k];
-    }
-  }
-  if (live && stat_accum) {
-    stat_accum[i] += sqrtf(g_m2[0] * g_m2[0] + g_m2[1] * g_m2[1]);
-    stat_denom[i] += 1.f;
-    stat_maxr[i] = fmaxf(stat_maxr[i], (float)radii[i]);
-  }
+  for (int k = 0; k < 4; ++k) acc.q[k] += g_q[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc.S6[k] += g_S6[k];
+  acc.op += g_op;
+  acc.m2[0] = g_m2[0]; acc.m2[1] = g_m2[1];     // per view (densification statistics use the per-view norm)
+}
 
-  // block reduction of the pose gradient: DPP inside each wave, fixed order across the 4 waves
+// Phase 1 (dense): thread = entry of a view's compact visible list; grid = (ceil(N/256), views), blocks beyond the
+// list exit at once.  Writes one 64-byte gradient record per (view, visible Gaussian) and the view's pose partials.
+// With a single view the rarely used extras (SH degree > 0, precomputed colour / covariance) go straight to the outputs.
+__global__ void __launch_bounds__(256) preprocess_bwd_dense_kernel(
+    ViewTab tab, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, float* __restrict__ dshs, float* __restrict__ dcov3D, int accumulate) {
   __shared__ float red[4][6];
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int v = blockIdx.y;
+  const char* saved = tab.saved[v];
+  const int V = (int)((const SavedHeader*)(saved + L.o_hdr))->num_visible;
+  if ((int)(blockIdx.x * blockDim.x) >= V) return;             // whole block beyond the list (uniform)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < V;
+  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const int i = (int)((const uint32_t*)(saved + L.o_vis_list))[t];
+    GaussGrad acc;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    float t = wave_sum(tau[k]);
-    if (lane == 0) red[wv][k] = t;
+    for (int k = 0; k < 3; ++k) { acc.p[k] = 0.f; acc.s[k] = 0.f; acc.rgb_or_sh0[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc.q[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc.S6[k] = 0.f;
+    acc.op = 0.f; acc.m2[0] = 0.f; acc.m2[1] = 0.f;
+    preprocess_bwd_one_view(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, tab.viewmatrix[v], tab.projmatrix[v],
+                            cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                            (const uint32_t*)(saved + L.o_offsets), (const uint32_t*)(saved + L.o_touched),
+                            (const uint8_t*)(saved + L.o_clamped), (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
+                            dshs, accumulate, acc, tau);
+    float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)t * 4;
+    rec[0] = make_float4(acc.p[0], acc.p[1], acc.p[2], acc.rgb_or_sh0[0]);
+    rec[1] = make_float4(acc.rgb_or_sh0[1], acc.rgb_or_sh0[2], acc.op, acc.s[0]);
+    rec[2] = make_float4(acc.s[1], acc.s[2], acc.q[0], acc.q[1]);
+    rec[3] = make_float4(acc.q[2], acc.q[3], acc.m2[0], acc.m2[1]);
+    if (dcov3D) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { if (accumulate) dcov3D[6 * i + k] += acc.S6[k]; else dcov3D[6 * i + k] = acc.S6[k]; }
+    }
   }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    int k = threadIdx.x;
-    tau_part[(size_t)blockIdx.x * 6 + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+  if (tab.dL_dtau[v]) {      // uniform: pose gradient of this view requested
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float s = wave_sum(tau[k]);
+      if (lane == 0) red[wv][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      int k = threadIdx.x;
+      ((float*)(tab.scratch[v] + L.o_tau_part))[(size_t)blockIdx.x * 6 + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    }
   }
 }
 
-// second stage: one block sums the per-block partials in a fixed order
-__global__ void __launch_bounds__(384) tau_reduce_kernel(const float* __restrict__ tau_part, int nblocks, float* __restrict__ dtau,
-                                                         const SavedHeader* __restrict__ hdr) {
+// Phase 2 (light): thread = Gaussian; adds up its records over the views of the batch in fixed order (deterministic, no
+// atomics), then writes (single view, every element defined) or accumulates (only Gaussians some view saw).
+__global__ void __launch_bounds__(256) grad_gather_kernel(
+    ViewTab tab, int nviews, LOff L, int deg, int M, int has_colors, float* __restrict__ dmeans3D,
+    float* __restrict__ dmeans2D, float* __restrict__ dopac, float* __restrict__ dshs, float* __restrict__ dcolors,
+    float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D, int accumulate,
+    float* __restrict__ stat_accum, float* __restrict__ stat_denom, float* __restrict__ stat_maxr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L.N) return;
+  float a[14];
+#pragma unroll
+  for (int k = 0; k < 14; ++k) a[k] = 0.f;
+  float m2x = 0.f, m2y = 0.f, st_norm = 0.f, st_cnt = 0.f, st_maxr = 0.f;
+  bool any = false;
+  for (int v = 0; v < nviews; ++v) {
+    const int r = tab.radii[v][i];
+    if (r <= 0) continue;
+    any = true;
+    const uint32_t pos = ((const uint32_t*)(tab.saved[v] + L.o_vis_pos))[i];
+    const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)pos * 4;
+    float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
+    a[8] += r2.x; a[9] += r2.y; a[10] += r2.z; a[11] += r2.w; a[12] += r3.x; a[13] += r3.y;
+    m2x += r3.z; m2y += r3.w;
+    st_norm += sqrtf(r3.z * r3.z + r3.w * r3.w);
+    st_cnt += 1.f;
+    st_maxr = fmaxf(st_maxr, (float)r);
+  }
+  float* sh0 = has_colors ? dcolors : dshs;
+  const size_t sh_stride = has_colors ? 3 : (size_t)M * 3;
+  if (accumulate) {
+    if (!any) return;
+    if (dmeans3D) { dmeans3D[3 * i] += a[0]; dmeans3D[3 * i + 1] += a[1]; dmeans3D[3 * i + 2] += a[2]; }
+    if (sh0 && (has_colors || deg == 0)) { sh0[i * sh_stride] += a[3]; sh0[i * sh_stride + 1] += a[4]; sh0[i * sh_stride + 2] += a[5]; }
+    if (dopac) dopac[i] += a[6];
+    if (dscales) { dscales[3 * i] += a[7]; dscales[3 * i + 1] += a[8]; dscales[3 * i + 2] += a[9]; }
+    if (drots) { drots[4 * i] += a[10]; drots[4 * i + 1] += a[11]; drots[4 * i + 2] += a[12]; drots[4 * i + 3] += a[13]; }
+    if (dmeans2D) { dmeans2D[3 * i] += m2x; dmeans2D[3 * i + 1] += m2y; }
+  } else {
+    if (dmeans3D) { dmeans3D[3 * i] = a[0]; dmeans3D[3 * i + 1] = a[1]; dmeans3D[3 * i + 2] = a[2]; }
+    if (sh0 && (has_colors || deg == 0)) {
+      sh0[i * sh_stride] = a[3]; sh0[i * sh_stride + 1] = a[4]; sh0[i * sh_stride + 2] = a[5];
+      for (size_t k = 3; k < sh_stride; ++k) sh0[i * sh_stride + k] = 0.f;
+    } else if (dshs && !any) {
+      for (size_t k = 0; k < sh_stride; ++k) dshs[i * sh_stride + k] = 0.f;    // degree > 0: phase 1 wrote the visible rows
+    }
+    if (dopac) dopac[i] = a[6];
+    if (dscales) { dscales[3 * i] = a[7]; dscales[3 * i + 1] = a[8]; dscales[3 * i + 2] = a[9]; }
+    if (drots) { drots[4 * i] = a[10]; drots[4 * i + 1] = a[11]; drots[4 * i + 2] = a[12]; drots[4 * i + 3] = a[13]; }
+    if (dmeans2D) { dmeans2D[3 * i] = m2x; dmeans2D[3 * i + 1] = m2y; dmeans2D[3 * i + 2] = 0.f; }
+    if (dcov3D && !any) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dcov3D[6 * i + k] = 0.f;
+    }
+  }
+  if (any && stat_accum) {
+    stat_accum[i] += st_norm;
+    stat_denom[i] += st_cnt;
+    stat_maxr[i] = fmaxf(stat_maxr[i], st_maxr);
+  }
+}
+
+// second stage: one block per view sums the per-block partials in a fixed order
+__global__ void __launch_bounds__(384) tau_reduce_kernel(ViewTab tab, LOff L) {
   __shared__ float red[6][64];
+  const int v = blockIdx.x;
+  float* dtau = tab.dL_dtau[v];
+  if (!dtau) return;
+  const float* tau_part = (const float*)(tab.scratch[v] + L.o_tau_part);
+  const int nblk = ((int)((const SavedHeader*)(tab.saved[v] + L.o_hdr))->num_visible + 255) / 256;
   int k = threadIdx.x / 64, lane = threadIdx.x & 63;
-  if (hdr) nblocks = ((int)hdr->num_visible + 255) / 256;     // accumulate mode: only these blocks wrote a partial
   float acc = 0.f;
-  for (int b = lane; b < nblocks; b += 64) acc += tau_part[(size_t)b * 6 + k];
+  for (int b = lane; b < nblk; b += 64) acc += tau_part[(size_t)b * 6 + k];
   red[k][lane] = acc;
   __syncthreads();
   if (lane == 0) {
@@ -576,40 +641,27 @@ __global__ void __launch_bounds__(384) tau_reduce_kernel(const float* __restrict
   }
 }
 
-void launch_preprocess_fwd(const SgrSettings& s, const SgrInputs& in, const SgrOutputs& out, const Layout& L, char* saved,
-                           hipStream_t st) {
-  if (s.num_gaussians <= 0) return;
-  int blocks = L.pre_blocks;
+void launch_preprocess_fwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
+  if (L.N <= 0) return;
   ProfScope prof(PK_PRE_FWD, st);
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, st, s.num_gaussians, s.image_height,
-                     s.image_width, s.sh_degree, s.sh_coeffs, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix,
-                     s.projmatrix, s.campos, in.means3D, in.opacities, in.shs, in.colors_precomp, in.scales,
-                     in.rotations, in.cov3D_precomp, L.gx, L.gy, L.sgx, L.sgy, out.radii, out.n_touched,
-                     (float2*)(saved + L.o_xy), (float4*)(saved + L.o_conic_o), (float4*)(saved + L.o_rgbd),
-                     (ushort4*)(saved + L.o_rect), (uint32_t*)(saved + L.o_touched), (uint32_t*)(saved + L.o_offsets),
-                     (uint8_t*)(saved + L.o_clamped), (uint32_t*)(saved + L.o_tile_count),
-                     (uint32_t*)(saved + L.o_block_touched), (uint32_t*)(saved + L.o_block_vis));
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.opacities,
+                     in.shs, in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp);
 }
 
-void launch_preprocess_bwd(const SgrSettings& s, const SgrInputs& in, const int32_t* radii, const SgrGradInputs& g,
-                           const Layout& L, const char* saved, char* scratch, hipStream_t st) {
-  if (s.num_gaussians <= 0) return;
-  int blocks = L.pre_blocks;
-  float* tau_part = (float*)(scratch + L.o_tau_part);
+void launch_preprocess_bwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in,
+                           const SgrGradInputs& g, hipStream_t st) {
+  if (L.N <= 0) return;
   ProfScope prof(PK_PRE_BWD, st);
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(256), 0, st, s.num_gaussians, s.image_height,
-                     s.image_width, s.sh_degree, s.sh_coeffs, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix,
-                     s.projmatrix, s.projmatrix_raw, s.campos, in.means3D, in.shs, in.colors_precomp, in.scales,
-                     in.rotations, in.cov3D_precomp, radii, (const uint32_t*)(saved + L.o_offsets),
-                     (const uint32_t*)(saved + L.o_touched), (const uint8_t*)(saved + L.o_clamped),
-                     (const float4*)(scratch + L.o_partials), L.cap, g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dopacities,
-                     g.dL_dshs, g.dL_dcolors_precomp, g.dL_dscales, g.dL_drotations, g.dL_dcov3D_precomp, tau_part,
-                     g.accumulate, g.stat_grad_accum, (g.stat_grad_accum ? g.stat_denom : nullptr),
-                     (g.stat_grad_accum ? g.stat_max_radii : nullptr),
-                     g.accumulate ? (const uint32_t*)(saved + L.o_vis_list) : nullptr, (const SavedHeader*)(saved + L.o_hdr));
-  if (g.dL_dtau)
-    hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(384), 0, st, tau_part, blocks, g.dL_dtau,
-                       g.accumulate ? (const SavedHeader*)(saved + L.o_hdr) : nullptr);
+  hipLaunchKernelGGL(preprocess_bwd_dense_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
+                     in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, g.dL_dshs, g.dL_dcov3D_precomp, g.accumulate);
+  hipLaunchKernelGGL(grad_gather_kernel, dim3(L.pre_blocks), dim3(256), 0, st, tab, nviews, L, cm.deg, cm.M,
+                     in.colors_precomp != nullptr ? 1 : 0, g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dopacities, g.dL_dshs,
+                     g.dL_dcolors_precomp, g.dL_dscales, g.dL_drotations, g.dL_dcov3D_precomp, g.accumulate,
+                     g.stat_grad_accum, (g.stat_grad_accum ? g.stat_denom : nullptr),
+                     (g.stat_grad_accum ? g.stat_max_radii : nullptr));
+  bool any_tau = false;
+  for (int v = 0; v < nviews; ++v) any_tau = any_tau || tab.dL_dtau[v] != nullptr;
+  if (any_tau) hipLaunchKernelGGL(tau_reduce_kernel, dim3(nviews), dim3(384), 0, st, tab, L);
 }
 
 }  // namespace sgr

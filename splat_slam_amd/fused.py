@@ -40,6 +40,8 @@ class _ViewBuffers:
         self.d_tau = torch.zeros(6, dtype=torch.float32, device=dev)
         self.loss_scratch = torch.empty(1024 * 16, dtype=torch.uint8, device=dev)
         self.saved = None
+        self.scratch = None
+        self.pairs = -1            # (tile, Gaussian) pairs seen by the probe render; -1 = not probed at this map size
         self.capacity = 0
         self.gt_depth = None
         self.depth_src = None
@@ -112,7 +114,8 @@ class FusedMappingLoop(MappingLoop):
         self.last_losses = []
         self._exp = None
         self._exp_rows = []
-        self._scratch_gen = 0
+        self._cap = 0
+        self._proj_raw = {}
 
     # ------------------------------------------------------------------------------------------------ state
     def _stream(self):
@@ -129,6 +132,7 @@ class FusedMappingLoop(MappingLoop):
                      "act_scale": z(N, 3), "act_rot": z(N, 4), "act_opac": z(N, 1)}
         self._acc_key = key
         self._views = {}           # N changed: per-camera buffers are re-made lazily
+        self._cap = 0
         if gm.active_sh_degree != 0 or gm._features_rest.numel() != 0:
             raise NotImplementedError("FusedMappingLoop supports the reference's default sh_degree 0 (mapper.py:85)")
         for g in gm.optimizer.param_groups:          # make sure Adam state exists exactly like torch would create it
@@ -159,21 +163,44 @@ class FusedMappingLoop(MappingLoop):
         s.scale_modifier, s.prefiltered, s.debug = 1.0, 0, 0
         view, full, center = cam._matrices()
         s.bg, s.viewmatrix, s.projmatrix = self.background.data_ptr(), view.data_ptr(), full.data_ptr()
-        if not cam.projection_matrix.is_contiguous():
-            cam.projection_matrix = cam.projection_matrix.contiguous()
-        s.projmatrix_raw, s.campos = cam.projection_matrix.data_ptr(), center.data_ptr()
+        # cameras with the same intrinsics share ONE raw projection matrix tensor: batched launches need identical
+        # view-independent settings (pointer equality is what the C ABI can check)
+        ik = (cam.fx, cam.fy, cam.cx, cam.cy, int(cam.image_width), int(cam.image_height))
+        praw = self._proj_raw.get(ik)
+        if praw is None:
+            praw = self._proj_raw[ik] = cam.projection_matrix.detach().contiguous().clone()
+        s.projmatrix_raw, s.campos = praw.data_ptr(), center.data_ptr()
         return s
 
     def _workspace(self, vb, N, H, W, cap):
+        """Saved + scratch blocks of one camera.  Scratch is private per camera: the views of an iteration run as ONE
+        batched launch per stage (sgr_map_views), so they cannot share it."""
         sb, tb = self.lib.sgr_saved_bytes(N, H, W, cap), self.lib.sgr_scratch_bytes(N, H, W, cap)
         if vb.saved is None or vb.saved.numel() < sb or vb.capacity != cap:
             vb.saved = torch.empty(sb, dtype=torch.uint8, device=self.device)
             vb.capacity = cap
-        if self._scratch is None or self._scratch.numel() < tb:
-            self._scratch = torch.empty(tb, dtype=torch.uint8, device=self.device)
-            self._scratch_gen += 1
-            self._views_dirty()                       # cached SgrMapViews point into the old scratch block
-        return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), self._scratch.data_ptr(), self._scratch.numel(), cap)
+        if vb.scratch is None or vb.scratch.numel() < tb:
+            vb.scratch = torch.empty(tb, dtype=torch.uint8, device=self.device)
+        return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), cap)
+
+    def _probe(self, cam, vb):
+        """One synchronous forward to learn this camera's pair count at the current map size."""
+        gm = self.gaussians
+        N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
+        s = self._settings(cam, N)
+        out = nat.SgrOutputs(vb.color.data_ptr(), vb.depth.data_ptr(), vb.opacity.data_ptr(), vb.radii.data_ptr(),
+                             vb.n_touched.data_ptr())
+        inp = self._inputs()
+        cap, R = max(self._cap, 1 << 16), C.c_int64(0)
+        while True:
+            ws = self._workspace(vb, N, H, W, cap)
+            rc = self.lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(R), self._stream())
+            if rc == nat.SGR_ERR_CAPACITY:
+                cap = int(R.value * 1.25) + 1024
+                continue
+            nat.check(rc, "sgr_forward")
+            break
+        vb.pairs = int(R.value)
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _activate(self):
@@ -195,34 +222,19 @@ class FusedMappingLoop(MappingLoop):
                                  gm.denom.data_ptr() if stats else None, gm.max_radii2D.data_ptr() if stats else None)
 
     def _map_view(self, cam, initialization=False):
-        """The cached SgrMapView of a camera (pointers into persistent buffers).  The first use at a new map size
-        renders once synchronously to learn the camera's pair count and sizes its saved block at 2x."""
+        """The cached SgrMapView of a camera: pointers into its persistent buffers, sized for the shared capacity."""
         vb = self._view(cam)
         gm = self.gaussians
         N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
         view, full, center = cam._matrices()
-        key = (view.data_ptr(), full.data_ptr(), vb.capacity, vb.gt_depth.data_ptr(), cam.original_image.data_ptr(),
+        key = (view.data_ptr(), full.data_ptr(), self._cap, vb.gt_depth.data_ptr(), cam.original_image.data_ptr(),
                cam.exposure_a.data_ptr(), bool(initialization))
-        if vb.mv is not None and vb.mv_key == key and vb.capacity > 0:
+        if vb.mv is not None and vb.mv_key == key:
             return vb.mv
         s = self._settings(cam, N)
         out = nat.SgrOutputs(vb.color.data_ptr(), vb.depth.data_ptr(), vb.opacity.data_ptr(), vb.radii.data_ptr(),
                              vb.n_touched.data_ptr())
-        if vb.capacity == 0:
-            inp = self._inputs()
-            cap, R = 1 << 16, C.c_int64(0)
-            while True:
-                ws = self._workspace(vb, N, H, W, cap)
-                rc = self.lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(R), self._stream())
-                if rc == nat.SGR_ERR_CAPACITY:
-                    cap = int(R.value * 1.25) + 1024
-                    continue
-                nat.check(rc, "sgr_forward")
-                break
-            cap = max(1 << 16, int(R.value * 2))
-        else:
-            cap = vb.capacity
-        ws = self._workspace(vb, N, H, W, cap)
+        ws = self._workspace(vb, N, H, W, self._cap)
         mv = nat.SgrMapView()
         mv.settings, mv.out, mv.ws = s, out, ws
         mv.gt_image, mv.gt_depth = cam.original_image.data_ptr(), vb.gt_depth.data_ptr()
@@ -231,21 +243,24 @@ class FusedMappingLoop(MappingLoop):
         mv.loss, mv.dL_dimage, mv.dL_ddepth = vb.loss.data_ptr(), vb.d_color.data_ptr(), vb.d_depth.data_ptr()
         row = self._exp.row_of(cam) if self._exp is not None else None
         mv.dL_dexposure = vb.d_exp.data_ptr() if row is None else self._exp.grad.data_ptr() + 8 * row
-        mv.dL_dtau = vb.d_tau.data_ptr()
+        mv.dL_dtau = vb.d_tau.data_ptr() if self.keyframe_optimizers is not None else None
         mv.loss_scratch, mv.loss_scratch_bytes = vb.loss_scratch.data_ptr(), vb.loss_scratch.numel()
-        vb.mv, vb.mv_key = mv, (view.data_ptr(), full.data_ptr(), cap, vb.gt_depth.data_ptr(),
-                                cam.original_image.data_ptr(), cam.exposure_a.data_ptr(), bool(initialization))
+        vb.mv, vb.mv_key = mv, key
         return mv
 
     def _run_views(self, cams, initialization=False, stats=True, forward_only=False):
         """ONE host call for all views of the iteration: forward -> loss -> backward(accumulate) each."""
         n = len(cams)
-        while True:                                   # a growing shared scratch block invalidates earlier structs
-            gen = self._scratch_gen
-            mvs = [self._map_view(c, initialization) for c in cams]
-            if gen == self._scratch_gen:
-                break
-        arr = (nat.SgrMapView * n)(*mvs)
+        need = self._cap
+        for c in cams:                                # cameras new at this map size: learn their pair count once
+            vb = self._view(c)
+            if vb.pairs < 0:
+                self._probe(c, vb)
+            need = max(need, 1 << 16, 2 * vb.pairs)
+        if need != self._cap:                         # ONE capacity for all cameras: batched launches share a layout
+            self._cap = need
+            self._views_dirty()
+        arr = (nat.SgrMapView * n)(*[self._map_view(c, initialization) for c in cams])
         inp = self._inputs()
         gi = self._grad_sinks(stats)
         tr = self.config["mapping"]["Training"]
@@ -336,17 +351,20 @@ class FusedMappingLoop(MappingLoop):
             self.keyframe_optimizers.zero_grad(set_to_none=True)
 
     def check_overflow(self):
-        """One synchronisation: did any camera's forward exceed its pair capacity since the last check?"""
+        """One synchronisation: did any camera's forward exceed the pair capacity since the last check?"""
         self._since_check = 0
+        worst = 0
         for uid, vb in self._views.items():
-            if vb.saved is None:
+            if vb.saved is None or vb.mv is None:
                 continue
             R, ov = C.c_int64(0), C.c_int32(0)
             nat.check(self.lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), self._stream()), "sgr_query")
-            if ov.value or R.value * 1.5 > vb.capacity:
-                self.overflow_events += int(bool(ov.value))
-                vb.capacity = max(1 << 16, int(R.value * 2))
-                vb.saved, vb.mv = None, None
+            self.overflow_events += int(bool(ov.value))
+            vb.pairs = int(R.value)
+            worst = max(worst, vb.pairs)
+        if worst * 1.5 > self._cap:
+            self._cap = max(1 << 16, 2 * worst)
+            self._views_dirty()
 
     def _tick(self):
         self._since_check += 1
