@@ -225,6 +225,38 @@ typedef struct SgrMapView {
 int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* in, const SgrGradInputs* grads,
                   float alpha, float rgb_boundary_threshold, int32_t forward_only, void* stream);
 
+/* One whole mapping iteration (src/mapper.py:414-568 without densification) in ONE host call:
+ *   sgr_activate -> sgr_map_views -> sgr_gaussian_adam_step -> sgr_masked_adam (exposures).
+ * Any stage is skipped when its pointer block is NULL / its count is 0. */
+typedef struct SgrMapStep {
+  int64_t num_gaussians;
+  const float* scaling;        /* raw parameters for sgr_activate (NULL = skip activation) */
+  const float* rotation;
+  const float* opacity;
+  float* scales_out;
+  float* rot_out;
+  float* opac_out;
+  int32_t num_views;
+  int32_t forward_only;
+  const SgrMapView* views;
+  const SgrInputs* in;
+  const SgrGradInputs* grads;
+  float alpha;
+  float rgb_boundary_threshold;
+  const SgrAdamGroup* adam_groups;   /* [5] or NULL (no optimiser step this iteration) */
+  float beta1, beta2, eps, iso_weight;
+  int32_t exp_rows;            /* rows of the exposure slab to consider (0 = skip) */
+  int32_t exp_row_width;
+  float* exp_param;
+  const float* exp_grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int32_t* exp_step;
+  const int32_t* exp_active;
+  float exp_lr, exp_beta1, exp_beta2, exp_eps;
+} SgrMapStep;
+int sgr_map_step(const SgrMapStep* step, void* stream);
+
 /* Adam on a small slab with a per-row switch: row r (width `row_width`) is updated iff active[r] != 0, using its own
  * step counter step[r] (incremented in place).  The exposure parameters of the keyframe optimiser
  * (src/mapper.py:1096-1111: lr 0.01, default eps 1e-8) live in such a slab. */

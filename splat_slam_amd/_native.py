@@ -57,6 +57,17 @@ class SgrAdamGroup(C.Structure):
                 ("step", C.c_int64)]
 
 
+class SgrMapStep(C.Structure):
+    _fields_ = [("num_gaussians", C.c_int64), ("scaling", _fp), ("rotation", _fp), ("opacity", _fp), ("scales_out", _fp),
+                ("rot_out", _fp), ("opac_out", _fp), ("num_views", C.c_int32), ("forward_only", C.c_int32),
+                ("views", C.POINTER(SgrMapView)), ("in_", C.POINTER(SgrInputs)), ("grads", C.POINTER(SgrGradInputs)),
+                ("alpha", C.c_float), ("rgb_boundary_threshold", C.c_float), ("adam_groups", C.POINTER(SgrAdamGroup)),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("iso_weight", C.c_float),
+                ("exp_rows", C.c_int32), ("exp_row_width", C.c_int32), ("exp_param", _fp), ("exp_grad", _fp),
+                ("exp_avg", _fp), ("exp_avg_sq", _fp), ("exp_step", _fp), ("exp_active", _fp), ("exp_lr", C.c_float),
+                ("exp_beta1", C.c_float), ("exp_beta2", C.c_float), ("exp_eps", C.c_float)]
+
+
 # name -> (restype, argtypes); must list every symbol include/splat_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "sgr_abi_version": (C.c_int, []),
@@ -79,6 +90,7 @@ SIGNATURES = {
     "sgr_gaussian_adam_step": (C.c_int, [C.c_int64, C.POINTER(SgrAdamGroup), C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
     "sgr_map_views": (C.c_int, [C.c_int32, C.POINTER(SgrMapView), C.POINTER(SgrInputs), C.POINTER(SgrGradInputs),
                                 C.c_float, C.c_float, C.c_int32, _fp]),
+    "sgr_map_step": (C.c_int, [C.POINTER(SgrMapStep), _fp]),
     "sgr_masked_adam": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _fp]),
     "sknn_scratch_bytes": (C.c_size_t, [C.c_int32]),

@@ -69,6 +69,7 @@ class Camera(nn.Module):
         self.exposure_b = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
         self.projection_matrix = projection_matrix.to(device=device).contiguous()   # raw pointers are handed to the C ABI
         self._cache = None
+        self._version = 0
 
     @staticmethod
     def init_from_dataset(dataset, data, projection_matrix):
@@ -104,6 +105,7 @@ class Camera(nn.Module):
         self.R = R.to(device=self.device)
         self.T = t.to(device=self.device)
         self._cache = None
+        self._version = getattr(self, "_version", 0) + 1
 
     def clean(self):
         self.original_image = None

@@ -14,6 +14,7 @@ namespace sgr {
 void launch_preprocess_fwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, hipStream_t);
 void launch_preprocess_bwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, const SgrGradInputs&, hipStream_t);
 void launch_binning(const ViewTab&, int, const LOff&, hipStream_t);
+void launch_zero_heads(const ViewTab&, int, const LOff&, size_t, hipStream_t);
 void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, hipStream_t);
 void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, hipStream_t);
 
@@ -131,7 +132,7 @@ static void tab_set_view(ViewTab& t, int v, const SgrSettings* s, const SgrOutpu
 // forward of a batch that shares N, H, W, capacity and the view-independent settings
 static int forward_batch(const ViewTab& tab, int nviews, const Layout& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
   LOff d = L.dev();
-  for (int v = 0; v < nviews; ++v) HIP_TRY(hipMemsetAsync(tab.saved[v] + L.o_hdr, 0, L.zero_bytes, st));
+  launch_zero_heads(tab, nviews, d, L.zero_bytes, st);   // header + per-tile pair counters
   launch_preprocess_fwd(tab, nviews, d, cm, in, st);     // K1: project, footprint, count pairs per tile
   launch_binning(tab, nviews, d, st);                    // K2: tile/block scans   K3: scatter keys
   return SGR_OK;
@@ -276,6 +277,22 @@ int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* i
     launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, st);
   }
   HIP_TRY(hipGetLastError());
+  return SGR_OK;
+}
+
+int sgr_map_step(const SgrMapStep* p, void* stream) {
+  if (!p) return set_error(SGR_ERR_INVALID, "map_step: null argument");
+  if (p->scaling || p->rotation || p->opacity)
+    if (int rc = sgr_activate(p->num_gaussians, p->scaling, p->rotation, p->opacity, p->scales_out, p->rot_out, p->opac_out, stream)) return rc;
+  if (p->num_views > 0)
+    if (int rc = sgr_map_views(p->num_views, p->views, p->in, p->grads, p->alpha, p->rgb_boundary_threshold, p->forward_only, stream))
+      return rc;
+  if (p->adam_groups)
+    if (int rc = sgr_gaussian_adam_step(p->num_gaussians, p->adam_groups, p->beta1, p->beta2, p->eps, p->iso_weight, stream)) return rc;
+  if (p->exp_rows > 0)
+    if (int rc = sgr_masked_adam(p->exp_rows, p->exp_row_width, p->exp_param, p->exp_grad, p->exp_avg, p->exp_avg_sq, p->exp_step,
+                                 p->exp_active, p->exp_lr, p->exp_beta1, p->exp_beta2, p->exp_eps, stream))
+      return rc;
   return SGR_OK;
 }
 

@@ -102,6 +102,19 @@ __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
   }
 }
 
+// header + per-tile pair counters of every view of the batch in one launch (replaces one memset per view)
+__global__ void __launch_bounds__(256) zero_heads_kernel(ViewTab tab, LOff L, size_t nwords) {
+  uint32_t* p = (uint32_t*)(tab.saved[blockIdx.y] + L.o_hdr);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+void launch_zero_heads(const ViewTab& tab, int nviews, const LOff& L, size_t zero_bytes, hipStream_t st) {
+  size_t nwords = zero_bytes / 4;
+  int blocks = (int)((nwords + 255) / 256);
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(zero_heads_kernel, dim3(blocks, nviews), dim3(256), 0, st, tab, L, nwords);
+}
+
 void launch_binning(const ViewTab& tab, int nviews, const LOff& L, hipStream_t st) {
   {
     ProfScope prof(PK_SCAN, st);

@@ -28,6 +28,10 @@ from splat_slam_amd.pose import update_pose
 _GROUPS = ["xyz", "f_dc", "opacity", "scaling", "rotation"]     # order expected by sgr_gaussian_adam_step
 
 
+class _Plan:
+    pass
+
+
 class _ViewBuffers:
     def __init__(self, H, W, N, dev):
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -111,11 +115,12 @@ class FusedMappingLoop(MappingLoop):
         self._acc_key = None
         self._scratch = None
         self._since_check = 0
-        self.last_losses = []
         self._exp = None
         self._exp_rows = []
         self._cap = 0
         self._proj_raw = {}
+        self._plan_key = None
+        self._plan_obj = None
 
     # ------------------------------------------------------------------------------------------------ state
     def _stream(self):
@@ -203,12 +208,6 @@ class FusedMappingLoop(MappingLoop):
         vb.pairs = int(R.value)
 
     # ------------------------------------------------------------------------------------------------ pieces
-    def _activate(self):
-        gm, a = self.gaussians, self._acc
-        nat.check(self.lib.sgr_activate(gm._xyz.shape[0], gm._scaling.data_ptr(), gm._rotation.data_ptr(),
-                                        gm._opacity.data_ptr(), a["act_scale"].data_ptr(), a["act_rot"].data_ptr(),
-                                        a["act_opac"].data_ptr(), self._stream()), "sgr_activate")
-
     def _inputs(self):
         gm, a = self.gaussians, self._acc
         return nat.SgrInputs(gm._xyz.data_ptr(), a["act_opac"].data_ptr(), gm._features_dc.data_ptr(), None,
@@ -224,13 +223,12 @@ class FusedMappingLoop(MappingLoop):
     def _map_view(self, cam, initialization=False):
         """The cached SgrMapView of a camera: pointers into its persistent buffers, sized for the shared capacity."""
         vb = self._view(cam)
-        gm = self.gaussians
-        N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
-        view, full, center = cam._matrices()
-        key = (view.data_ptr(), full.data_ptr(), self._cap, vb.gt_depth.data_ptr(), cam.original_image.data_ptr(),
-               cam.exposure_a.data_ptr(), bool(initialization))
+        key = (cam._version, self._cap, id(cam.exposure_a), id(cam.original_image), initialization,
+               self.keyframe_optimizers is not None)
         if vb.mv is not None and vb.mv_key == key:
             return vb.mv
+        gm = self.gaussians
+        N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
         s = self._settings(cam, N)
         out = nat.SgrOutputs(vb.color.data_ptr(), vb.depth.data_ptr(), vb.opacity.data_ptr(), vb.radii.data_ptr(),
                              vb.n_touched.data_ptr())
@@ -248,8 +246,7 @@ class FusedMappingLoop(MappingLoop):
         vb.mv, vb.mv_key = mv, key
         return mv
 
-    def _run_views(self, cams, initialization=False, stats=True, forward_only=False):
-        """ONE host call for all views of the iteration: forward -> loss -> backward(accumulate) each."""
+    def _views_array(self, cams, initialization):
         n = len(cams)
         need = self._cap
         for c in cams:                                # cameras new at this map size: learn their pair count once
@@ -260,41 +257,103 @@ class FusedMappingLoop(MappingLoop):
         if need != self._cap:                         # ONE capacity for all cameras: batched launches share a layout
             self._cap = need
             self._views_dirty()
-        arr = (nat.SgrMapView * n)(*[self._map_view(c, initialization) for c in cams])
-        inp = self._inputs()
-        gi = self._grad_sinks(stats)
-        tr = self.config["mapping"]["Training"]
-        # the scratch block is shared: size it for the largest capacity among these views
-        nat.check(self.lib.sgr_map_views(n, arr, C.byref(inp), C.byref(gi), float(tr.get("alpha", 0.95)),
-                                         float(tr["rgb_boundary_threshold"]), int(forward_only), self._stream()),
-                  "sgr_map_views")
+        return (nat.SgrMapView * n)(*[self._map_view(c, initialization) for c in cams])
+
+    def _plan(self):
+        """Structs that only change when the parameter tensors do (new N, opacity reset, ...)."""
+        gm, a = self.gaussians, self._acc
+        by_name = {g["name"]: g for g in gm.optimizer.param_groups}
+        key = tuple(id(by_name[n]["params"][0]) for n in _GROUPS) + (id(a["xyz"]),)
+        if self._plan_key != key:
+            pl = _Plan()
+            pl.inp = self._inputs()
+            pl.step = nat.SgrMapStep()
+            st = pl.step
+            st.num_gaussians = gm._xyz.shape[0]
+            st.scaling, st.rotation, st.opacity = gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr()
+            st.scales_out, st.rot_out, st.opac_out = a["act_scale"].data_ptr(), a["act_rot"].data_ptr(), a["act_opac"].data_ptr()
+            st.in_ = C.pointer(pl.inp)
+            tr = self.config["mapping"]["Training"]
+            st.alpha, st.rgb_boundary_threshold = float(tr.get("alpha", 0.95)), float(tr["rgb_boundary_threshold"])
+            pl.groups = (nat.SgrAdamGroup * 5)()
+            pl.states = []
+            for k, name in enumerate(_GROUPS):
+                g = by_name[name]
+                p = g["params"][0]
+                stt = gm.optimizer.state[p]
+                pl.states.append((g, stt))
+                pl.groups[k] = nat.SgrAdamGroup(p.data_ptr(), a[name].data_ptr(), stt["exp_avg"].data_ptr(),
+                                                stt["exp_avg_sq"].data_ptr(), float(g["lr"]), 0, int(stt["step"].item()))
+            pl.frest_state = gm.optimizer.state[by_name["f_rest"]["params"][0]]
+            st.beta1, st.beta2 = gm.optimizer.param_groups[0]["betas"]
+            st.eps = gm.optimizer.param_groups[0]["eps"]
+            pl.gi_stats = self._grad_sinks(True)
+            pl.gi_nostats = self._grad_sinks(False)
+            self._plan_obj, self._plan_key = pl, key
+        return self._plan_obj
+
+    def _step(self, cams, iso_weight=0.0, adam=True, skip=(), initialization=False, stats=True, forward_only=False,
+              exposure="none", activate=True):
+        """ONE host call: activate -> batched views (forward / loss / backward) -> Adam -> exposure Adam."""
+        pl = self._plan()
+        st = pl.step
+        arr = self._views_array(cams, initialization)
+        st.num_views, st.views, st.forward_only = len(cams), arr, int(forward_only)
+        if not activate:
+            sc, st.scaling = st.scaling, None
+            ro, st.rotation = st.rotation, None
+            op, st.opacity = st.opacity, None
+        st.grads = C.pointer(pl.gi_stats if stats else pl.gi_nostats)
+        if adam and not forward_only:
+            for k, (g, stt) in enumerate(pl.states):
+                grp = pl.groups[k]
+                grp.lr = float(g["lr"])
+                if _GROUPS[k] in skip:
+                    grp.skip = 1
+                else:
+                    grp.skip = 0
+                    grp.step += 1
+                    stt["step"] += 1
+            pl.frest_state["step"] += 1
+            st.adam_groups = pl.groups
+            st.iso_weight = float(iso_weight)
+        else:
+            st.adam_groups = None
+        st.exp_rows = 0
+        if exposure != "none" and self._exp is not None and self._exp_rows and not forward_only:
+            e = self._exp
+            if exposure == "window":
+                first, n, active = 0, max(self._exp_rows) + 1, e.active
+            else:                                   # only the rows in `exposure` (final_refine: the rendered camera)
+                rows = [r for r in exposure if r in self._exp_rows]
+                first, n, active = (rows[0], 1, e.ones) if rows else (0, 0, e.ones)
+            if n:
+                st.exp_rows, st.exp_row_width = n, 2
+                st.exp_param, st.exp_grad = e.param.data_ptr() + 8 * first, e.grad.data_ptr() + 8 * first
+                st.exp_avg, st.exp_avg_sq = e.m.data_ptr() + 8 * first, e.v.data_ptr() + 8 * first
+                st.exp_step, st.exp_active = e.step.data_ptr() + 4 * first, active.data_ptr()
+                st.exp_lr, st.exp_beta1, st.exp_beta2, st.exp_eps = 0.01, 0.9, 0.999, 1e-8
+        rc = self.lib.sgr_map_step(C.byref(st), self._stream())
+        if not activate:
+            st.scaling, st.rotation, st.opacity = sc, ro, op
+        nat.check(rc, "sgr_map_step")
+
+    def _run_views(self, cams, initialization=False, stats=True, forward_only=False):
+        """Views only (no activation, no optimiser step): used by tests and forward-only passes."""
+        self._step(cams, adam=False, initialization=initialization, stats=stats, forward_only=forward_only, activate=False)
 
     def _view_step(self, cam, initialization=False, stats=True):
         self._run_views([cam], initialization=initialization, stats=stats)
         return self._views[cam.uid]
 
+    def _activate(self):
+        self._step([], adam=False)
+
     def _forward(self, cam, vb=None):
         self._run_views([cam], forward_only=True)
 
     def _adam(self, iso_weight, skip=()):
-        gm, a = self.gaussians, self._acc
-        groups = (nat.SgrAdamGroup * 5)()
-        by_name = {g["name"]: g for g in gm.optimizer.param_groups}
-        for k, name in enumerate(_GROUPS):
-            g = by_name[name]
-            p = g["params"][0]
-            st = gm.optimizer.state[p]
-            sk = name in skip
-            if not sk:
-                st["step"] += 1
-            groups[k] = nat.SgrAdamGroup(p.data_ptr(), a[name].data_ptr(), st["exp_avg"].data_ptr(),
-                                         st["exp_avg_sq"].data_ptr(), float(g["lr"]), int(sk), int(st["step"].item()) if not sk else 0)
-        fr = by_name["f_rest"]                      # empty at sh_degree 0: torch would still count its step
-        st = gm.optimizer.state[fr["params"][0]]
-        st["step"] += 1
-        b1, b2 = gm.optimizer.param_groups[0]["betas"]
-        nat.check(self.lib.sgr_gaussian_adam_step(gm._xyz.shape[0], groups, b1, b2, gm.optimizer.param_groups[0]["eps"],
-                                                  float(iso_weight), self._stream()), "sgr_gaussian_adam_step")
+        self._step([], iso_weight=iso_weight, adam=True, skip=skip, activate=False)
 
     # ---- exposure (keyframe) optimiser: slab-resident parameters + one masked Adam launch
     def build_keyframe_optimizers(self):
@@ -373,29 +432,33 @@ class FusedMappingLoop(MappingLoop):
 
     # ------------------------------------------------------------------------------------------------ loops
     def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
-        vb = None
+        vb, nt = None, None
         for mapping_iteration in range(self.init_itr_num if iters is None else iters):
             self.iteration_count += 1
             self._ensure_state()
-            self._activate()
-            vb = self._view_step(viewpoint, initialization=True, stats=True)
-            skip, densified = (), False
-            with torch.no_grad():
-                if mapping_iteration % self.init_gaussian_update == 0:
-                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.init_gaussian_th,
-                                                     self.init_gaussian_extent, None)
-                    densified = True
-                if self.iteration_count == self.init_gaussian_reset or (
-                        self.iteration_count == self.opt_params.densify_from_iter):
-                    self.gaussians.reset_opacity()
-                    skip = ("opacity",)
-            if densified:
-                # every parameter tensor was re-created: in the reference their .grad is None and Adam skips them all
+            densify = mapping_iteration % self.init_gaussian_update == 0
+            reset = self.iteration_count == self.init_gaussian_reset or (
+                self.iteration_count == self.opt_params.densify_from_iter)
+            if densify or reset:
+                # the reference densifies / resets between backward and optimizer.step (mapper.py:339-352): tensors
+                # re-created there have grad None and are skipped by Adam
+                self._step([viewpoint], adam=False, initialization=True)
+                vb = self._views[viewpoint.uid]
                 nt = vb.n_touched
-                self._acc_key = None
-                continue
-            nt = vb.n_touched
-            self._adam(0.0, skip=skip)
+                with torch.no_grad():
+                    if densify:
+                        self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.init_gaussian_th,
+                                                         self.init_gaussian_extent, None)
+                    if reset:
+                        self.gaussians.reset_opacity()
+                if densify:
+                    self._acc_key = None             # every tensor was re-created: no step at all this iteration
+                    continue
+                self._step([], adam=True, skip=("opacity",), activate=False)
+            else:
+                self._step([viewpoint], adam=True, initialization=True)
+                vb = self._views[viewpoint.uid]
+                nt = vb.n_touched
             self._tick()
         # like the reference, visibility comes from the LAST iteration's render (mapper.py:355)
         self.occ_aware_visibility[cur_frame_idx] = (nt > 0).long()
@@ -413,44 +476,44 @@ class FusedMappingLoop(MappingLoop):
         for it in range(iters):
             self.iteration_count += 1
             self._ensure_state()
-            self._activate()
             if prune:
-                self._run_views(viewpoint_stack, forward_only=True)
+                self._step(viewpoint_stack, adam=False, forward_only=True)
                 self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
                                              for kf, c in zip(current_window, viewpoint_stack)}
                 return False
             used = list(viewpoint_stack)
-            for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2]:
+            for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2].tolist():
                 used.append(random_viewpoint_stack[cam_idx])
-            self._run_views(used)
-            self.last_losses = [self._views[c.uid].loss for c in used]
-            with torch.no_grad():
-                update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
-                reset = (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian)
-                if it == iters - 1 or update_gaussian:
-                    # the reference rebuilds this dict every iteration (mapper.py:494-498); only the value that
-                    # survives the call (or a change of N) is observable
-                    self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
-                                                 for kf, c in zip(current_window, viewpoint_stack)}
-                skip = ()
-                if update_gaussian:
-                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
-                                                     self.gaussian_extent, self.size_threshold)
-                    gaussian_split = True
-                    self._acc_key = None
-                if reset:
-                    self.gaussians.reset_opacity_nonvisible([self._views[c.uid].radii > 0 for c in used])
-                    gaussian_split = True
-                    skip = ("opacity",)
-                if not update_gaussian:
-                    self._adam(10.0, skip=skip)
-                self.gaussians.update_learning_rate(self.iteration_count)
-                self._exposure_step(used)
-                if pose_opt:
-                    for cam_idx in range(min(frames_to_optimize, len(current_window))):
-                        if viewpoint_stack[cam_idx].uid == 0:
-                            continue
-                        update_pose(viewpoint_stack[cam_idx])
+            update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
+            reset = (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian)
+            special = update_gaussian or reset
+            # regular iteration: everything in one host call; densify / reset iterations split around the torch-side surgery
+            self._step(used, iso_weight=10.0, adam=not special, exposure="none" if (special or pose_opt) else "window")
+            if special or pose_opt or it == iters - 1:
+                with torch.no_grad():
+                    if it == iters - 1 or update_gaussian:
+                        # the reference rebuilds this dict every iteration (mapper.py:494-498); only the value that
+                        # survives the call (or a change of N) is observable
+                        self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
+                                                     for kf, c in zip(current_window, viewpoint_stack)}
+                    if update_gaussian:
+                        self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
+                                                         self.gaussian_extent, self.size_threshold)
+                        gaussian_split = True
+                        self._acc_key = None
+                    if reset:
+                        self.gaussians.reset_opacity_nonvisible([self._views[c.uid].radii > 0 for c in used])
+                        gaussian_split = True
+                        self._step([], iso_weight=10.0, adam=True, skip=("opacity",), activate=False)
+                    if special or pose_opt:
+                        self._exposure_step(used)
+                    if pose_opt:
+                        for cam_idx in range(min(frames_to_optimize, len(current_window))):
+                            if viewpoint_stack[cam_idx].uid == 0:
+                                continue
+                            update_pose(viewpoint_stack[cam_idx])
+            self.gaussians.update_learning_rate(self.iteration_count)
+            self.last_used = used
             self._tick()
         return gaussian_split
 
@@ -459,14 +522,17 @@ class FusedMappingLoop(MappingLoop):
         for _ in range(iters):
             self.iteration_count += 1
             self._ensure_state()
-            self._activate()
             cam = stack[np.random.randint(0, len(stack))]
-            self._run_views([cam], stats=False)
-            self._adam(0.0)
+            row = self._exp.row_of(cam) if self._exp is not None else None
+            self._step([cam], adam=True, stats=False, exposure=[row] if row is not None else "none")
             self.gaussians.update_learning_rate(self.iteration_count)
-            self._exposure_step([cam], only_rendered=True)
+            self.last_used = [cam]
             self._tick()
 
     # convenience for evaluation / tests
+    @property
+    def last_losses(self):
+        return [self._views[c.uid].loss for c in getattr(self, "last_used", [])]
+
     def total_loss(self):
         return torch.stack([l[0] for l in self.last_losses]).sum()
