@@ -89,9 +89,11 @@ def main():
     # would change N (the metric is quoted AT 300k Gaussians); start right after such a point -> 149 clean iterations
     loop.iteration_count = 50
     assert args.warmup + args.steps < 149, "keep warmup+steps < 149 so that no densification changes N mid-benchmark"
-    sync = GradientSync(loop.gaussians, world) if world > 1 else None
-    if sync is not None:
-        loop.grad_sync = sync
+    if world > 1:
+        if args.loop == "fused":
+            loop.world = world                                  # flat accumulator buffer, one all-reduce per step
+        else:
+            loop.grad_sync = GradientSync(loop.gaussians, world)
 
     def steps(k):
         # exactly k iterations of the mapping loop, driven the way the reference drives it: ONE map() call

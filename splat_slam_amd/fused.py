@@ -121,8 +121,15 @@ class FusedMappingLoop(MappingLoop):
         self._proj_raw = {}
         self._plan_key = None
         self._plan_obj = None
+        self.world = 1              # ranks exchanging gradients (set by the multi-GPU driver together with dist_group)
+        self.dist_group = None
 
     # ------------------------------------------------------------------------------------------------ state
+    def _all_reduce_sum(self, t):
+        """RCCL all-reduce of the flat gradient buffer (backend "nccl" is RCCL on ROCm; it rides xGMI inside a node)."""
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dist_group)
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
@@ -133,7 +140,12 @@ class FusedMappingLoop(MappingLoop):
             return
         N, dev = gm._xyz.shape[0], self.device
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        self._acc = {"xyz": z(N, 3), "f_dc": z(N, 1, 3), "opacity": z(N, 1), "scaling": z(N, 3), "rotation": z(N, 4),
+        # the five gradient accumulators are views of ONE flat buffer (14 floats per Gaussian): a multi-GPU step
+        # exchanges it with a single collective (parallel.py), no packing
+        flat = z(N * 14)
+        self._acc = {"flat": flat, "xyz": flat[: 3 * N].view(N, 3), "f_dc": flat[3 * N: 6 * N].view(N, 1, 3),
+                     "opacity": flat[6 * N: 7 * N].view(N, 1), "scaling": flat[7 * N: 10 * N].view(N, 3),
+                     "rotation": flat[10 * N: 14 * N].view(N, 4),
                      "act_scale": z(N, 3), "act_rot": z(N, 4), "act_opac": z(N, 1)}
         self._acc_key = key
         self._views = {}           # N changed: per-camera buffers are re-made lazily
@@ -333,7 +345,22 @@ class FusedMappingLoop(MappingLoop):
                 st.exp_avg, st.exp_avg_sq = e.m.data_ptr() + 8 * first, e.v.data_ptr() + 8 * first
                 st.exp_step, st.exp_active = e.step.data_ptr() + 4 * first, active.data_ptr()
                 st.exp_lr, st.exp_beta1, st.exp_beta2, st.exp_eps = 0.01, 0.9, 0.999, 1e-8
-        rc = self.lib.sgr_map_step(C.byref(st), self._stream())
+        if self.world > 1 and st.adam_groups and len(cams) and not forward_only:
+            # multi-GPU: (1) this rank's views, (2) sum the flat gradient buffer over ranks with ONE RCCL all-reduce,
+            # (3) the identical Adam step on every rank (the isotropy term is added locally, once)
+            exp_rows = int(st.exp_rows)     # (reading a POINTER field aliases the struct memory: re-assign pl.groups below)
+            st.adam_groups, st.exp_rows = None, 0
+            rc = self.lib.sgr_map_step(C.byref(st), self._stream())
+            if rc == 0:
+                self._all_reduce_sum(self._acc["flat"])
+                st.adam_groups, st.exp_rows, st.num_views = pl.groups, exp_rows, 0
+                s2, st.scaling = st.scaling, None
+                r2, st.rotation = st.rotation, None
+                o2, st.opacity = st.opacity, None
+                rc = self.lib.sgr_map_step(C.byref(st), self._stream())
+                st.scaling, st.rotation, st.opacity = s2, r2, o2
+        else:
+            rc = self.lib.sgr_map_step(C.byref(st), self._stream())
         if not activate:
             st.scaling, st.rotation, st.opacity = sc, ro, op
         nat.check(rc, "sgr_map_step")
@@ -497,6 +524,12 @@ class FusedMappingLoop(MappingLoop):
                         self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
                                                      for kf, c in zip(current_window, viewpoint_stack)}
                     if update_gaussian:
+                        if self.world > 1:     # densification statistics are per rank: combine, then every rank
+                            import torch.distributed as dist        # takes the identical (same-seed) decision
+                            gm = self.gaussians
+                            dist.all_reduce(gm.xyz_gradient_accum, op=dist.ReduceOp.SUM, group=self.dist_group)
+                            dist.all_reduce(gm.denom, op=dist.ReduceOp.SUM, group=self.dist_group)
+                            dist.all_reduce(gm.max_radii2D, op=dist.ReduceOp.MAX, group=self.dist_group)
                         self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
                                                          self.gaussian_extent, self.size_threshold)
                         gaussian_split = True
