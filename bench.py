@@ -162,33 +162,58 @@ def main():
     render_fwd_bwd_ms = timed(fwd_bwd)
     trace("timed fwd_bwd ok")
 
-    # work counters of one view (through the drop-in autograd surface, same kernels)
+    # ---- work counters of the views of the last timed step (saved blocks of the fused loop; one sync each)
     stats = (C.c_int64 * 4)()
-    pkg = render(cam0, loop.gaussians, PipelineParams(), bg)
-    torch.cuda.synchronize(); trace("stats render ok")
-    fn = pkg["render"].grad_fn
-    saved = fn.saved_tensors[-1]
-    radii = pkg["radii"]
-    st = dgr._state(dev)
-    ws = nat.SgrWorkspace(saved.data_ptr(), saved.numel(), st.scratch.data_ptr(), st.scratch.numel(), fn.capacity)
-    assert loop.gaussians.get_xyz.shape[0] == N, "N changed during the benchmark"
-    nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], radii.data_ptr(), stats,
-                                  torch.cuda.current_stream(dev).cuda_stream), "sgr_query_stats")
-    V, R, R_eff, tiles_nonempty = [int(x) for x in stats]
-    trace("stats ok")
     HW = intr["H"] * intr["W"]
+    assert loop.gaussians.get_xyz.shape[0] == N, "N changed during the benchmark"
+    per_view = []
+    if args.loop == "fused":
+        for cam in loop.last_used:
+            vb = loop._views[cam.uid]
+            ws = nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), loop._cap)
+            nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], vb.radii.data_ptr(), stats,
+                                          torch.cuda.current_stream(dev).cuda_stream), "sgr_query_stats")
+            per_view.append([int(x) for x in stats])
+    else:
+        pkg = render(cam0, loop.gaussians, PipelineParams(), bg)
+        fn = pkg["render"].grad_fn
+        saved = fn.saved_tensors[-1]
+        st = dgr._state(dev)
+        ws = nat.SgrWorkspace(saved.data_ptr(), saved.numel(), st.scratch.data_ptr(), st.scratch.numel(), fn.capacity)
+        nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], pkg["radii"].data_ptr(), stats,
+                                      torch.cuda.current_stream(dev).cuda_stream), "sgr_query_stats")
+        per_view.append([int(x) for x in stats])
+    trace("stats ok")
+    nv = len(per_view)
+    V = sum(p[0] for p in per_view) // nv
+    R = sum(p[1] for p in per_view) // nv
+    R_eff_sum = sum(p[2] for p in per_view)
+    tiles_nonempty = sum(p[3] for p in per_view) // nv
 
-    # ---- roofline of the dominant kernel (tile-blend backward), SURVEY.md 8d algorithmic bytes
+    # ---- roofline of the dominant kernel (tile-blend backward).  One launch covers `views_in_launch` views (batched).
     bwd_launches = int(cnt[7])
     bwd_ms = float(ms[7]) / max(1, bwd_launches)
-    alg_bytes = 84 * R_eff + 24 * HW + 40 * N
+    views_in_launch = nv if args.loop == "fused" else 1
+    r_eff_launch = R_eff_sum if args.loop == "fused" else per_view[0][2]
+    alg_bytes = 84 * r_eff_launch + (24 * HW + 40 * N) * views_in_launch          # SURVEY.md 8d figure
+    own_bytes = 92 * r_eff_launch + 24 * HW * views_in_launch                      # what this design moves
     achieved = alg_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-    pair_evals = R_eff * 64                      # (pixel, splat) pairs the kernel evaluates
+    pair_evals = r_eff_launch * 64               # (pixel, splat) pairs the kernel evaluates
     valu_tflops = pair_evals * 60 / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+    traffic = None
+    try:                                         # PMC pass of this same command, committed under profiles/
+        pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_hbm_bytes.json")))
+        if pm.get("workload") == [N, intr["W"], intr["H"], views_in_launch]:
+            traffic = pm["kernels"]["sgr::blend_bwd_kernel"]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
     roofline = {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_launch_ms": round(bwd_ms, 5), "launches": bwd_launches, "algorithmic_bytes": alg_bytes,
-                "valu_frac_at_60flop_per_pair": round(valu_tflops / FP32_PEAK_TFLOPS, 4)}
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "avg_launch_ms": round(bwd_ms, 5), "launches": bwd_launches, "views_per_launch": views_in_launch,
+                "algorithmic_bytes": alg_bytes, "own_formula_bytes": own_bytes,
+                "pixel_splat_pairs_per_launch": pair_evals,
+                "valu_frac_at_60flop_per_pair": round(valu_tflops / FP32_PEAK_TFLOPS, 4),
+                "note": "splat-list blending is VALU-issue bound (DESIGN.md 3): HBM fraction is small by construction"}
 
     out = {
         "metric": "mapping frames/sec + render ms @640x480, 300k Gaussians; PSNR vs ref",
@@ -202,7 +227,7 @@ def main():
                    "parallelism": "view-parallel x%d, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
         "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4),
         "render_ms": {"forward": round(render_fwd_ms, 4), "forward_backward_loss": round(render_fwd_bwd_ms, 4)},
-        "work_per_view": {"visible_gaussians": V, "tile_pairs_R": R, "tile_pairs_walked_R_eff": R_eff,
+        "work_per_view": {"visible_gaussians": V, "tile_pairs_R": R, "tile_pairs_walked_R_eff": R_eff_sum // nv,
                           "nonempty_tiles": tiles_nonempty},
         "roofline": roofline,
     }

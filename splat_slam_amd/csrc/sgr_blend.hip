@@ -262,6 +262,7 @@ __device__ __forceinline__ void bwd_chunk(
   float s_gx = 0.f, s_gy = 0.f, s_gxx = 0.f, s_gxy = 0.f, s_gyy = 0.f;
   float a_o = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
 
+#pragma unroll 2
   for (int it = 0; it < kWave / PP; ++it) {
     const int p = it * PP + sub;                 // this lane's pixel (same for the whole group)
     const float4 pa = pixA[p];                   // dCr, dCg, dCb, dD     (LDS, broadcast inside the group)
