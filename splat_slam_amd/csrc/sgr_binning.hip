@@ -62,43 +62,48 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   }
 }
 
-// K3: finishes the two-level scans (absolute partial-slot offsets, compact visible list) and scatters one
-// (depth bits | Gaussian) key per pair into its tile's run.  Order inside a run is arbitrary here; K4 sorts it.
+// K3: grid = (ceil(N/1024), views), thread = 4 consecutive Gaussians (one int4 of radii; most threads see nothing and
+// leave), no barriers: finishes the visible list (absolute position = block base + in-block prefix from K1) and
+// scatters one (depth bits | Gaussian) key per pair into its tile's run.  Order inside a run is arbitrary; K4 sorts it.
 __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
-  __shared__ uint32_t red[4];
-  const int v = blockIdx.y, N = L.N;
+  const int v = blockIdx.y;
   char* saved = tab.saved[v];
-  const int32_t* __restrict__ radii = tab.radii[v];
-  uint32_t* __restrict__ offsets = (uint32_t*)(saved + L.o_offsets);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool vis = i < N && radii[i] > 0;
-  uint32_t tot;
-  uint32_t vpos = block256_exclusive_scan(vis ? 1u : 0u, red, tot);
-  if (tot == 0) return;                                   // nothing visible in this block (uniform)
-  if (i >= N) return;
-  uint32_t off = offsets[i] + ((const uint32_t*)(saved + L.o_block_base_t))[blockIdx.x];
-  offsets[i] = off;
-  if (!vis) return;
-  const uint32_t vp = ((const uint32_t*)(saved + L.o_block_base_v))[blockIdx.x] + vpos;
-  ((uint32_t*)(saved + L.o_vis_list))[vp] = (uint32_t)i;
-  ((uint32_t*)(saved + L.o_vis_pos))[i] = vp;
-  if (((const uint32_t*)(saved + L.o_touched))[i] == 0) return;
-  ushort4 r = ((const ushort4*)(saved + L.o_rect))[i];
-  uint64_t key = ((uint64_t)__float_as_uint(((const float4*)(saved + L.o_rgbd))[i].w) << 32) | (uint32_t)i;
+  const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= L.N) return;
+  int rr[4] = {0, 0, 0, 0};
+  if (i0 + 3 < L.N) {
+    int4 q = *(const int4*)(tab.radii[v] + i0);
+    rr[0] = q.x; rr[1] = q.y; rr[2] = q.z; rr[3] = q.w;
+  } else {
+    for (int k = 0; k < 4 && i0 + k < L.N; ++k) rr[k] = tab.radii[v][i0 + k];
+  }
+  if ((rr[0] | rr[1] | rr[2] | rr[3]) <= 0) return;
+  uint32_t* vis_pos = (uint32_t*)(saved + L.o_vis_pos);
   uint2* ranges = (uint2*)(saved + L.o_ranges);
   uint64_t* entries = (uint64_t*)(tab.scratch[v] + L.o_entries);
-  const int w = (int)r.z - (int)r.x, cnt = w * ((int)r.w - (int)r.y);
-  // returning atomics are latency-bound: keep 4 in flight per thread (most splats cover <= 4 bins)
-  for (int k0 = 0; k0 < cnt; k0 += 4) {
-    uint32_t pos[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int kk = k0 + k;
-      if (kk < cnt) pos[k] = atomicAdd(&ranges[((int)r.y + kk / w) * L.gx + (int)r.x + kk % w].y, 1u);
+  for (int k = 0; k < 4; ++k) {
+    if (rr[k] <= 0) continue;
+    const uint32_t i = (uint32_t)(i0 + k);
+    const uint32_t vp = vis_pos[i] + ((const uint32_t*)(saved + L.o_block_base_v))[i >> 8];
+    vis_pos[i] = vp;
+    ((uint32_t*)(saved + L.o_vis_list))[vp] = i;
+    if (((const uint32_t*)(saved + L.o_touched))[i] == 0) continue;
+    ushort4 r = ((const ushort4*)(saved + L.o_rect))[i];
+    uint64_t key = ((uint64_t)__float_as_uint(((const float4*)(saved + L.o_rgbd))[i].w) << 32) | i;
+    const int w = (int)r.z - (int)r.x, cnt = w * ((int)r.w - (int)r.y);
+    // returning atomics are latency-bound: keep 4 in flight (most splats cover <= 4 bins)
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+      uint32_t pos[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int kk = k0 + j;
+        if (kk < cnt) pos[j] = atomicAdd(&ranges[((int)r.y + kk / w) * L.gx + (int)r.x + kk % w].y, 1u);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k0 + j < cnt && (int64_t)pos[j] < L.cap) entries[pos[j]] = key;
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k0 + k < cnt && (int64_t)pos[k] < L.cap) entries[pos[k]] = key;
   }
 }
 
@@ -122,7 +127,7 @@ void launch_binning(const ViewTab& tab, int nviews, const LOff& L, hipStream_t s
   }
   if (L.N > 0) {
     ProfScope prof(PK_SCATTER, st);
-    hipLaunchKernelGGL(scatter_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L);
+    hipLaunchKernelGGL(scatter_kernel, dim3((L.N + 1023) / 1024, nviews), dim3(256), 0, st, tab, L);
   }
 }
 

@@ -243,8 +243,8 @@ template <int GW>
 __device__ __forceinline__ void bwd_chunk(
     int lane, int c, int eff, int64_t begin, float tx0, float ty0, const float4* pixA /*LDS*/, float4* pixB /*LDS*/,
     const uint32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
-    const float4* __restrict__ rgbd, const ushort4* __restrict__ rect, const uint32_t* __restrict__ offsets, int tx,
-    int ty, float halfW, float halfH, float4* __restrict__ partials, int64_t cap) {
+    const float4* __restrict__ rgbd, const ushort4* __restrict__ rect, const char* __restrict__ saved, const LOff& L,
+    int tx, int ty, float halfW, float halfH, float4* __restrict__ partials, int64_t cap) {
   constexpr int PP = kWave / GW;                 // pixels processed per iteration
   const int sub = lane / GW;                     // which of them this lane works on
   const int sl = lane % GW;
@@ -315,7 +315,7 @@ __device__ __forceinline__ void bwd_chunk(
   if (valid && sub == 0) {
     // slot of this (tile, Gaussian) pair inside the Gaussian's own run of partials
     ushort4 r = rect[g];
-    uint64_t slot = (uint64_t)offsets[g] + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
+    uint64_t slot = (uint64_t)abs_offset(saved, L, g) + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
     if ((int64_t)slot < cap) {
       float dmx = (-(A * s_gx) - B * s_gy) * halfW;
       float dmy = (-(Cc * s_gy) - B * s_gx) * halfH;
@@ -337,7 +337,6 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   const float4* __restrict__ conic_o = (const float4*)(saved + L.o_conic_o);
   const float4* __restrict__ rgbd = (const float4*)(saved + L.o_rgbd);
   const ushort4* __restrict__ rect = (const ushort4*)(saved + L.o_rect);
-  const uint32_t* __restrict__ offsets = (const uint32_t*)(saved + L.o_offsets);
   const float* __restrict__ final_T = (const float*)(saved + L.o_final_T);
   const uint32_t* __restrict__ n_contrib = (const uint32_t*)(saved + L.o_n_contrib);
   const uint32_t* __restrict__ tile_maxc = (const uint32_t*)(saved + L.o_tile_maxc);
@@ -363,7 +362,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   for (int idx = eff + lane; idx < count; idx += kWave) {
     uint32_t g = point_list[begin + idx];
     ushort4 r = rect[g];
-    uint64_t slot = (uint64_t)offsets[g] + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
+    uint64_t slot = (uint64_t)abs_offset(saved, L, g) + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
     if ((int64_t)slot < cap) {
       partials[slot * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
       partials[slot * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -398,15 +397,15 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
 
   if (eff <= 16) {
-    bwd_chunk<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, offsets, tx, ty, halfW,
+    bwd_chunk<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty, halfW,
                   halfH, partials, cap);
   } else if (eff <= 32) {
-    bwd_chunk<32>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, offsets, tx, ty, halfW,
+    bwd_chunk<32>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty, halfW,
                   halfH, partials, cap);
   } else {
     const int nchunks = (eff + kWave - 1) / kWave;
     for (int c = nchunks - 1; c >= 0; --c) {
-      bwd_chunk<64>(lane, c, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, offsets, tx, ty,
+      bwd_chunk<64>(lane, c, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty,
                     halfW, halfH, partials, cap);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();

@@ -63,7 +63,7 @@ struct LOff {
   int64_t cap;
   size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_vis_pos, o_entries, o_partials, o_tau_part, o_gradrec;
+      o_vis_pos, o_entries, o_partials, o_tau_part, o_gradrec, o_taurec;
 };
 // shared (view independent) scalars of a batch
 struct Common {
@@ -87,7 +87,7 @@ struct Layout {
   // scratch (forward)
   size_t o_entries;
   // scratch (backward) -- aliases the forward scratch
-  size_t o_partials, o_tau_part, o_gradrec, scratch_bytes;
+  size_t o_partials, o_tau_part, o_gradrec, o_taurec, scratch_bytes;
   int pre_blocks;
 
   __host__ Layout(int N_, int H_, int W_, int64_t cap_) : N(N_), H(H_), W(W_), cap(cap_) {
@@ -133,6 +133,7 @@ struct Layout {
     o_partials = take(c * 48);
     o_tau_part = take((size_t)(pre_blocks > 0 ? pre_blocks : 1) * 6 * 4);
     o_gradrec = take(n * 64);          // per visible Gaussian: 16-float gradient record of this view
+    o_taurec = take(n * 24);           // per visible Gaussian: its 6 pose-gradient terms (only when requested)
     scratch_bytes = fwd > o ? fwd : o;
   }
   __host__ LOff dev() const {
@@ -145,7 +146,7 @@ struct Layout {
     d.o_n_contrib = o_n_contrib; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
     d.o_block_base_t = o_block_base_t; d.o_block_base_v = o_block_base_v; d.o_vis_list = o_vis_list;
     d.o_vis_pos = o_vis_pos; d.o_entries = o_entries; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
-    d.o_gradrec = o_gradrec;
+    d.o_gradrec = o_gradrec; d.o_taurec = o_taurec;
     return d;
   }
 };
@@ -176,6 +177,11 @@ struct ProfScope {
   ProfScope(int k, hipStream_t s) : kind(k), st(s) { prof_begin(kind, st); }
   ~ProfScope() { prof_end(kind, st); }
 };
+
+// absolute partial-slot offset of Gaussian g: in-block prefix (written by preprocess_fwd) + its block's base (tile_scan)
+__device__ __forceinline__ uint32_t abs_offset(const char* saved, const LOff& L, uint32_t g) {
+  return ((const uint32_t*)(saved + L.o_offsets))[g] + ((const uint32_t*)(saved + L.o_block_base_t))[g >> 8];
+}
 
 // ---- tiny fixed-size linear algebra on registers
 struct V3 { float x, y, z; };

@@ -119,43 +119,35 @@ struct PreOut {
   unsigned clamped;
 };
 
-__device__ __forceinline__ void preprocess_one(
-    int i, int H, int W, int deg, int M, float tanfovx, float tanfovy, float mod, const float* vm, const float* pm,
-    const float* __restrict__ campos, const float* __restrict__ means3D, const float* __restrict__ opacities,
-    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, int gx, int gy, int sgx, int sgy,
-    PreOut& o) {
+// K1: per-Gaussian projection + footprint + 8x8 bin rectangle, and the first half of the binning:
+//   * per-tile pair counts (one fire-and-forget atomic per (tile, Gaussian) pair),
+//   * in-block exclusive prefixes of `touched` and `visible` + the block totals (finished by tile_scan_kernel: a
+//     deterministic two-level scan instead of a device-wide scan library call).
+// grid = (ceil(N/256), views): blockIdx.y selects the view.  (Walking the views inside one block to share the
+// per-Gaussian loads was measured slower: 12x fewer waves cannot hide the latency of the load -> atomic -> scan chain.)
+struct PreIn {
+  float p[3], opac, S6[6], c_in[3];
+};
+
+__device__ __forceinline__ void preprocess_view(const PreIn& in, int i, int H, int W, int deg, int M, float tanfovx,
+                                                float tanfovy, const float* vm, const float* pm,
+                                                const float* __restrict__ campos, const float* __restrict__ shs,
+                                                bool has_colors, int gx, int gy, int sgx, int sgy, PreOut& o) {
   o.visible = false;
   o.x0 = o.x1 = o.y0 = o.y1 = 0;
-  // issue every per-Gaussian load before the first dependent branch: one HBM round trip instead of four
-  float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
-  const float opac = opacities[i];
-  float S6[6], s_in[3] = {0.f, 0.f, 0.f}, q_in[4] = {1.f, 0.f, 0.f, 0.f};
-  if (cov3D_precomp) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) S6[k] = cov3D_precomp[6 * i + k];
-  } else {
-    s_in[0] = scales[3 * i]; s_in[1] = scales[3 * i + 1]; s_in[2] = scales[3 * i + 2];
-    q_in[0] = rotations[4 * i]; q_in[1] = rotations[4 * i + 1]; q_in[2] = rotations[4 * i + 2]; q_in[3] = rotations[4 * i + 3];
-  }
-  float c_in[3] = {0.f, 0.f, 0.f};
-  if (colors_precomp) { c_in[0] = colors_precomp[3 * i]; c_in[1] = colors_precomp[3 * i + 1]; c_in[2] = colors_precomp[3 * i + 2]; }
-  else if (deg == 0) { c_in[0] = shs[(size_t)i * M * 3]; c_in[1] = shs[(size_t)i * M * 3 + 1]; c_in[2] = shs[(size_t)i * M * 3 + 2]; }
+  const float* p = in.p;
   float pv[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) pv[r] = vm[r] * p[0] + vm[4 + r] * p[1] + vm[8 + r] * p[2] + vm[12 + r];
   if (!(pv[2] > kNearPlane)) return;
-
   float ph[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) ph[r] = pm[r] * p[0] + pm[4 + r] * p[1] + pm[8 + r] * p[2] + pm[12 + r];
   float pw = 1.f / (ph[3] + 1e-7f);
   float ndcx = ph[0] * pw, ndcy = ph[1] * pw;
-
-  if (!cov3D_precomp) cov3d_from_scale_rot(s_in, mod, q_in, S6);
   float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
   Ewa e;
-  ewa_project(pv, vm, S6, fx, fy, 1.3f * tanfovx, 1.3f * tanfovy, e);
+  ewa_project(pv, vm, in.S6, fx, fy, 1.3f * tanfovx, 1.3f * tanfovy, e);
   float det = e.a * e.c - e.b * e.b;
   if (det == 0.f) return;
   float det_inv = 1.f / det;
@@ -174,6 +166,7 @@ __device__ __forceinline__ void preprocess_one(
   int ry1 = min(sgy, max(0, (int)((py + rad + (kRefTile - 1)) / (float)kRefTile)));
   if ((rx1 - rx0) * (ry1 - ry0) == 0) return;
 
+  const float opac = in.opac;
   // our bins are 8x8 (one wave): refine the rectangle, then drop bins no pixel of which can pass alpha >= 1/255.
   int x0 = min(gx, 2 * rx0), x1 = min(gx, 2 * rx1), y0 = min(gy, 2 * ry0), y1 = min(gy, 2 * ry1);
   {
@@ -199,12 +192,12 @@ __device__ __forceinline__ void preprocess_one(
   }
 
   o.clamped = 0;
-  if (colors_precomp) {
-    o.rgb[0] = c_in[0]; o.rgb[1] = c_in[1]; o.rgb[2] = c_in[2];
+  if (has_colors) {
+    o.rgb[0] = in.c_in[0]; o.rgb[1] = in.c_in[1]; o.rgb[2] = in.c_in[2];
   } else if (deg == 0) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float r = SH_C0 * c_in[c] + 0.5f;
+      float r = SH_C0 * in.c_in[c] + 0.5f;
       if (r < 0.f) { o.clamped |= 1u << c; r = 0.f; }
       o.rgb[c] = r;
     }
@@ -219,55 +212,72 @@ __device__ __forceinline__ void preprocess_one(
   o.x0 = x0; o.y0 = y0; o.x1 = x1; o.y1 = y1;
 }
 
-// K1: per-Gaussian projection + footprint + 8x8 bin rectangle, and the first half of the binning:
-//   * per-tile pair counts (one fire-and-forget atomic per (tile, Gaussian) pair),
-//   * in-block exclusive prefix of `touched` / `visible` + the block totals (finished by tile_scan_kernel: a
-//     deterministic two-level scan instead of a device-wide scan library call).
-// grid = (ceil(N/256), views): blockIdx.y selects the view of the batch.
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
-    ViewTab tab, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    ViewTab tab, int nviews, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp) {
   __shared__ uint32_t red[4];
-  const int v = blockIdx.y, N = L.N;
-  char* saved = tab.saved[v];
-  int32_t* __restrict__ radii = tab.radii[v];
-  int32_t* __restrict__ n_touched = tab.n_touched[v];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  PreOut o;
-  o.visible = false;
-  o.x0 = o.x1 = o.y0 = o.y1 = 0;
-  if (i < N) {
-    float vm[16], pm[16];
-    load16(tab.viewmatrix[v], vm);
-    load16(tab.projmatrix[v], pm);
-    preprocess_one(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, vm, pm, tab.campos[v], means3D, opacities, shs,
-                   colors_precomp, scales, rotations, cov3D_precomp, L.gx, L.gy, L.sgx, L.sgy, o);
-  }
-  uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
-  if (i < N) {
-    radii[i] = o.visible ? (int32_t)o.rad : 0;
-    n_touched[i] = 0;
-    ((uint32_t*)(saved + L.o_touched))[i] = cnt;
-    if (o.visible) {
-      ((float2*)(saved + L.o_xy))[i] = make_float2(o.px, o.py);
-      ((float4*)(saved + L.o_conic_o))[i] = make_float4(o.A, o.B, o.C, o.opac);
-      ((float4*)(saved + L.o_rgbd))[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
-      ((ushort4*)(saved + L.o_rect))[i] =
-          make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
-      ((uint8_t*)(saved + L.o_clamped))[i] = (uint8_t)o.clamped;
-      uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
-      for (int y = o.y0; y < o.y1; ++y)
-        for (int x = o.x0; x < o.x1; ++x) atomicAdd(&tile_count[y * L.gx + x], 1u);
+  const int N = L.N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_range = i < N;
+  PreIn in;
+  if (in_range) {      // every per-Gaussian load up front: one HBM round trip, shared by all views
+    in.p[0] = means3D[3 * i]; in.p[1] = means3D[3 * i + 1]; in.p[2] = means3D[3 * i + 2];
+    in.opac = opacities[i];
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) in.S6[k] = cov3D_precomp[6 * i + k];
+    } else {
+      float s_in[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+      float q_in[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+      cov3d_from_scale_rot(s_in, cm.mod, q_in, in.S6);
     }
+    in.c_in[0] = in.c_in[1] = in.c_in[2] = 0.f;
+    if (colors_precomp) { in.c_in[0] = colors_precomp[3 * i]; in.c_in[1] = colors_precomp[3 * i + 1]; in.c_in[2] = colors_precomp[3 * i + 2]; }
+    else if (cm.deg == 0) { in.c_in[0] = shs[(size_t)i * cm.M * 3]; in.c_in[1] = shs[(size_t)i * cm.M * 3 + 1]; in.c_in[2] = shs[(size_t)i * cm.M * 3 + 2]; }
   }
-  uint32_t tot_t, tot_v;
-  uint32_t ex = block256_exclusive_scan(cnt, red, tot_t);
-  (void)block256_exclusive_scan(o.visible ? 1u : 0u, red, tot_v);
-  if (i < N) ((uint32_t*)(saved + L.o_offsets))[i] = ex;
-  if (threadIdx.x == 0) {
-    ((uint32_t*)(saved + L.o_block_touched))[blockIdx.x] = tot_t;
-    ((uint32_t*)(saved + L.o_block_vis))[blockIdx.x] = tot_v;
+  {
+    const int v = blockIdx.y;
+    (void)nviews;
+    char* saved = tab.saved[v];
+    PreOut o;
+    o.visible = false;
+    o.x0 = o.x1 = o.y0 = o.y1 = 0;
+    if (in_range) {
+      float vm[16], pm[16];
+      load16(tab.viewmatrix[v], vm);
+      load16(tab.projmatrix[v], pm);
+      preprocess_view(in, i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, vm, pm, tab.campos[v], shs,
+                      colors_precomp != nullptr, L.gx, L.gy, L.sgx, L.sgy, o);
+    }
+    uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
+    if (in_range) {
+      tab.radii[v][i] = o.visible ? (int32_t)o.rad : 0;
+      tab.n_touched[v][i] = 0;
+      ((uint32_t*)(saved + L.o_touched))[i] = cnt;
+      if (o.visible) {
+        ((float2*)(saved + L.o_xy))[i] = make_float2(o.px, o.py);
+        ((float4*)(saved + L.o_conic_o))[i] = make_float4(o.A, o.B, o.C, o.opac);
+        ((float4*)(saved + L.o_rgbd))[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+        ((ushort4*)(saved + L.o_rect))[i] =
+            make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
+        ((uint8_t*)(saved + L.o_clamped))[i] = (uint8_t)o.clamped;
+        uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
+        for (int y = o.y0; y < o.y1; ++y)
+          for (int x = o.x0; x < o.x1; ++x) atomicAdd(&tile_count[y * L.gx + x], 1u);
+      }
+    }
+    uint32_t tot_t, tot_v;
+    uint32_t ex = block256_exclusive_scan(cnt, red, tot_t);
+    uint32_t exv = block256_exclusive_scan(o.visible ? 1u : 0u, red, tot_v);
+    if (in_range) {
+      ((uint32_t*)(saved + L.o_offsets))[i] = ex;              // relative; abs_offset() adds the block base
+      if (o.visible) ((uint32_t*)(saved + L.o_vis_pos))[i] = exv;   // relative; scatter_kernel makes it absolute
+    }
+    if (threadIdx.x == 0) {
+      ((uint32_t*)(saved + L.o_block_touched))[blockIdx.x] = tot_t;
+      ((uint32_t*)(saved + L.o_block_vis))[blockIdx.x] = tot_v;
+    }
   }
 }
 
@@ -286,7 +296,7 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
     const float* __restrict__ projmatrix, const float* __restrict__ projraw, const float* __restrict__ campos,
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ touched, const uint8_t* __restrict__ clamped_in,
+    uint32_t slot0, const uint32_t* __restrict__ touched, const uint8_t* __restrict__ clamped_in,
     const float4* __restrict__ partials, int64_t cap, float* __restrict__ dshs, int sh_accumulate, GaussGrad& acc,
     float tau[6]) {
   float g_m2[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_rgb[3] = {0.f, 0.f, 0.f}, g_dep = 0.f;
@@ -298,7 +308,7 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
   float* dcolors = nullptr;   // precomputed-colour gradient is returned through acc.rgb_or_sh0
   {
     // fixed-order gather of this Gaussian's per-tile partials: deterministic, no atomics
-    uint32_t off = offsets[i], cnt = touched[i];
+    uint32_t off = slot0, cnt = touched[i];
     for (uint32_t k = 0; k < cnt; ++k) {
       uint64_t e = (uint64_t)off + k;
       if ((int64_t)e >= cap) break;
@@ -511,7 +521,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_dense_kernel(
     ViewTab tab, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, float* __restrict__ dshs, float* __restrict__ dcov3D, int accumulate) {
-  __shared__ float red[4][6];
   const int v = blockIdx.y;
   const char* saved = tab.saved[v];
   const int V = (int)((const SavedHeader*)(saved + L.o_hdr))->num_visible;
@@ -531,7 +540,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_dense_kernel(
     acc.op = 0.f; acc.m2[0] = 0.f; acc.m2[1] = 0.f;
     preprocess_bwd_one_view(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, tab.viewmatrix[v], tab.projmatrix[v],
                             cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                            (const uint32_t*)(saved + L.o_offsets), (const uint32_t*)(saved + L.o_touched),
+                            abs_offset(saved, L, (uint32_t)i), (const uint32_t*)(saved + L.o_touched),
                             (const uint8_t*)(saved + L.o_clamped), (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
                             dshs, accumulate, acc, tau);
     float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)t * 4;
@@ -544,18 +553,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_dense_kernel(
       for (int k = 0; k < 6; ++k) { if (accumulate) dcov3D[6 * i + k] += acc.S6[k]; else dcov3D[6 * i + k] = acc.S6[k]; }
     }
   }
-  if (tab.dL_dtau[v]) {      // uniform: pose gradient of this view requested
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (tab.dL_dtau[v] && live) {      // pose gradient requested: keep this Gaussian's 6 terms for the ordered reduction
+    float* tr = (float*)(tab.scratch[v] + L.o_taurec) + (size_t)t * 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      float s = wave_sum(tau[k]);
-      if (lane == 0) red[wv][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-      int k = threadIdx.x;
-      ((float*)(tab.scratch[v] + L.o_tau_part))[(size_t)blockIdx.x * 6 + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
-    }
+    for (int k = 0; k < 6; ++k) tr[k] = tau[k];
   }
 }
 
@@ -566,27 +567,46 @@ __global__ void __launch_bounds__(256) grad_gather_kernel(
     float* __restrict__ dmeans2D, float* __restrict__ dopac, float* __restrict__ dshs, float* __restrict__ dcolors,
     float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D, int accumulate,
     float* __restrict__ stat_accum, float* __restrict__ stat_denom, float* __restrict__ stat_maxr) {
+  __shared__ float red[4][6];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L.N) return;
+  const bool in_range = i < L.N;
   float a[14];
 #pragma unroll
   for (int k = 0; k < 14; ++k) a[k] = 0.f;
   float m2x = 0.f, m2y = 0.f, st_norm = 0.f, st_cnt = 0.f, st_maxr = 0.f;
   bool any = false;
   for (int v = 0; v < nviews; ++v) {
-    const int r = tab.radii[v][i];
-    if (r <= 0) continue;
-    any = true;
-    const uint32_t pos = ((const uint32_t*)(tab.saved[v] + L.o_vis_pos))[i];
-    const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)pos * 4;
-    float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-    a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
-    a[8] += r2.x; a[9] += r2.y; a[10] += r2.z; a[11] += r2.w; a[12] += r3.x; a[13] += r3.y;
-    m2x += r3.z; m2y += r3.w;
-    st_norm += sqrtf(r3.z * r3.z + r3.w * r3.w);
-    st_cnt += 1.f;
-    st_maxr = fmaxf(st_maxr, (float)r);
+    const int r = in_range ? tab.radii[v][i] : 0;
+    uint32_t pos = 0;
+    if (r > 0) {
+      any = true;
+      pos = ((const uint32_t*)(tab.saved[v] + L.o_vis_pos))[i];
+      const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)pos * 4;
+      float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+      a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
+      a[8] += r2.x; a[9] += r2.y; a[10] += r2.z; a[11] += r2.w; a[12] += r3.x; a[13] += r3.y;
+      m2x += r3.z; m2y += r3.w;
+      st_norm += sqrtf(r3.z * r3.z + r3.w * r3.w);
+      st_cnt += 1.f;
+      st_maxr = fmaxf(st_maxr, (float)r);
+    }
+    if (tab.dL_dtau[v]) {      // uniform: ordered (by Gaussian index) reduction of this view's pose gradient
+      const float* tr = (const float*)(tab.scratch[v] + L.o_taurec) + (size_t)pos * 6;
+      int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        float s = wave_sum(r > 0 ? tr[k] : 0.f);
+        if (lane == 0) red[wv][k] = s;
+      }
+      __syncthreads();
+      if (threadIdx.x < 6) {
+        int k = threadIdx.x;
+        ((float*)(tab.scratch[v] + L.o_tau_part))[(size_t)blockIdx.x * 6 + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+      }
+      __syncthreads();
+    }
   }
+  if (!in_range) return;
   float* sh0 = has_colors ? dcolors : dshs;
   const size_t sh_stride = has_colors ? 3 : (size_t)M * 3;
   if (accumulate) {
@@ -628,7 +648,7 @@ __global__ void __launch_bounds__(384) tau_reduce_kernel(ViewTab tab, LOff L) {
   float* dtau = tab.dL_dtau[v];
   if (!dtau) return;
   const float* tau_part = (const float*)(tab.scratch[v] + L.o_tau_part);
-  const int nblk = ((int)((const SavedHeader*)(tab.saved[v] + L.o_hdr))->num_visible + 255) / 256;
+  const int nblk = L.pre_blocks;
   int k = threadIdx.x / 64, lane = threadIdx.x & 63;
   float acc = 0.f;
   for (int b = lane; b < nblk; b += 64) acc += tau_part[(size_t)b * 6 + k];
@@ -644,7 +664,7 @@ __global__ void __launch_bounds__(384) tau_reduce_kernel(ViewTab tab, LOff L) {
 void launch_preprocess_fwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_FWD, st);
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.opacities,
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
                      in.shs, in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp);
 }
 
