@@ -15,7 +15,7 @@ void launch_preprocess_fwd(const ViewTab&, int, const LOff&, const Common&, cons
 void launch_preprocess_bwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, const SgrGradInputs&, hipStream_t);
 void launch_binning(const ViewTab&, int, const LOff&, hipStream_t);
 void launch_zero_heads(const ViewTab&, int, const LOff&, size_t, hipStream_t);
-void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, hipStream_t);
+void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
 void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, hipStream_t);
 
 static thread_local char g_err[512] = "";
@@ -171,7 +171,7 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
     *num_rendered_host = R;
     if ((int64_t)R > L.cap) return set_error(SGR_ERR_CAPACITY, "%u (tile, Gaussian) pairs exceed capacity %lld", R, (long long)L.cap);
   }
-  launch_blend_fwd(tab, 1, L.dev(), s->bg, st);          // K4: per-tile sort + compositing
+  launch_blend_fwd(tab, 1, L.dev(), s->bg, nullptr, nullptr, st);          // K4: per-tile sort + compositing
   HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
@@ -260,8 +260,10 @@ int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* i
         return set_error(SGR_ERR_INVALID, "map_views: null output pointer");
       tab_set_view(tab, v, &m.settings, &m.out, &m.ws);
       if (!forward_only) {
-        if (!m.gt_image || !m.gt_depth || !m.dL_dimage || !m.dL_ddepth || !m.loss_scratch || m.loss_scratch_bytes < 1024 * 16)
-          return set_error(SGR_ERR_INVALID, "map_views: loss buffers missing");
+        if (!m.gt_image || !m.gt_depth || !m.dL_dimage || !m.dL_ddepth || !m.loss_scratch ||
+            m.loss_scratch_bytes < (size_t)L.ntiles * sizeof(LossPart))
+          return set_error(SGR_ERR_INVALID, "map_views: loss buffers missing (loss_scratch needs 16 B per 8x8 tile = %zu)",
+                           (size_t)L.ntiles * sizeof(LossPart));
         tab.dL_dcolor[v] = m.dL_dimage; tab.dL_ddepth[v] = m.dL_ddepth; tab.dL_dtau[v] = m.dL_dtau;
         lt.image[v] = m.out.color; lt.depth[v] = m.out.depth; lt.gt_image[v] = m.gt_image; lt.gt_depth[v] = m.gt_depth;
         lt.exp_a[v] = m.exposure_a; lt.exp_b[v] = m.exposure_b; lt.loss[v] = m.loss; lt.dimage[v] = m.dL_dimage;
@@ -270,9 +272,15 @@ int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* i
       }
     }
     if (int rc = forward_batch(tab, nv, L, cm, *in, st)) return rc;
-    launch_blend_fwd(tab, nv, d, f.settings.bg, st);
-    if (forward_only) continue;
-    launch_mapping_loss(lt, nv, HW, alpha, rgb_boundary_threshold, 1.0f, st);
+    if (forward_only) {
+      launch_blend_fwd(tab, nv, d, f.settings.bg, nullptr, nullptr, st);
+      continue;
+    }
+    // the mapping loss rides in the compositing epilogue (no second pass over the images); only its tiny fixed-order
+    // reduction is a separate launch
+    LossCoef lc = {alpha / (3.f * (float)HW), (1.f - alpha) / (float)HW, rgb_boundary_threshold};
+    launch_blend_fwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
+    launch_mapping_loss_final(lt, nv, HW, L.ntiles, alpha, st);
     launch_blend_bwd(tab, nv, d, f.settings.bg, st);
     launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, st);
   }

@@ -12,7 +12,6 @@ namespace sgr {
 int set_error(int code, const char* fmt, ...);
 
 // ------------------------------------------------------------------------------------------------ mapping loss
-struct LossPart { float rgb, dep, da, db; };
 
 __global__ void __launch_bounds__(256) mapping_loss_kernel(LossTab tab, int HW, float w_rgb, float w_dep, float thr) {
   const int vw = blockIdx.y;
@@ -61,18 +60,25 @@ __global__ void __launch_bounds__(256) mapping_loss_kernel(LossTab tab, int HW, 
   }
 }
 
-__global__ void mapping_loss_final_kernel(LossTab tab, int nparts, float inv_rgb, float inv_dep, float alpha) {
-  __shared__ LossPart red[64];
+// second stage: one 256-thread block per view adds the partials in a fixed order (thread-strided, then DPP + LDS)
+__global__ void __launch_bounds__(256) mapping_loss_final_kernel(LossTab tab, int nparts, float inv_rgb, float inv_dep, float alpha) {
+  __shared__ LossPart red[4];
   const int vw = blockIdx.x;
   const LossPart* __restrict__ parts = (const LossPart*)tab.parts[vw];
-  int lane = threadIdx.x;
   LossPart t = {0.f, 0.f, 0.f, 0.f};
-  for (int i = lane; i < nparts; i += 64) { t.rgb += parts[i].rgb; t.dep += parts[i].dep; t.da += parts[i].da; t.db += parts[i].db; }
-  red[lane] = t;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    LossPart p = parts[i];
+    t.rgb += p.rgb; t.dep += p.dep; t.da += p.da; t.db += p.db;
+  }
+  float v[4] = {t.rgb, t.dep, t.da, t.db};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) red[wv] = {v[0], v[1], v[2], v[3]};
   __syncthreads();
-  if (lane == 0) {
-    LossPart s = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < 64; ++i) { s.rgb += red[i].rgb; s.dep += red[i].dep; s.da += red[i].da; s.db += red[i].db; }
+  if (threadIdx.x == 0) {
+    LossPart s = red[0];
+    for (int w = 1; w < 4; ++w) { s.rgb += red[w].rgb; s.dep += red[w].dep; s.da += red[w].da; s.db += red[w].db; }
     if (tab.loss[vw]) tab.loss[vw][0] = alpha * (s.rgb * inv_rgb) + (1.f - alpha) * (s.dep * inv_dep);
     if (tab.da[vw]) tab.da[vw][0] = s.da;
     if (tab.db[vw]) tab.db[vw][0] = s.db;
@@ -84,12 +90,17 @@ static int loss_blocks(int HW) {
   return blocks > 1024 ? 1024 : blocks;
 }
 
+void launch_mapping_loss_final(const LossTab& tab, int nviews, int HW, int nparts, float alpha, hipStream_t st) {
+  float inv_rgb = 1.f / (3.f * (float)HW), inv_dep = 1.f / (float)HW;
+  hipLaunchKernelGGL(mapping_loss_final_kernel, dim3(nviews), dim3(256), 0, st, tab, nparts, inv_rgb, inv_dep, alpha);
+}
+
 void launch_mapping_loss(const LossTab& tab, int nviews, int HW, float alpha, float thr, float upstream, hipStream_t st) {
   int blocks = loss_blocks(HW);
   float inv_rgb = 1.f / (3.f * (float)HW), inv_dep = 1.f / (float)HW;
   hipLaunchKernelGGL(mapping_loss_kernel, dim3(blocks, nviews), dim3(256), 0, st, tab, HW, upstream * alpha * inv_rgb,
                      upstream * (1.f - alpha) * inv_dep, thr);
-  hipLaunchKernelGGL(mapping_loss_final_kernel, dim3(nviews), dim3(64), 0, st, tab, blocks, inv_rgb, inv_dep, alpha);
+  hipLaunchKernelGGL(mapping_loss_final_kernel, dim3(nviews), dim3(256), 0, st, tab, blocks, inv_rgb, inv_dep, alpha);
 }
 
 // ------------------------------------------------------------------------------------------------ Adam

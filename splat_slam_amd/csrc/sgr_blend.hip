@@ -80,7 +80,8 @@ __device__ __forceinline__ void wave_sort_any(int n, int lane, LD load, ST store
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int SORT_MAX>
-__global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg) {
+__global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
+                                                        LossCoef lc) {
   const int vw = blockIdx.y;
   char* saved = tab.saved[vw];
   const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
@@ -194,15 +195,45 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
   if (lane == 0) tile_maxc[tile] = mx;
 
+  float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;
+  const float* __restrict__ gt_image = lt.gt_image[vw];
   if (inside) {
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
     final_T[pix] = T;
     n_contrib[pix] = last;
-    out_color[pix] = C0 + T * bg[0];
-    out_color[hw + pix] = C1 + T * bg[1];
-    out_color[2 * hw + pix] = C2 + T * bg[2];
+    const float I[3] = {C0 + T * bg[0], C1 + T * bg[1], C2 + T * bg[2]};
+    out_color[pix] = I[0];
+    out_color[hw + pix] = I[1];
+    out_color[2 * hw + pix] = I[2];
     out_depth[pix] = D;
     out_opacity[pix] = 1.f - T;
+    if (gt_image) {
+      // fused mapping loss (slam_utils.py:71-105): this pixel's residuals, the gradients the backward consumes, and
+      // its share of the four sums (|rgb|, |depth|, d/da, d/db)
+      const float ea = lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f;
+      const float eb = lt.exp_b[vw] ? lt.exp_b[vw][0] : 0.f;
+      const float g[3] = {gt_image[pix], gt_image[hw + pix], gt_image[2 * hw + pix]};
+      const bool m = (g[0] + g[1] + g[2]) > lc.thr;
+      float* __restrict__ dimage = lt.dimage[vw];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float r = m ? (ea * I[c] + eb) - g[c] : 0.f;
+        l_rgb += fabsf(r);
+        float sgn = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+        float dab = lc.w_rgb * sgn;
+        dimage[c * hw + pix] = dab * ea;
+        l_da += dab * ea * I[c];
+        l_db += dab;
+      }
+      const float gd = lt.gt_depth[vw][pix];
+      const float rd = (gd > 0.01f) ? D - gd : 0.f;
+      l_dep = fabsf(rd);
+      lt.ddepth[vw][pix] = lc.w_dep * ((rd > 0.f) ? 1.f : ((rd < 0.f) ? -1.f : 0.f));
+    }
+  }
+  if (gt_image) {      // uniform per view
+    l_rgb = wave_sum(l_rgb); l_dep = wave_sum(l_dep); l_da = wave_sum(l_da); l_db = wave_sum(l_db);
+    if (lane == 0) ((LossPart*)lt.parts[vw])[tile] = {l_rgb, l_dep, l_da, l_db};
   }
 }
 
@@ -414,7 +445,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
 }
 
 template <int SORT_MAX>
-static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, const float* bg, hipStream_t st) {
+static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab& lt,
+                               const LossCoef& lc, hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
   constexpr size_t lds = 4 * (size_t)(SORT_MAX * 8 + kWave * 48);
@@ -423,15 +455,22 @@ static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, co
     (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(blend_fwd_kernel<SORT_MAX>, dim3(grid, nviews), dim3(256), lds, st, tab, L, bg);
+  hipLaunchKernelGGL(blend_fwd_kernel<SORT_MAX>, dim3(grid, nviews), dim3(256), lds, st, tab, L, bg, lt, lc);
 }
 
-void launch_blend_fwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, hipStream_t st) {
+// lt: per-view loss pointers (gt_image[v] == NULL -> plain render).  With a loss, every 8x8 tile also leaves one
+// LossPart in lt.parts[v][tile]; launch_mapping_loss_final adds them up in fixed order.
+void launch_blend_fwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab* lt, const LossCoef* lc,
+                      hipStream_t st) {
   ProfScope prof(PK_BLEND_FWD, st);
+  LossTab none = {};
+  LossCoef nocoef = {0.f, 0.f, 0.f};
+  const LossTab& t = lt ? *lt : none;
+  const LossCoef& c = lc ? *lc : nocoef;
   // the caller sizes `capacity` at ~2x the pair count it has seen: capacity / tiles / 2 estimates the mean list length
   const int64_t mean_len = L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
-  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy>(tab, nviews, L, bg, st);
-  else launch_blend_fwd_t<kSortLight>(tab, nviews, L, bg, st);
+  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy>(tab, nviews, L, bg, t, c, st);
+  else launch_blend_fwd_t<kSortLight>(tab, nviews, L, bg, t, c, st);
 }
 
 void launch_blend_bwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, hipStream_t st) {

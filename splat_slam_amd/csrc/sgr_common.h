@@ -167,6 +167,10 @@ struct LossTab {
   void* parts[kMaxViews];
 };
 void launch_mapping_loss(const LossTab& tab, int nviews, int HW, float alpha, float thr, float upstream, hipStream_t st);
+// second stage only: `nparts` partial sums per view were already written (by blend_fwd's fused loss epilogue)
+void launch_mapping_loss_final(const LossTab& tab, int nviews, int HW, int nparts, float alpha, hipStream_t st);
+struct LossPart { float rgb, dep, da, db; };
+struct LossCoef { float w_rgb, w_dep, thr; };
 
 // ---- optional per-kernel event timing (sgr_profile_enable / sgr_profile_read)
 enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_SCATTER, PK_UNUSED3, PK_UNUSED4, PK_BLEND_FWD, PK_UNUSED6, PK_BLEND_BWD, PK_PRE_BWD };

@@ -42,7 +42,8 @@ class _ViewBuffers:
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.d_exp = torch.zeros(2, dtype=torch.float32, device=dev)
         self.d_tau = torch.zeros(6, dtype=torch.float32, device=dev)
-        self.loss_scratch = torch.empty(1024 * 16, dtype=torch.uint8, device=dev)
+        ntiles = ((H + 7) // 8) * ((W + 7) // 8)
+        self.loss_scratch = torch.empty(max(1024, ntiles) * 16, dtype=torch.uint8, device=dev)   # one LossPart per 8x8 tile
         self.saved = None
         self.scratch = None
         self.pairs = -1            # (tile, Gaussian) pairs seen by the probe render; -1 = not probed at this map size
