@@ -383,6 +383,14 @@ class FusedMappingLoop(MappingLoop):
     def _adam(self, iso_weight, skip=()):
         self._step([], iso_weight=iso_weight, adam=True, skip=skip, activate=False)
 
+    def render_forward(self, viewpoint):
+        """Forward-only render used for keyframe selection (mapper.py:972-978): buffers of the camera, no autograd."""
+        self._ensure_state()
+        self._step([viewpoint], adam=False, forward_only=True)
+        vb = self._views[viewpoint.uid]
+        return {"render": vb.color, "depth": vb.depth, "opacity": vb.opacity, "radii": vb.radii, "n_touched": vb.n_touched,
+                "visibility_filter": vb.radii > 0}
+
     # ---- exposure (keyframe) optimiser: slab-resident parameters + one masked Adam launch
     def build_keyframe_optimizers(self):
         """mapper.py:1067-1111.  Exposure parameters live in a device slab (Camera.exposure_a/b are views of their

@@ -71,6 +71,11 @@ class MappingLoop:
         self.keyframe_optimizers = None
         self.gaussians.prune_points(self.gaussians.unique_kfIDs >= 0)
 
+    @torch.no_grad()
+    def render_forward(self, viewpoint):
+        """Forward-only render used for keyframe selection (mapper.py:972-978)."""
+        return render(viewpoint, self.gaussians, self.pipeline_params, self.background)
+
     def build_keyframe_optimizers(self):
         """mapper.py:1067-1111."""
         opt_params = []

@@ -13,13 +13,14 @@ from splat_slam_amd.gaussian_model import GaussianModel, OptParams, RGB2SH
 DEFAULT_CONFIG = {
     "mapping": {
         "BA": False, "pcd_downsample": 32, "pcd_downsample_init": 16, "adaptive_pointsize": True, "point_size": 0.05,
-        "final_refine_iters": 26000,
+        "final_refine_iters": 26000, "move_points": True,
         "Training": {"ssim_loss": False, "gt_camera": False, "alpha": 0.80, "init_itr_num": 1050,
                      "init_gaussian_update": 100, "init_gaussian_reset": 500, "init_gaussian_th": 0.005,
                      "init_gaussian_extent": 30, "mapping_itr_num": 60, "gaussian_update_every": 150,
                      "gaussian_update_offset": 50, "gaussian_th": 0.7, "gaussian_extent": 1.0, "gaussian_reset": 2001,
                      "size_threshold": 20, "window_size": 10, "pose_window": 5, "edge_threshold": 4,
-                     "rgb_boundary_threshold": 0.01, "spherical_harmonics": False,
+                     "rgb_boundary_threshold": 0.01, "kf_translation": 0.04, "kf_min_translation": 0.02,
+                     "kf_overlap": 0.95, "prune_mode": "slam", "spherical_harmonics": False,
                      "lr": {"cam_rot_delta": 0.003, "cam_trans_delta": 0.001}},
         "opt_params": {"position_lr_init": 0.00016, "position_lr_final": 0.0000016, "position_lr_delay_mult": 0.01,
                        "position_lr_max_steps": 30000, "feature_lr": 0.0025, "opacity_lr": 0.05, "scaling_lr": 0.001,
@@ -134,3 +135,28 @@ def make_views(params, K, intr, device, seed=43, perturb=True, config=None):
         cam.depth = pkg["depth"][0].contiguous()
         cams.append(cam)
     return cams
+
+
+@torch.no_grad()
+def keyframe_stream(num_frames, intr, device, n_world=60000, seed=43, sweep_deg=80.0):
+    """Mapping-only feed: (video_idx, frame_idx, color[3,H,W], depth[H,W], w2c[4,4]) for `num_frames` cameras sweeping
+    `sweep_deg` of the orbit, observed from a dense, opaque ground-truth version of the room.  Stands in for the tracker
+    messages + DepthVideo.get_depth_and_pose + frame_reader; poses are exact, depth is the rendered one."""
+    from splat_slam_amd.mapper import PipelineParams
+    from splat_slam_amd.renderer import render
+    world = room_parameters(n_world, seed=seed, device=device)
+    world["scaling"] = world["scaling"] * 0 + world["scaling"].mean(dim=1, keepdim=True) + 1.6    # opaque surface splats
+    world["opacity"] = torch.full_like(world["opacity"], 4.0)
+    gm = model_from_parameters(world, device=device, knn_fn=lambda p: torch.ones(p.shape[0], device=p.device))
+    bg = torch.zeros(3, device=device)
+    H, W = intr["H"], intr["W"]
+    K = int(round(360.0 / sweep_deg * max(1, num_frames - 1))) if num_frames > 1 else 1
+    out = []
+    for k in range(num_frames):
+        w2c = orbit_w2c(k, max(K, 1))
+        cam = make_camera(k, w2c, intr, torch.zeros(3, H, W, device=device), torch.zeros(H, W, device=device), device)
+        pkg = render(cam, gm, PipelineParams(), bg)
+        opa = pkg["opacity"][0]
+        depth = torch.where(opa > 0.5, pkg["depth"][0] / opa.clamp_min(1e-6), torch.zeros_like(opa))
+        out.append((k, k, pkg["render"].clamp(0, 1).contiguous(), depth.contiguous(), w2c))
+    return out
