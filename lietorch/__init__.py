@@ -9,7 +9,7 @@ import torch
 
 from splat_slam_amd import _native as nat
 
-__all__ = ["SE3"]
+__all__ = ["SE3", "Sim3"]
 
 
 def _call(fn_name, n, *tensors_then_out):
@@ -105,3 +105,7 @@ class SE3:
 
     def __getitem__(self, idx):
         return SE3(self.data[idx])
+
+
+class Sim3:
+    """Placeholder: the reference only does `isinstance(x, Sim3)` (thirdparty/glorie_slam/geom/projective_ops.py:98)."""
