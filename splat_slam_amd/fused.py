@@ -209,6 +209,10 @@ class FusedMappingLoop(MappingLoop):
         out = nat.SgrOutputs(vb.color.data_ptr(), vb.depth.data_ptr(), vb.opacity.data_ptr(), vb.radii.data_ptr(),
                              vb.n_touched.data_ptr())
         inp = self._inputs()
+        a = self._acc          # the probe runs before the step's own activation: activate now (idempotent)
+        nat.check(self.lib.sgr_activate(N, gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
+                                        a["act_scale"].data_ptr(), a["act_rot"].data_ptr(), a["act_opac"].data_ptr(),
+                                        self._stream()), "sgr_activate")
         cap, R = max(self._cap, 1 << 16), C.c_int64(0)
         while True:
             ws = self._workspace(vb, N, H, W, cap)

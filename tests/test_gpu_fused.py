@@ -181,3 +181,19 @@ def test_view_parallel_ranks_stay_bitwise_identical_and_match_single_process():
     for k, step in lr.items():
         d = (out[0][k] - getattr(f.gaussians, k).detach().cpu()).abs()
         assert (d > 0.02 * step).float().mean().item() < 0.01, k
+
+
+def test_probe_render_sees_activated_parameters_and_sizes_capacity():
+    """Regression: the capacity probe of a camera runs before the step's own activation pass."""
+    from splat_slam_amd.fused import FusedMappingLoop
+    from splat_slam_amd.mapper import MappingLoop
+    syn, params, cams = _scene(n=6000, views=2, seed=3)
+    f = _loop(FusedMappingLoop, syn, params, cams, [0, 1])
+    a = _loop(MappingLoop, syn, params, cams, [0, 1])
+    pf = f.render_forward(cams[0])
+    pa = a.render_forward(cams[0])
+    torch.cuda.synchronize()
+    assert f._views[0].pairs > 0 and f._cap >= 2 * f._views[0].pairs
+    assert torch.equal(pf["radii"], pa["radii"])
+    assert torch.allclose(pf["render"], pa["render"], atol=1e-5)
+    assert torch.equal(pf["n_touched"], pa["n_touched"])
