@@ -206,6 +206,76 @@ class GaussianModel:
                 param_group["lr"] = lr
                 return lr
 
+    # ---- PLY checkpoint (gaussian_model.py:331-380, 397-486): one all-float32 `vertex` element, binary little endian,
+    # property order x y z nx ny nz f_dc_* f_rest_* opacity scale_* rot_*  (what plyfile writes for that dtype list)
+    def construct_list_of_attributes(self):
+        l = ["x", "y", "z", "nx", "ny", "nz"]
+        for i in range(self._features_dc.shape[1] * self._features_dc.shape[2]):
+            l.append("f_dc_{}".format(i))
+        for i in range(self._features_rest.shape[1] * self._features_rest.shape[2]):
+            l.append("f_rest_{}".format(i))
+        l.append("opacity")
+        for i in range(self._scaling.shape[1]):
+            l.append("scale_{}".format(i))
+        for i in range(self._rotation.shape[1]):
+            l.append("rot_{}".format(i))
+        return l
+
+    def save_ply(self, path):
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        xyz = self._xyz.detach().cpu().numpy()
+        f_dc = self._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
+        f_rest = self._features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
+        attributes = np.concatenate((xyz, np.zeros_like(xyz), f_dc, f_rest, self._opacity.detach().cpu().numpy(),
+                                     self._scaling.detach().cpu().numpy(), self._rotation.detach().cpu().numpy()), axis=1)
+        names = self.construct_list_of_attributes()
+        assert attributes.shape[1] == len(names)
+        header = "ply\nformat binary_little_endian 1.0\nelement vertex {}\n".format(xyz.shape[0])
+        header += "".join("property float {}\n".format(n) for n in names) + "end_header\n"
+        with open(path, "wb") as f:
+            f.write(header.encode("ascii"))
+            f.write(np.ascontiguousarray(attributes, dtype="<f4").tobytes())
+
+    def load_ply(self, path):
+        with open(path, "rb") as f:
+            names, n, fmt = [], 0, None
+            line = f.readline().decode("ascii").strip()
+            assert line == "ply", "not a PLY file"
+            while True:
+                line = f.readline().decode("ascii").strip()
+                if line.startswith("format"):
+                    fmt = line.split()[1]
+                elif line.startswith("element vertex"):
+                    n = int(line.split()[-1])
+                elif line.startswith("property"):
+                    assert line.split()[1] in ("float", "float32"), "only all-float vertex elements are supported"
+                    names.append(line.split()[-1])
+                elif line == "end_header":
+                    break
+            assert fmt == "binary_little_endian", "only binary_little_endian PLY is supported"
+            data = np.frombuffer(f.read(n * len(names) * 4), dtype="<f4").reshape(n, len(names))
+        col = {name: data[:, i] for i, name in enumerate(names)}
+        xyz = np.stack((col["x"], col["y"], col["z"]), axis=1)
+        features_dc = np.stack((col["f_dc_0"], col["f_dc_1"], col["f_dc_2"]), axis=1)[:, :, None]
+        extra = sorted([k for k in names if k.startswith("f_rest_")], key=lambda x: int(x.split("_")[-1]))
+        assert len(extra) == 3 * (self.max_sh_degree + 1) ** 2 - 3
+        features_extra = np.stack([col[k] for k in extra], axis=1).reshape(n, 3, (self.max_sh_degree + 1) ** 2 - 1) \
+            if extra else np.zeros((n, 3, 0), dtype=np.float32)
+        scale_names = sorted([k for k in names if k.startswith("scale_")], key=lambda x: int(x.split("_")[-1]))
+        rot_names = sorted([k for k in names if k.startswith("rot")], key=lambda x: int(x.split("_")[-1]))
+        T = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float, device=self.device)
+        self._xyz = nn.Parameter(T(xyz).requires_grad_(True))
+        self._features_dc = nn.Parameter(T(features_dc).transpose(1, 2).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(T(features_extra).transpose(1, 2).contiguous().requires_grad_(True))
+        self._opacity = nn.Parameter(T(col["opacity"][:, None]).requires_grad_(True))
+        self._scaling = nn.Parameter(T(np.stack([col[k] for k in scale_names], axis=1)).requires_grad_(True))
+        self._rotation = nn.Parameter(T(np.stack([col[k] for k in rot_names], axis=1)).requires_grad_(True))
+        self.active_sh_degree = self.max_sh_degree
+        self.max_radii2D = torch.zeros((n), device=self.device)
+        self.unique_kfIDs = torch.zeros((n), device=self.device).int()
+        self.n_obs = torch.zeros((n), device=self.device).int()
+
     # ---- opacity resets (gaussian_model.py:382-395)
     def reset_opacity(self):
         opacities_new = inverse_sigmoid(torch.ones_like(self.get_opacity) * 0.01)

@@ -1,0 +1,73 @@
+"""Host-side GaussianModel pieces that need no GPU: PLY checkpoint format, seeding from an RGB-D frame."""
+import numpy as np
+import torch
+
+from splat_slam_amd.gaussian_model import GaussianModel, OptParams
+
+
+def _model(n=37, deg=0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    gm = GaussianModel(deg, config=None, device="cpu")
+    gm.training_setup(OptParams())
+    K = (deg + 1) ** 2
+    feats = torch.randn(n, 3, K, generator=g)
+    gm.extend_from_pcd(torch.randn(n, 3, generator=g), feats, torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g),
+                       torch.randn(n, 1, generator=g), 3)
+    return gm
+
+
+def test_ply_roundtrip_and_layout(tmp_path):
+    for deg in (0, 1):
+        gm = _model(deg=deg)
+        path = str(tmp_path / f"map{deg}.ply")
+        gm.save_ply(path)
+        raw = open(path, "rb").read()
+        head, body = raw.split(b"end_header\n", 1)
+        lines = head.decode().strip().split("\n")
+        assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 37"]
+        props = [l.split()[-1] for l in lines[3:]]
+        K = (deg + 1) ** 2
+        expect = (["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(3 * (K - 1))]
+                  + ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)])
+        assert props == expect                       # gaussian_model.py:331-343
+        assert all(l.split()[1] == "float" for l in lines[3:])
+        assert len(body) == 37 * len(expect) * 4
+        arr = np.frombuffer(body, dtype="<f4").reshape(37, -1)
+        assert np.array_equal(arr[:, :3], gm._xyz.detach().numpy()) and np.all(arr[:, 3:6] == 0)
+        # f_dc / f_rest are stored channel-major (transpose(1,2).flatten), like the reference
+        assert np.array_equal(arr[:, 6:9], gm._features_dc.detach().transpose(1, 2).flatten(1).numpy())
+        other = GaussianModel(deg, device="cpu")
+        other.load_ply(path)
+        for name in ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]:
+            assert torch.equal(getattr(other, name).detach(), getattr(gm, name).detach()), name
+        assert other.active_sh_degree == deg and other.max_radii2D.shape == (37,)
+
+
+def test_seeding_from_rgbd_backprojects_valid_pixels_only():
+    cfg = {"mapping": {"pcd_downsample": 4, "pcd_downsample_init": 2, "adaptive_pointsize": True, "point_size": 0.05}}
+    gm = GaussianModel(0, config=cfg, device="cpu", knn_fn=lambda p: torch.full((p.shape[0],), 0.04))
+    gm.training_setup(OptParams())
+
+    class Cam:
+        pass
+    cam = Cam()
+    H, W = 12, 16
+    cam.fx = cam.fy = 10.0
+    cam.cx, cam.cy = 7.5, 5.5
+    cam.R, cam.T = torch.eye(3), torch.tensor([0.1, -0.2, 0.3])
+    cam.exposure_a, cam.exposure_b = torch.zeros(1), torch.zeros(1)
+    cam.original_image = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1))
+    depth = torch.full((H, W), 2.0)
+    depth[:3] = 0.0                                   # invalid rows are never seeded
+    torch.manual_seed(0)
+    gm.extend_from_pcd_seq(cam, kf_id=5, init=True, depthmap=depth)
+    n_valid = int((depth > 0).sum())
+    assert gm.get_xyz.shape[0] == n_valid // 2        # pcd_downsample_init
+    pc = gm.get_xyz.detach() @ cam.R.T + cam.T        # back in the camera frame: every point sits at z = 2 on a valid pixel
+    assert torch.allclose(pc[:, 2], torch.full((pc.shape[0],), 2.0), atol=1e-5)
+    v = pc[:, 1] * cam.fy / pc[:, 2] + cam.cy
+    assert float(v.min()) > 2.5
+    # scale = log sqrt(clamp(knn, 1e-7) * point_size), quaternion identity, opacity logit(0.5) (gaussian_model.py:194-215)
+    assert torch.allclose(gm._scaling.detach(), torch.full_like(gm._scaling, float(np.log(np.sqrt(0.04 * 0.05)))), atol=1e-6)
+    assert torch.equal(gm._rotation.detach()[:, 0], torch.ones(pc.shape[0])) and gm._rotation.detach()[:, 1:].abs().max() == 0
+    assert gm._opacity.detach().abs().max() < 1e-6 and torch.all(gm.unique_kfIDs == 5)
