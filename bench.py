@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--loop", default="fused", choices=["fused", "autograd"],
                     help="fused: autograd-free C-ABI sequence (product path); autograd: torch.autograd mirror of the reference loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--refine-iters", type=int, default=200, help="final_refine iterations timed for refine it/s (0 = skip)")
     ap.add_argument("--profile-all", action="store_true", help="event-time every kernel kind (adds overhead)")
     return ap.parse_args()
 
@@ -184,6 +185,17 @@ def main():
                                       torch.cuda.current_stream(dev).cuda_stream), "sgr_query_stats")
         per_view.append([int(x) for x in stats])
     trace("stats ok")
+    # ---- final-refinement throughput (mapper.py:656-708: ONE random view fwd+bwd + Adam on all N per iteration);
+    # measured after the counters were read because it keeps optimising the map.  Outside the headline timed region.
+    refine_its = None
+    if args.loop == "fused" and args.refine_iters > 0:
+        loop.final_refine(iters=5)
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        loop.final_refine(iters=args.refine_iters)
+        torch.cuda.synchronize()
+        refine_its = args.refine_iters / (time.perf_counter() - a)
+        trace("refine ok")
     nv = len(per_view)
     V = sum(p[0] for p in per_view) // nv
     R = sum(p[1] for p in per_view) // nv
@@ -227,6 +239,8 @@ def main():
                    "parallelism": "view-parallel x%d, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
         "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4),
         "render_ms": {"forward": round(render_fwd_ms, 4), "forward_backward_loss": round(render_fwd_bwd_ms, 4)},
+        "map_iterations_per_s": round(args.steps / elapsed, 2),
+        "refine_iterations_per_s": None if refine_its is None else round(refine_its, 1),
         "work_per_view": {"visible_gaussians": V, "tile_pairs_R": R, "tile_pairs_walked_R_eff": R_eff_sum // nv,
                           "nonempty_tiles": tiles_nonempty},
         "roofline": roofline,

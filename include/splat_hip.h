@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 2
+#define SGR_ABI_VERSION 3
 
 typedef enum SgrStatus {
   SGR_OK = 0,
@@ -254,8 +254,35 @@ typedef struct SgrMapStep {
   int32_t* exp_step;
   const int32_t* exp_active;
   float exp_lr, exp_beta1, exp_beta2, exp_eps;
+  int32_t grads_clean;         /* > 0: the gradient sinks are known to be all-zero on entry (as every Adam step leaves
+                                  them); the fused gather+Adam pass then never touches them.  0: unknown.
+                                  < 0: keep gather and Adam as separate passes (verification) */
 } SgrMapStep;
 int sgr_map_step(const SgrMapStep* step, void* stream);
+
+/* A run of `num_iters` REGULAR mapping iterations (no densification / opacity reset between them) enqueued by one host
+ * call: what `for _ in range(iters)` of Mapper.map (src/mapper.py:414-568) or Mapper.final_refine (:656-708) does
+ * between two map-surgery points.  Iteration k renders window[0..num_window) plus pool[picks[k*picks_per_iter + j]]
+ * (the reference's random keyframes, drawn by the caller so that its RNG stream is unchanged), steps Adam with
+ * adam_groups[0].lr = lr0[k] (the xyz schedule, src/mapper.py:564) and bumps every non-skipped group's step counter;
+ * `adam_groups` is updated in place so that the caller can read the counters back.
+ * pool_exp_row (optional): exposure-slab row of each pool entry (-1 = none); when given, iteration k steps only the
+ * row of its first pick (final_refine: torch's Adam skips parameters without a gradient) -- step.exp_* then point at
+ * row 0 of the slab and step.exp_active at an all-ones array. */
+typedef struct SgrMapRun {
+  SgrMapStep step;              /* template of one iteration; its views / num_views / adam_groups are ignored */
+  int32_t num_iters;
+  int32_t num_window;
+  const SgrMapView* window;
+  int32_t pool_size;
+  int32_t picks_per_iter;
+  const SgrMapView* pool;
+  const int32_t* picks;         /* host, [num_iters * picks_per_iter] */
+  const float* lr0;             /* host, [num_iters] or NULL (keep adam_groups[0].lr) */
+  SgrAdamGroup* adam_groups;    /* host, [5] or NULL */
+  const int32_t* pool_exp_row;  /* host, [pool_size] or NULL */
+} SgrMapRun;
+int sgr_map_run(const SgrMapRun* run, void* stream);
 
 /* Adam on a small slab with a per-row switch: row r (width `row_width`) is updated iff active[r] != 0, using its own
  * step counter step[r] (incremented in place).  The exposure parameters of the keyframe optimiser

@@ -65,7 +65,14 @@ class SgrMapStep(C.Structure):
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("iso_weight", C.c_float),
                 ("exp_rows", C.c_int32), ("exp_row_width", C.c_int32), ("exp_param", _fp), ("exp_grad", _fp),
                 ("exp_avg", _fp), ("exp_avg_sq", _fp), ("exp_step", _fp), ("exp_active", _fp), ("exp_lr", C.c_float),
-                ("exp_beta1", C.c_float), ("exp_beta2", C.c_float), ("exp_eps", C.c_float)]
+                ("exp_beta1", C.c_float), ("exp_beta2", C.c_float), ("exp_eps", C.c_float), ("grads_clean", C.c_int32)]
+
+
+class SgrMapRun(C.Structure):
+    _fields_ = [("step", SgrMapStep), ("num_iters", C.c_int32), ("num_window", C.c_int32), ("window", C.POINTER(SgrMapView)),
+                ("pool_size", C.c_int32), ("picks_per_iter", C.c_int32), ("pool", C.POINTER(SgrMapView)),
+                ("picks", C.POINTER(C.c_int32)), ("lr0", C.POINTER(C.c_float)), ("adam_groups", C.POINTER(SgrAdamGroup)),
+                ("pool_exp_row", C.POINTER(C.c_int32))]
 
 
 # name -> (restype, argtypes); must list every symbol include/splat_hip.h declares (tests/test_abi.py checks)
@@ -91,6 +98,7 @@ SIGNATURES = {
     "sgr_map_views": (C.c_int, [C.c_int32, C.POINTER(SgrMapView), C.POINTER(SgrInputs), C.POINTER(SgrGradInputs),
                                 C.c_float, C.c_float, C.c_int32, _fp]),
     "sgr_map_step": (C.c_int, [C.POINTER(SgrMapStep), _fp]),
+    "sgr_map_run": (C.c_int, [C.POINTER(SgrMapRun), _fp]),
     "sgr_masked_adam": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _fp]),
     "sknn_scratch_bytes": (C.c_size_t, [C.c_int32]),
@@ -120,7 +128,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.sgr_abi_version() != 2:
+        if h.sgr_abi_version() != 3:
             raise ImportError("libsplat_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -12,7 +12,8 @@
 namespace sgr {
 
 void launch_preprocess_fwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, hipStream_t);
-void launch_preprocess_bwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, const SgrGradInputs&, hipStream_t);
+void launch_preprocess_bwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, const SgrGradInputs&, const FusedAdam*,
+                           hipStream_t);
 void launch_binning(const ViewTab&, int, const LOff&, hipStream_t);
 void launch_zero_heads(const ViewTab&, int, const LOff&, size_t, hipStream_t);
 void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
@@ -199,13 +200,18 @@ int sgr_backward(const SgrSettings* s, const SgrInputs* in, const int32_t* radii
   LOff d = L.dev();
   Common cm = make_common(s);
   launch_blend_bwd(tab, 1, d, s->bg, st);
-  launch_preprocess_bwd(tab, 1, d, cm, *in, *gi, st);
+  launch_preprocess_bwd(tab, 1, d, cm, *in, *gi, nullptr, st);
   HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
 
-int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* in, const SgrGradInputs* grads, float alpha,
-                  float rgb_boundary_threshold, int32_t forward_only, void* stream) {
+}  // extern "C"
+
+// fused: optimiser tail to run inside the gather pass; *fused_done tells whether it did (uniform single-chunk batches only)
+static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrInputs* in, const SgrGradInputs* grads, float alpha,
+                          float rgb_boundary_threshold, int32_t forward_only, const FusedAdam* fused, bool* fused_done,
+                          void* stream) {
+  if (fused_done) *fused_done = false;
   if (num_views < 0 || (num_views > 0 && (!views || !in)) || (!forward_only && !grads))
     return set_error(SGR_ERR_INVALID, "map_views: null argument");
   if (num_views == 0) return SGR_OK;
@@ -282,25 +288,112 @@ int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* i
     launch_blend_fwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
     launch_mapping_loss_final(lt, nv, HW, L.ntiles, alpha, st);
     launch_blend_bwd(tab, nv, d, f.settings.bg, st);
-    launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, st);
+    const bool fuse = fused && num_views <= kMaxViews;
+    launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, fuse ? fused : nullptr, st);
+    if (fuse && fused_done) *fused_done = true;
   }
   HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
 
-int sgr_map_step(const SgrMapStep* p, void* stream) {
+extern "C" {
+
+int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* in, const SgrGradInputs* grads, float alpha,
+                  float rgb_boundary_threshold, int32_t forward_only, void* stream) {
+  return map_views_impl(num_views, views, in, grads, alpha, rgb_boundary_threshold, forward_only, nullptr, nullptr, stream);
+}
+
+}  // extern "C"
+
+// One iteration.  When the Adam step directly follows the views of a uniform single-chunk batch and the gradient sinks
+// are the optimiser's own gradient buffers, gather + Adam + next activations run as ONE pass (gather_adam_kernel).
+static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_clean, bool allow_fuse, bool* fused_out, void* stream) {
+  if (fused_out) *fused_out = false;
   if (!p) return set_error(SGR_ERR_INVALID, "map_step: null argument");
-  if (p->scaling || p->rotation || p->opacity)
+  if (!skip_activate && (p->scaling || p->rotation || p->opacity))
     if (int rc = sgr_activate(p->num_gaussians, p->scaling, p->rotation, p->opacity, p->scales_out, p->rot_out, p->opac_out, stream)) return rc;
+  FusedAdam fa;
+  bool try_fuse = false;
+  if (allow_fuse && p->adam_groups && p->num_views > 0 && p->num_views <= kMaxViews && !p->forward_only && p->grads && p->in && p->views) {
+    const SgrGradInputs& g = *p->grads;
+    const SgrAdamGroup* G = p->adam_groups;
+    try_fuse = g.accumulate && g.dL_dmeans3D == G[0].grad && g.dL_dshs == G[1].grad && g.dL_dopacities == G[2].grad &&
+               g.dL_dscales == G[3].grad && g.dL_drotations == G[4].grad && !g.dL_dmeans2D && !g.dL_dcolors_precomp &&
+               !g.dL_dcov3D_precomp && p->in->shs && !p->in->colors_precomp && p->in->scales && p->in->rotations &&
+               p->num_gaussians == p->views[0].settings.num_gaussians;
+    for (int v = 0; v < p->num_views && try_fuse; ++v)
+      try_fuse = !p->views[v].dL_dtau && p->views[v].settings.sh_degree == 0 && p->views[v].settings.sh_coeffs == 1;
+    if (try_fuse) {
+      if (int rc = make_fused_adam(p->num_gaussians, G, p->beta1, p->beta2, p->eps, p->iso_weight, &fa)) return rc;
+      fa.grads_clean = grads_clean ? 1 : 0;
+      fa.s_out = p->scales_out; fa.r_out = p->rot_out; fa.o_out = p->opac_out;
+      fa.stat_accum = g.stat_grad_accum;
+      fa.stat_denom = g.stat_grad_accum ? g.stat_denom : nullptr;
+      fa.stat_maxr = g.stat_grad_accum ? g.stat_max_radii : nullptr;
+    }
+  }
+  bool fused = false;
   if (p->num_views > 0)
-    if (int rc = sgr_map_views(p->num_views, p->views, p->in, p->grads, p->alpha, p->rgb_boundary_threshold, p->forward_only, stream))
+    if (int rc = map_views_impl(p->num_views, p->views, p->in, p->grads, p->alpha, p->rgb_boundary_threshold, p->forward_only,
+                                try_fuse ? &fa : nullptr, &fused, stream))
       return rc;
-  if (p->adam_groups)
+  if (p->adam_groups && !fused)
     if (int rc = sgr_gaussian_adam_step(p->num_gaussians, p->adam_groups, p->beta1, p->beta2, p->eps, p->iso_weight, stream)) return rc;
   if (p->exp_rows > 0)
     if (int rc = sgr_masked_adam(p->exp_rows, p->exp_row_width, p->exp_param, p->exp_grad, p->exp_avg, p->exp_avg_sq, p->exp_step,
                                  p->exp_active, p->exp_lr, p->exp_beta1, p->exp_beta2, p->exp_eps, stream))
       return rc;
+  if (fused_out) *fused_out = fused;
+  return SGR_OK;
+}
+
+extern "C" {
+
+int sgr_map_step(const SgrMapStep* p, void* stream) {
+  if (!p) return set_error(SGR_ERR_INVALID, "map_step: null argument");
+  return map_step_impl(p, false, p->grads_clean > 0, p->grads_clean >= 0, nullptr, stream);
+}
+
+int sgr_map_run(const SgrMapRun* r, void* stream) {
+  if (!r || r->num_iters < 0 || r->num_window < 0 || r->picks_per_iter < 0 || (r->num_window > 0 && !r->window) ||
+      (r->picks_per_iter > 0 && (!r->pool || !r->picks || r->pool_size <= 0)))
+    return set_error(SGR_ERR_INVALID, "map_run: bad argument");
+  const int nv = r->num_window + r->picks_per_iter;
+  if (nv > 64) return set_error(SGR_ERR_INVALID, "map_run: more than 64 views per iteration");
+  SgrMapView views[64];
+  for (int v = 0; v < r->num_window; ++v) views[v] = r->window[v];
+  SgrMapStep st = r->step;
+  st.views = views;
+  st.num_views = nv;
+  st.adam_groups = r->adam_groups;
+  const int32_t exp_rows = st.exp_rows;
+  bool prev_fused = false;
+  for (int it = 0; it < r->num_iters; ++it) {
+    for (int j = 0; j < r->picks_per_iter; ++j) {
+      const int32_t k = r->picks[(size_t)it * r->picks_per_iter + j];
+      if (k < 0 || k >= r->pool_size) return set_error(SGR_ERR_INVALID, "map_run: pick %d outside the pool", k);
+      views[r->num_window + j] = r->pool[k];
+    }
+    if (r->adam_groups) {
+      if (r->lr0) r->adam_groups[0].lr = r->lr0[it];
+      for (int g = 0; g < 5; ++g)
+        if (!r->adam_groups[g].skip) r->adam_groups[g].step += 1;
+    }
+    if (r->pool_exp_row && r->picks_per_iter > 0 && exp_rows > 0) {
+      const int32_t row = r->pool_exp_row[r->picks[(size_t)it * r->picks_per_iter]];
+      const size_t o = (size_t)(row < 0 ? 0 : row) * (size_t)st.exp_row_width;
+      st.exp_rows = row < 0 ? 0 : 1;
+      st.exp_param = r->step.exp_param + o; st.exp_grad = r->step.exp_grad + o;
+      st.exp_avg = r->step.exp_avg + o; st.exp_avg_sq = r->step.exp_avg_sq + o;
+      st.exp_step = r->step.exp_step + (row < 0 ? 0 : row);
+    }
+    // after a fused tail the activations of the updated parameters are already written and the sinks are clean
+    bool fused = false;
+    if (int rc = map_step_impl(&st, prev_fused, it == 0 ? r->step.grads_clean > 0 : r->adam_groups != nullptr, r->step.grads_clean >= 0,
+                               &fused, stream))
+      return rc;
+    prev_fused = fused;
+  }
   return SGR_OK;
 }
 

@@ -158,8 +158,6 @@ __global__ void __launch_bounds__(256) activate_kernel(int64_t n, const float* _
   if (o_out) o_out[i] = 1.f / (1.f + expf(-opacity[i]));
 }
 
-struct AdamConst { float b1, b2, eps; float bc2_sqrt[5], step_size[5]; };
-struct AdamGroups { SgrAdamGroup g[5]; };   // xyz, f_dc, opacity, scaling, rotation
 #define adam_update(p, g, m, v, GRP, c)                      \
   do {                                                       \
     m = m + (g - m) * (1.f - c.b1);                          \
@@ -168,9 +166,21 @@ struct AdamGroups { SgrAdamGroup g[5]; };   // xyz, f_dc, opacity, scaling, rota
     p = p - c.step_size[GRP] * (m / denom_);                 \
   } while (0)
 
-__global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroups G, AdamConst c, float iso_coef) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// MODE 0: gradient = sink (read, then zeroed)            -- sgr_gaussian_adam_step
+// MODE 1: gradient = sink + gathered (sink zeroed)        -- fused tail, sinks may hold earlier contributions
+// MODE 2: gradient = gathered (sinks known to be zero)    -- fused tail, steady state: the sinks are never touched
+template <int MODE>
+__device__ __forceinline__ float take_grad(float* __restrict__ sink, int64_t j, float gathered) {
+  if (MODE == 2) return gathered;
+  float g = sink[j];
+  sink[j] = 0.f;
+  return MODE == 1 ? g + gathered : g;
+}
+
+template <int MODE>
+__device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G, const AdamConst& c, float iso_coef,
+                                                  const float* e /*[14] gathered or zeros*/, float* __restrict__ s_out,
+                                                  float* __restrict__ r_out, float* __restrict__ o_out) {
   // xyz and f_dc: identity activations
 #pragma unroll
   for (int grp = 0; grp < 2; ++grp) {
@@ -178,23 +188,24 @@ __global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroup
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       int64_t j = 3 * i + k;
-      float g = A.grad[j], p = A.param[j], m = A.exp_avg[j], v = A.exp_avg_sq[j];
-      A.grad[j] = 0.f;
+      float g = take_grad<MODE>(A.grad, j, e[3 * grp + k]);
       if (A.skip) continue;
+      float p = A.param[j], m = A.exp_avg[j], v = A.exp_avg_sq[j];
       adam_update(p, g, m, v, grp, c);
       A.param[j] = p; A.exp_avg[j] = m; A.exp_avg_sq[j] = v;
     }
   }
   {   // opacity: sigmoid
     const SgrAdamGroup& A = G.g[2];
-    float p = A.param[i], m = A.exp_avg[i], v = A.exp_avg_sq[i];
+    float p = A.param[i];
     float sg = 1.f / (1.f + expf(-p));
-    float g = A.grad[i] * sg * (1.f - sg);
-    A.grad[i] = 0.f;
+    float g = take_grad<MODE>(A.grad, i, e[6]) * sg * (1.f - sg);
     if (!A.skip) {
+      float m = A.exp_avg[i], v = A.exp_avg_sq[i];
       adam_update(p, g, m, v, 2, c);
       A.param[i] = p; A.exp_avg[i] = m; A.exp_avg_sq[i] = v;
     }
+    if (MODE != 0 && o_out) o_out[i] = 1.f / (1.f + expf(-p));
   }
   {   // scaling: exp, plus d/ds of iso_weight * mean_{N,3} |s - mean_3(s)|
     const SgrAdamGroup& A = G.g[3];
@@ -208,19 +219,28 @@ __global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroup
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       int64_t j = 3 * i + k;
-      float gs = A.grad[j] + iso_coef * (sg[k] - ssum / 3.f);
+      float gs = take_grad<MODE>(A.grad, j, e[7 + k]) + iso_coef * (sg[k] - ssum / 3.f);
       float g = gs * s[k];
-      float pp = p[k], m = A.exp_avg[j], v = A.exp_avg_sq[j];
-      A.grad[j] = 0.f;
-      if (A.skip) continue;
-      adam_update(pp, g, m, v, 3, c);
-      A.param[j] = pp; A.exp_avg[j] = m; A.exp_avg_sq[j] = v;
+      if (!A.skip) {
+        float pp = p[k], m = A.exp_avg[j], v = A.exp_avg_sq[j];
+        adam_update(pp, g, m, v, 3, c);
+        A.param[j] = pp; A.exp_avg[j] = m; A.exp_avg_sq[j] = v;
+        p[k] = pp;
+      }
+      if (MODE != 0 && s_out) s_out[j] = expf(p[k]);
     }
   }
   {   // rotation: x / max(|x|, 1e-12)
     const SgrAdamGroup& A = G.g[4];
-    float4 x = *(const float4*)(A.param + 4 * i), gy = *(const float4*)(A.grad + 4 * i);
-    float4 m = *(const float4*)(A.exp_avg + 4 * i), v = *(const float4*)(A.exp_avg_sq + 4 * i);
+    float4 x = *(const float4*)(A.param + 4 * i);
+    float4 gy;
+    if (MODE == 2) {
+      gy = make_float4(e[10], e[11], e[12], e[13]);
+    } else {
+      gy = *(const float4*)(A.grad + 4 * i);
+      *(float4*)(A.grad + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == 1) { gy.x += e[10]; gy.y += e[11]; gy.z += e[12]; gy.w += e[13]; }
+    }
     float nrm = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
     float gx[4];
     if (nrm > 1e-12f) {
@@ -232,16 +252,70 @@ __global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroup
     } else {
       gx[0] = gy.x * 1e12f; gx[1] = gy.y * 1e12f; gx[2] = gy.z * 1e12f; gx[3] = gy.w * 1e12f;
     }
-    float pp[4] = {x.x, x.y, x.z, x.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
-    *(float4*)(A.grad + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pp[4] = {x.x, x.y, x.z, x.w};
     if (!A.skip) {
+      float4 m = *(const float4*)(A.exp_avg + 4 * i), v = *(const float4*)(A.exp_avg_sq + 4 * i);
+      float mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) adam_update(pp[k], gx[k], mm[k], vv[k], 4, c);
       *(float4*)(A.param + 4 * i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
       *(float4*)(A.exp_avg + 4 * i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
       *(float4*)(A.exp_avg_sq + 4 * i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
+    if (MODE != 0 && r_out) {      // same expression as activate_kernel
+      float nn = fmaxf(sqrtf(pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2] + pp[3] * pp[3]), 1e-12f);
+      *(float4*)(r_out + 4 * i) = make_float4(pp[0] / nn, pp[1] / nn, pp[2] / nn, pp[3] / nn);
+    }
   }
+}
+
+__global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroups G, AdamConst c, float iso_coef) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float zero[14] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  gaussian_adam_one<0>(i, G, c, iso_coef, zero, nullptr, nullptr, nullptr);
+}
+
+// The single-GPU tail of a mapping iteration in one pass: thread = Gaussian; adds up its gradient records over the
+// views of the batch in view order (exactly grad_gather_kernel's sum), then the Adam step of all five groups, then the
+// activations the next iteration renders with.
+template <int MODE>
+__global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nviews, LOff L, FusedAdam fa) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L.N) return;
+  float a[14];
+#pragma unroll
+  for (int k = 0; k < 14; ++k) a[k] = 0.f;
+  float st_norm = 0.f, st_cnt = 0.f, st_maxr = 0.f;
+  bool any = false;
+  for (int v = 0; v < nviews; ++v) {
+    const int r = tab.radii[v][i];
+    if (r > 0) {
+      any = true;
+      const uint32_t pos = ((const uint32_t*)(tab.saved[v] + L.o_vis_pos))[i];
+      const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)pos * 4;
+      float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+      a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
+      a[8] += r2.x; a[9] += r2.y; a[10] += r2.z; a[11] += r2.w; a[12] += r3.x; a[13] += r3.y;
+      st_norm += sqrtf(r3.z * r3.z + r3.w * r3.w);
+      st_cnt += 1.f;
+      st_maxr = fmaxf(st_maxr, (float)r);
+    }
+  }
+  if (any && fa.stat_accum) {
+    fa.stat_accum[i] += st_norm;
+    fa.stat_denom[i] += st_cnt;
+    fa.stat_maxr[i] = fmaxf(fa.stat_maxr[i], st_maxr);
+  }
+  gaussian_adam_one<MODE>(i, fa.G, fa.c, fa.iso_coef, a, fa.s_out, fa.r_out, fa.o_out);
+}
+
+void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st) {
+  if (L.N <= 0) return;
+  if (fa.grads_clean)
+    hipLaunchKernelGGL(gather_adam_kernel<2>, dim3(L.pre_blocks), dim3(256), 0, st, tab, nviews, L, fa);
+  else
+    hipLaunchKernelGGL(gather_adam_kernel<1>, dim3(L.pre_blocks), dim3(256), 0, st, tab, nviews, L, fa);
 }
 
 // ------------------------------------------------------------------------------------------------ 3-NN
@@ -427,6 +501,24 @@ static int se3_launch(int64_t n, const float* a, const float* b, float* out, voi
   return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "se3 launch failed");
 }
 
+int make_fused_adam(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight, FusedAdam* out) {
+  FusedAdam& fa = *out;
+  fa = FusedAdam{};
+  fa.c.b1 = beta1; fa.c.b2 = beta2; fa.c.eps = eps;
+  for (int k = 0; k < 5; ++k) {
+    fa.G.g[k] = groups[k];
+    const SgrAdamGroup& g = fa.G.g[k];
+    if (!g.grad || !g.param || (!g.skip && (!g.exp_avg || !g.exp_avg_sq || g.step < 1)))
+      return set_error(SGR_ERR_INVALID, "gaussian_adam: null pointer / bad step in group %d", k);
+    int64_t st = g.step < 1 ? 1 : g.step;
+    double bc1 = 1.0 - std::pow((double)beta1, (double)st), bc2 = 1.0 - std::pow((double)beta2, (double)st);
+    fa.c.bc2_sqrt[k] = (float)std::sqrt(bc2);
+    fa.c.step_size[k] = (float)((double)g.lr / bc1);
+  }
+  fa.iso_coef = iso_weight / (3.f * (float)n);
+  return SGR_OK;
+}
+
 }  // namespace sgr
 
 using namespace sgr;
@@ -478,20 +570,10 @@ int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1,
                            void* stream) {
   if (n < 0 || !groups) return set_error(SGR_ERR_INVALID, "gaussian_adam: bad argument");
   if (n == 0) return SGR_OK;
-  AdamGroups G;
-  AdamConst c;
-  c.b1 = beta1; c.b2 = beta2; c.eps = eps;
-  for (int k = 0; k < 5; ++k) {
-    G.g[k] = groups[k];
-    if (!G.g[k].grad || (!G.g[k].skip && (!G.g[k].param || !G.g[k].exp_avg || !G.g[k].exp_avg_sq || G.g[k].step < 1)))
-      return set_error(SGR_ERR_INVALID, "gaussian_adam: null pointer / bad step in group %d", k);
-    int64_t st = G.g[k].step < 1 ? 1 : G.g[k].step;
-    double bc1 = 1.0 - std::pow((double)beta1, (double)st), bc2 = 1.0 - std::pow((double)beta2, (double)st);
-    c.bc2_sqrt[k] = (float)std::sqrt(bc2);
-    c.step_size[k] = (float)((double)G.g[k].lr / bc1);
-  }
-  float iso_coef = iso_weight / (3.f * (float)n);
-  hipLaunchKernelGGL(gaussian_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, G, c, iso_coef);
+  FusedAdam fa;
+  if (int rc = make_fused_adam(n, groups, beta1, beta2, eps, iso_weight, &fa)) return rc;
+  hipLaunchKernelGGL(gaussian_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, fa.G, fa.c,
+                     fa.iso_coef);
   return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "gaussian_adam launch failed");
 }
 

@@ -172,6 +172,22 @@ void launch_mapping_loss_final(const LossTab& tab, int nviews, int HW, int npart
 struct LossPart { float rgb, dep, da, db; };
 struct LossCoef { float w_rgb, w_dep, thr; };
 
+// ---- Adam constants of one step (host side computes the bias corrections in double like torch.optim.Adam does)
+struct AdamConst { float b1, b2, eps; float bc2_sqrt[5], step_size[5]; };
+struct AdamGroups { SgrAdamGroup g[5]; };   // xyz, f_dc, opacity, scaling, rotation
+// gradient gather (over the views of a batch) + activation chain rule + isotropy + Adam + next activations in ONE
+// pass over the Gaussians: the tail of a single-GPU mapping iteration
+struct FusedAdam {
+  AdamGroups G;
+  AdamConst c;
+  float iso_coef;
+  int grads_clean;            // gradient sinks are all-zero on entry: neither read nor written
+  float *s_out, *r_out, *o_out;
+  float *stat_accum, *stat_denom, *stat_maxr;
+};
+int make_fused_adam(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight, FusedAdam* out);
+void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st);
+
 // ---- optional per-kernel event timing (sgr_profile_enable / sgr_profile_read)
 enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_SCATTER, PK_UNUSED3, PK_UNUSED4, PK_BLEND_FWD, PK_UNUSED6, PK_BLEND_BWD, PK_PRE_BWD };
 void prof_begin(int kind, hipStream_t st);

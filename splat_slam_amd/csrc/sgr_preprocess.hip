@@ -669,11 +669,15 @@ void launch_preprocess_fwd(const ViewTab& tab, int nviews, const LOff& L, const 
 }
 
 void launch_preprocess_bwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in,
-                           const SgrGradInputs& g, hipStream_t st) {
+                           const SgrGradInputs& g, const FusedAdam* fused, hipStream_t st) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_BWD, st);
   hipLaunchKernelGGL(preprocess_bwd_dense_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
                      in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, g.dL_dshs, g.dL_dcov3D_precomp, g.accumulate);
+  if (fused) {               // single-GPU mapping iteration: the gather rides in the optimiser pass (no gradient round trip)
+    launch_gather_adam(tab, nviews, L, *fused, st);
+    return;
+  }
   hipLaunchKernelGGL(grad_gather_kernel, dim3(L.pre_blocks), dim3(256), 0, st, tab, nviews, L, cm.deg, cm.M,
                      in.colors_precomp != nullptr ? 1 : 0, g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dopacities, g.dL_dshs,
                      g.dL_dcolors_precomp, g.dL_dscales, g.dL_drotations, g.dL_dcov3D_precomp, g.accumulate,

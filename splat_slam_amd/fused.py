@@ -106,14 +106,17 @@ class _ExposureSlab:
 
 
 class FusedMappingLoop(MappingLoop):
-    def __init__(self, config, device="cuda:0", knn_fn=None, check_every=50):
+    def __init__(self, config, device="cuda:0", knn_fn=None, check_every=50, span_calls=True):
         super().__init__(config, device=device, fused_loss=True, knn_fn=knn_fn)
         self.lib = nat.lib()
         self.check_every = check_every
+        self.fuse_tail = True            # gather + Adam + next activations in one pass (single GPU, regular iterations)
+        self.span_calls = span_calls     # regular iterations between map-surgery points go through sgr_map_run
         self.overflow_events = 0
         self._views = {}
         self._acc = None          # gradient accumulators wrt activated inputs + activated copies
         self._acc_key = None
+        self._acc_clean = True
         self._scratch = None
         self._since_check = 0
         self._exp = None
@@ -149,6 +152,7 @@ class FusedMappingLoop(MappingLoop):
                      "rotation": flat[10 * N: 14 * N].view(N, 4),
                      "act_scale": z(N, 3), "act_rot": z(N, 4), "act_opac": z(N, 1)}
         self._acc_key = key
+        self._acc_clean = True     # the gradient sinks are all-zero (every Adam step leaves them so)
         self._views = {}           # N changed: per-camera buffers are re-made lazily
         self._cap = 0
         if gm.active_sh_degree != 0 or gm._features_rest.numel() != 0:
@@ -309,17 +313,12 @@ class FusedMappingLoop(MappingLoop):
             self._plan_obj, self._plan_key = pl, key
         return self._plan_obj
 
-    def _step(self, cams, iso_weight=0.0, adam=True, skip=(), initialization=False, stats=True, forward_only=False,
-              exposure="none", activate=True):
-        """ONE host call: activate -> batched views (forward / loss / backward) -> Adam -> exposure Adam."""
-        pl = self._plan()
+    def _setup(self, pl, iso_weight, adam, skip, stats, forward_only, exposure, bump=True):
+        """Fills the view-independent part of pl.step.  bump: advance the Adam step counters here (one iteration);
+        sgr_map_run advances them itself."""
         st = pl.step
-        arr = self._views_array(cams, initialization)
-        st.num_views, st.views, st.forward_only = len(cams), arr, int(forward_only)
-        if not activate:
-            sc, st.scaling = st.scaling, None
-            ro, st.rotation = st.rotation, None
-            op, st.opacity = st.opacity, None
+        st.forward_only = int(forward_only)
+        st.grads_clean = int(self._acc_clean) if self.fuse_tail else -1
         st.grads = C.pointer(pl.gi_stats if stats else pl.gi_nostats)
         if adam and not forward_only:
             for k, (g, stt) in enumerate(pl.states):
@@ -329,9 +328,11 @@ class FusedMappingLoop(MappingLoop):
                     grp.skip = 1
                 else:
                     grp.skip = 0
-                    grp.step += 1
-                    stt["step"] += 1
-            pl.frest_state["step"] += 1
+                    if bump:
+                        grp.step += 1
+                        stt["step"] += 1
+            if bump:
+                pl.frest_state["step"] += 1
             st.adam_groups = pl.groups
             st.iso_weight = float(iso_weight)
         else:
@@ -341,6 +342,8 @@ class FusedMappingLoop(MappingLoop):
             e = self._exp
             if exposure == "window":
                 first, n, active = 0, max(self._exp_rows) + 1, e.active
+            elif exposure == "per_pick":            # sgr_map_run offsets the row itself (pool_exp_row)
+                first, n, active = 0, 1, e.ones
             else:                                   # only the rows in `exposure` (final_refine: the rendered camera)
                 rows = [r for r in exposure if r in self._exp_rows]
                 first, n, active = (rows[0], 1, e.ones) if rows else (0, 0, e.ones)
@@ -350,6 +353,54 @@ class FusedMappingLoop(MappingLoop):
                 st.exp_avg, st.exp_avg_sq = e.m.data_ptr() + 8 * first, e.v.data_ptr() + 8 * first
                 st.exp_step, st.exp_active = e.step.data_ptr() + 4 * first, active.data_ptr()
                 st.exp_lr, st.exp_beta1, st.exp_beta2, st.exp_eps = 0.01, 0.9, 0.999, 1e-8
+        return st
+
+    def _run_span(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True):
+        """len(lrs) regular iterations with ONE host call (sgr_map_run): iteration k renders window_cams plus
+        pool_cams[picks[k]] and steps Adam with the xyz learning rate lrs[k]."""
+        n_it = len(lrs)
+        if self.world > 1 or n_it == 0:
+            raise RuntimeError("_run_span is the single-GPU fast path")
+        pl = self._plan()
+        self._views_array(list(window_cams) + list(pool_cams), False)      # probes new cameras, settles the capacity
+        win = self._views_array(window_cams, False) if window_cams else None
+        pool = self._views_array(pool_cams, False) if pool_cams else None
+        st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
+        per = len(picks) // n_it if picks else 0
+        run = nat.SgrMapRun()
+        run.step = st
+        run.num_iters, run.num_window, run.pool_size, run.picks_per_iter = n_it, len(window_cams), len(pool_cams), per
+        if win is not None:
+            run.window = win
+        if pool is not None:
+            run.pool = pool
+        pk = (C.c_int32 * max(1, len(picks)))(*picks)
+        lr = (C.c_float * n_it)(*lrs)
+        run.picks, run.lr0, run.adam_groups = pk, lr, pl.groups
+        rows = None
+        if exposure == "per_pick":
+            rows = (C.c_int32 * max(1, len(pool_cams)))(*[
+                (self._exp.row_of(c) if self._exp is not None and self._exp.row_of(c) in self._exp_rows else -1)
+                for c in pool_cams])
+            run.pool_exp_row = rows
+        rc = self.lib.sgr_map_run(C.byref(run), self._stream())
+        nat.check(rc, "sgr_map_run")
+        self._acc_clean = True
+        for g, stt in pl.states:                 # the library advanced pl.groups[k].step; mirror it in torch's state
+            stt["step"] += n_it
+        pl.frest_state["step"] += n_it
+
+    def _step(self, cams, iso_weight=0.0, adam=True, skip=(), initialization=False, stats=True, forward_only=False,
+              exposure="none", activate=True):
+        """ONE host call: activate -> batched views (forward / loss / backward) -> Adam -> exposure Adam."""
+        pl = self._plan()
+        arr = self._views_array(cams, initialization)
+        st = self._setup(pl, iso_weight, adam, skip, stats, forward_only, exposure)
+        st.num_views, st.views = len(cams), arr
+        if not activate:
+            sc, st.scaling = st.scaling, None
+            ro, st.rotation = st.rotation, None
+            op, st.opacity = st.opacity, None
         if self.world > 1 and st.adam_groups and len(cams) and not forward_only:
             # multi-GPU: (1) this rank's views, (2) sum the flat gradient buffer over ranks with ONE RCCL all-reduce,
             # (3) the identical Adam step on every rank (the isotropy term is added locally, once)
@@ -369,6 +420,11 @@ class FusedMappingLoop(MappingLoop):
         if not activate:
             st.scaling, st.rotation, st.opacity = sc, ro, op
         nat.check(rc, "sgr_map_step")
+        if not forward_only:
+            if adam:
+                self._acc_clean = True
+            elif len(cams):
+                self._acc_clean = False
 
     def _run_views(self, cams, initialization=False, stats=True, forward_only=False):
         """Views only (no activation, no optimiser step): used by tests and forward-only passes."""
@@ -513,7 +569,33 @@ class FusedMappingLoop(MappingLoop):
         random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in cw]
         pose_opt = self.keyframe_optimizers is not None
         gaussian_split = False
-        for it in range(iters):
+        it = -1
+        while it + 1 < iters:
+            it += 1
+            # a span of regular iterations (no densification / opacity reset, no pose optimiser) is ONE host call
+            n = 0
+            if not prune and not pose_opt and self.world == 1 and self.span_calls:
+                while it + n < iters and not self._is_special(self.iteration_count + n + 1):
+                    n += 1
+            if n > 0:
+                self._ensure_state()
+                c0 = self.iteration_count
+                picks, per = [], min(2, len(random_viewpoint_stack))
+                for _ in range(n):               # the reference's draws, in its order (mapper.py:470)
+                    picks += torch.randperm(len(random_viewpoint_stack))[:2].tolist()
+                lrs = [float(self._xyz_group()["lr"])] + [self.gaussians.lr_at(c0 + k) for k in range(1, n)]
+                self._run_span(viewpoint_stack, random_viewpoint_stack, picks, lrs, 10.0, "window")
+                self.iteration_count = c0 + n
+                self.gaussians.update_learning_rate(self.iteration_count)
+                self.last_used = list(viewpoint_stack) + [random_viewpoint_stack[k] for k in picks[len(picks) - per:]]
+                it += n - 1
+                if it == iters - 1:
+                    self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
+                                                 for kf, c in zip(current_window, viewpoint_stack)}
+                self._since_check += n
+                if self._since_check >= self.check_every:
+                    self.check_overflow()
+                continue
             self.iteration_count += 1
             self._ensure_state()
             if prune:
@@ -563,9 +645,33 @@ class FusedMappingLoop(MappingLoop):
             self._tick()
         return gaussian_split
 
+    def _is_special(self, count):
+        update_gaussian = count % self.gaussian_update_every == self.gaussian_update_offset
+        return update_gaussian or (count % self.gaussian_reset) == 0
+
+    def _xyz_group(self):
+        for g in self.gaussians.optimizer.param_groups:
+            if g["name"] == "xyz":
+                return g
+
     def final_refine(self, iters=26000):
         stack = list(self.viewpoints.values())
-        for _ in range(iters):
+        done = 0
+        while self.world == 1 and self.span_calls and done < iters:
+            n = min(iters - done, 512)           # (the overflow check runs between chunks)
+            self._ensure_state()
+            c0 = self.iteration_count
+            picks = [int(np.random.randint(0, len(stack))) for _ in range(n)]
+            lrs = [float(self._xyz_group()["lr"])] + [self.gaussians.lr_at(c0 + k) for k in range(1, n)]
+            self._run_span([], stack, picks, lrs, 0.0, "per_pick", stats=False)
+            self.iteration_count = c0 + n
+            self.gaussians.update_learning_rate(self.iteration_count)
+            self.last_used = [stack[picks[-1]]]
+            self._since_check += n
+            if self._since_check >= self.check_every:
+                self.check_overflow()
+            done += n
+        for _ in range(iters - done):
             self.iteration_count += 1
             self._ensure_state()
             cam = stack[np.random.randint(0, len(stack))]

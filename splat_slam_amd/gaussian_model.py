@@ -198,6 +198,11 @@ class GaussianModel:
         self.lr_delay_mult = training_args.position_lr_delay_mult
         self.max_steps = training_args.position_lr_max_steps
 
+    def lr_at(self, iteration):
+        """xyz learning rate update_learning_rate(iteration) would set (no side effect)."""
+        return float(helper(iteration, lr_init=self.lr_init, lr_final=self.lr_final, lr_delay_mult=self.lr_delay_mult,
+                            max_steps=self.max_steps))
+
     def update_learning_rate(self, iteration):
         for param_group in self.optimizer.param_groups:
             if param_group["name"] == "xyz":

@@ -197,3 +197,81 @@ def test_probe_render_sees_activated_parameters_and_sizes_capacity():
     assert torch.equal(pf["radii"], pa["radii"])
     assert torch.allclose(pf["render"], pa["render"], atol=1e-5)
     assert torch.equal(pf["n_touched"], pa["n_touched"])
+
+
+def _fresh_cams(syn, cams):
+    out = []
+    for c in cams:
+        n = syn.make_camera(c.uid, torch.eye(4), syn.INTRINSICS["tiny"], c.original_image.clone(), c.depth.clone(), DEV)
+        n.update_RT(c.R, c.T)
+        out.append(n)
+    return out
+
+
+def test_span_call_equals_iteration_by_iteration_calls():
+    """sgr_map_run (one host call for a run of regular iterations) is the same computation as one sgr_map_step per
+    iteration: identical parameters, Adam state, exposure parameters, learning rate and step counters, bit for bit."""
+    import numpy as np
+    from splat_slam_amd.fused import FusedMappingLoop
+    syn, params, cams = _scene(n=2500, views=7)
+    res = []
+    for span, fuse in ((True, True), (False, True), (False, False), (True, False)):
+        loop = FusedMappingLoop(syn.DEFAULT_CONFIG, device=DEV, span_calls=span)
+        loop.fuse_tail = fuse                     # gather+Adam+activation in one pass vs three passes
+        loop.gaussians = syn.model_from_parameters(params, device=DEV)
+        loop.viewpoints = {c.uid: c for c in _fresh_cams(syn, cams)}
+        loop.current_window = [0, 1, 2, 3]
+        loop.build_keyframe_optimizers()
+        loop.iteration_count = 50                 # 50 % 150 == 50 was the densify point: 149 regular iterations follow
+        torch.manual_seed(5)
+        np.random.seed(5)
+        loop.map(loop.current_window, iters=7)
+        loop.map(loop.current_window, iters=3)
+        loop.final_refine(iters=6)
+        torch.cuda.synchronize()
+        gm = loop.gaussians
+        st = {g["name"]: gm.optimizer.state[g["params"][0]] for g in gm.optimizer.param_groups}
+        res.append({"xyz": gm._xyz.detach().clone(), "f_dc": gm._features_dc.detach().clone(),
+                    "opacity": gm._opacity.detach().clone(), "scaling": gm._scaling.detach().clone(),
+                    "rotation": gm._rotation.detach().clone(), "m_xyz": st["xyz"]["exp_avg"].clone(),
+                    "v_rot": st["rotation"]["exp_avg_sq"].clone(), "exp": loop._exp.param.clone(),
+                    "exp_step": loop._exp.step.clone(), "accum": gm.xyz_gradient_accum.clone(), "denom": gm.denom.clone(),
+                    "steps": torch.tensor([float(st[k]["step"]) for k in sorted(st)]),
+                    "lr": torch.tensor([loop._xyz_group()["lr"]], dtype=torch.float64),
+                    "count": torch.tensor([loop.iteration_count]),
+                    "occ": torch.stack([v for _, v in sorted(loop.occ_aware_visibility.items())]),
+                    "last": torch.tensor([c.uid for c in loop.last_used])})
+    for other in res[1:]:
+        for k in res[0]:
+            assert torch.equal(res[0][k], other[k]), k
+    assert res[0]["steps"].tolist() == [16.0] * len(res[0]["steps"]) and int(res[0]["count"]) == 66
+    assert float(res[0]["exp_step"].max()) > 0
+
+
+def test_fused_tail_with_preloaded_gradient_sinks():
+    """Views rendered earlier without an optimiser step leave their gradients in the sinks; the fused gather+Adam pass
+    must add them (MODE 1) exactly like the separate gather -> Adam sequence does."""
+    from splat_slam_amd.fused import FusedMappingLoop
+    syn, params, cams = _scene(n=2000, views=4)
+    out = []
+    for fuse in (True, False):
+        loop = _loop(FusedMappingLoop, syn, params, _fresh_cams(syn, cams), range(3))
+        loop.fuse_tail = fuse
+        loop._ensure_state()
+        loop._activate()
+        loop._run_views([loop.viewpoints[3]])
+        assert not loop._acc_clean
+        loop._step([loop.viewpoints[0], loop.viewpoints[1]], iso_weight=10.0, adam=True, exposure="window")
+        assert loop._acc_clean and float(loop._acc["flat"].abs().max()) == 0.0
+        loop._step([loop.viewpoints[2]], iso_weight=10.0, adam=True)          # MODE 2: sinks stay untouched
+        assert float(loop._acc["flat"].abs().max()) == 0.0
+        torch.cuda.synchronize()
+        gm = loop.gaussians
+        out.append([gm._xyz.detach().clone(), gm._features_dc.detach().clone(), gm._opacity.detach().clone(),
+                    gm._scaling.detach().clone(), gm._rotation.detach().clone(), loop._acc["act_scale"].clone(),
+                    loop._acc["act_rot"].clone(), loop._acc["act_opac"].clone()])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    # the activations written by the fused pass are those of the updated parameters
+    gm = loop.gaussians
+    assert torch.equal(out[0][5], torch.exp(out[0][3])) or torch.allclose(out[0][5], torch.exp(out[0][3]), rtol=1e-6)
