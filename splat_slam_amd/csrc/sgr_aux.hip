@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(256) activate_kernel(int64_t n, const float* _
                                                        const float* __restrict__ rotation, const float* __restrict__ opacity,
                                                        float* __restrict__ s_out, float* __restrict__ r_out,
                                                        float* __restrict__ o_out) {
+#pragma clang fp contract(off)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (s_out) {
@@ -181,6 +182,9 @@ template <int MODE>
 __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G, const AdamConst& c, float iso_coef,
                                                   const float* e /*[14] gathered or zeros*/, float* __restrict__ s_out,
                                                   float* __restrict__ r_out, float* __restrict__ o_out) {
+  // every product and sum below is rounded on its own: the three instantiations (and the separate activate_kernel)
+  // must agree bit for bit, which fused multiply-adds chosen per instantiation would not guarantee
+#pragma clang fp contract(off)
   // xyz and f_dc: identity activations
 #pragma unroll
   for (int grp = 0; grp < 2; ++grp) {

@@ -36,8 +36,8 @@ __device__ uint32_t block1024_scan(const uint32_t* __restrict__ in, uint32_t* __
   return carry;
 }
 
-// K2: three independent scans per view, one 1024-thread block each (grid = (3, views)): (0) tile starts, (1) block
-// bases of the partial-slot offsets, (2) block bases of the visible list.  ranges[t] = (start, start): scatter uses .y
+// K2: three independent scans per view, one 1024-thread block each (grid = (3, views)): (0) tile starts, (1) segment
+// bases of the partial-slot offsets, (2) the number of visible Gaussians (sum of the segments' list lengths).  ranges[t] = (start, start): scatter uses .y
 // as the fill cursor, so after K3 it is the end of the tile's run.
 __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   __shared__ uint32_t red[16];
@@ -55,43 +55,30 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
       hdr->sorted_count = (uint32_t)((int64_t)R > L.cap ? L.cap : (int64_t)R);
     }
   } else if (blockIdx.x == 1) {
-    (void)block1024_scan((const uint32_t*)(saved + L.o_block_touched), (uint32_t*)(saved + L.o_block_base_t), L.pre_blocks, red);
+    (void)block1024_scan((const uint32_t*)(saved + L.o_block_touched), (uint32_t*)(saved + L.o_block_base_t), L.nseg, red);
   } else {
-    uint32_t V = block1024_scan((const uint32_t*)(saved + L.o_block_vis), (uint32_t*)(saved + L.o_block_base_v), L.pre_blocks, red);
+    uint32_t V = block1024_scan((const uint32_t*)(saved + L.o_block_vis), (uint32_t*)(saved + L.o_block_base_v), L.nseg, red);
     if (threadIdx.x == 0) hdr->num_visible = V;
   }
 }
 
-// K3: grid = (ceil(N/1024), views), thread = 4 consecutive Gaussians (one int4 of radii; most threads see nothing and
-// leave), no barriers: finishes the visible list (absolute position = block base + in-block prefix from K1) and
-// scatters one (depth bits | Gaussian) key per pair into its tile's run.  Order inside a run is arbitrary; K4 sorts it.
+// K3: grid = (segments, views); the block walks its segment's visible list (K1) and scatters one (depth bits | Gaussian)
+// key per (tile, Gaussian) pair into the tile's run.  Order inside a run is arbitrary; K4 sorts it.  Waves beyond the
+// list leave at once (a SLAM view sees a few % of the map: typically one live wave per segment, all lanes busy).
 __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
   const int v = blockIdx.y;
   char* saved = tab.saved[v];
-  const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i0 >= L.N) return;
-  int rr[4] = {0, 0, 0, 0};
-  if (i0 + 3 < L.N) {
-    int4 q = *(const int4*)(tab.radii[v] + i0);
-    rr[0] = q.x; rr[1] = q.y; rr[2] = q.z; rr[3] = q.w;
-  } else {
-    for (int k = 0; k < 4 && i0 + k < L.N; ++k) rr[k] = tab.radii[v][i0 + k];
-  }
-  if ((rr[0] | rr[1] | rr[2] | rr[3]) <= 0) return;
-  uint32_t* vis_pos = (uint32_t*)(saved + L.o_vis_pos);
+  const int nvis = (int)((const uint32_t*)(saved + L.o_block_vis))[blockIdx.x];
   uint2* ranges = (uint2*)(saved + L.o_ranges);
   uint64_t* entries = (uint64_t*)(tab.scratch[v] + L.o_entries);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (rr[k] <= 0) continue;
-    const uint32_t i = (uint32_t)(i0 + k);
-    const uint32_t vp = vis_pos[i] + ((const uint32_t*)(saved + L.o_block_base_v))[i >> 8];
-    vis_pos[i] = vp;
-    ((uint32_t*)(saved + L.o_vis_list))[vp] = i;
-    if (((const uint32_t*)(saved + L.o_touched))[i] == 0) continue;
+#pragma unroll 1
+  for (int t = threadIdx.x; t < nvis; t += 256) {
+    const uint32_t i = ((const uint32_t*)(saved + L.o_vis_list))[blockIdx.x * kSeg + t];
+    const int cnt = (int)((const uint32_t*)(saved + L.o_touched))[i];
+    if (cnt == 0) continue;
     ushort4 r = ((const ushort4*)(saved + L.o_rect))[i];
     uint64_t key = ((uint64_t)__float_as_uint(((const float4*)(saved + L.o_rgbd))[i].w) << 32) | i;
-    const int w = (int)r.z - (int)r.x, cnt = w * ((int)r.w - (int)r.y);
+    const int w = (int)r.z - (int)r.x;
     // returning atomics are latency-bound: keep 4 in flight (most splats cover <= 4 bins)
     for (int k0 = 0; k0 < cnt; k0 += 4) {
       uint32_t pos[4];
@@ -127,7 +114,7 @@ void launch_binning(const ViewTab& tab, int nviews, const LOff& L, hipStream_t s
   }
   if (L.N > 0) {
     ProfScope prof(PK_SCATTER, st);
-    hipLaunchKernelGGL(scatter_kernel, dim3((L.N + 1023) / 1024, nviews), dim3(256), 0, st, tab, L);
+    hipLaunchKernelGGL(scatter_kernel, dim3(L.nseg, nviews), dim3(256), 0, st, tab, L);
   }
 }
 

@@ -239,14 +239,27 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
 
 // ------------------------------------------------------------------------------------------------ backward
 // inclusive scans restricted to groups of GW lanes (GW = 16: one DPP row, 32: two rows, 64: whole wave)
+// One scan step as a single VALU op: v_mul_f32_dpp with vdst = src0 = src1.  A lane whose DPP source is out of range
+// (bound_ctrl off) or outside row_mask is DISABLED and keeps its value -- exactly the identity a product scan needs
+// (the builtin path costs a v_mov_dpp with old = 1.0 plus a v_mul).  s_nop 1 = the 2 wait states a DPP read of a
+// freshly written VGPR requires.
+#define SGR_MUL_DPP(CTRL) "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 " CTRL "\n\t"
 template <int GW>
 __device__ __forceinline__ float group_scan_mul(float v) {
-  v *= dpp_f<DPP_ROW_SHR1>(1.f, v);
-  v *= dpp_f<DPP_ROW_SHR2>(1.f, v);
-  v *= dpp_f<DPP_ROW_SHR4>(1.f, v);
-  v *= dpp_f<DPP_ROW_SHR8>(1.f, v);
-  if (GW >= 32) v *= dpp_f<DPP_ROW_BCAST15, 0xa>(1.f, v);
-  if (GW >= 64) v *= dpp_f<DPP_ROW_BCAST31, 0xc>(1.f, v);
+  if (GW == 16)
+    asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        : "+v"(v));
+  else if (GW == 32)
+    asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        SGR_MUL_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        : "+v"(v));
+  else
+    asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        SGR_MUL_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf") SGR_MUL_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(v));
   return v;
 }
 template <int GW>

@@ -19,6 +19,8 @@ constexpr float kTouchedT = 0.5f;
 constexpr int kRefTile = 16;           // upstream tile edge: defines which pixels a splat may reach
 constexpr int kTile = 8;               // our binning tile = one wave64 = 8x8 pixels
 constexpr int kWave = 64;
+constexpr int kSeg = 1024;             // Gaussians per preprocess segment (one 256-thread block), see preprocess_fwd_kernel
+constexpr int kSegShift = 10;
 
 constexpr float SH_C0 = 0.28209479177387814f;
 constexpr float SH_C1 = 0.4886025119029199f;
@@ -59,7 +61,7 @@ struct ViewTab {
 };
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {
-  int N, H, W, gx, gy, sgx, sgy, ntiles, pre_blocks;
+  int N, H, W, gx, gy, sgx, sgy, ntiles, pre_blocks, nseg;
   int64_t cap;
   size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
@@ -88,7 +90,7 @@ struct Layout {
   size_t o_entries;
   // scratch (backward) -- aliases the forward scratch
   size_t o_partials, o_tau_part, o_gradrec, o_taurec, scratch_bytes;
-  int pre_blocks;
+  int pre_blocks, nseg;
 
   __host__ Layout(int N_, int H_, int W_, int64_t cap_) : N(N_), H(H_), W(W_), cap(cap_) {
     gx = (W + kTile - 1) / kTile;
@@ -102,6 +104,7 @@ struct Layout {
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
     size_t n = (size_t)(N > 0 ? N : 1), hw = (size_t)H * W, c = (size_t)(cap > 0 ? cap : 1);
     pre_blocks = (N + 255) / 256;
+    nseg = (N + kSeg - 1) / kSeg;
     size_t nb = (size_t)(pre_blocks > 0 ? pre_blocks : 1);
     o_hdr = take(sizeof(SavedHeader));
     o_tile_count = take((size_t)ntiles * 4);     // hdr + tile_count are zeroed by ONE memset per forward
@@ -138,7 +141,7 @@ struct Layout {
   }
   __host__ LOff dev() const {
     LOff d;
-    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks;
+    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg;
     d.cap = cap;
     d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_xy = o_xy; d.o_conic_o = o_conic_o; d.o_rgbd = o_rgbd;
     d.o_rect = o_rect; d.o_offsets = o_offsets; d.o_touched = o_touched; d.o_clamped = o_clamped;
@@ -198,9 +201,9 @@ struct ProfScope {
   ~ProfScope() { prof_end(kind, st); }
 };
 
-// absolute partial-slot offset of Gaussian g: in-block prefix (written by preprocess_fwd) + its block's base (tile_scan)
+// absolute partial-slot offset of Gaussian g: in-segment prefix (written by preprocess_fwd) + its segment's base (tile_scan)
 __device__ __forceinline__ uint32_t abs_offset(const char* saved, const LOff& L, uint32_t g) {
-  return ((const uint32_t*)(saved + L.o_offsets))[g] + ((const uint32_t*)(saved + L.o_block_base_t))[g >> 8];
+  return ((const uint32_t*)(saved + L.o_offsets))[g] + ((const uint32_t*)(saved + L.o_block_base_t))[g >> kSegShift];
 }
 
 // ---- tiny fixed-size linear algebra on registers

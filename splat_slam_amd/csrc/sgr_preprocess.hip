@@ -54,8 +54,8 @@ struct Ewa {
   float a, b, c;             // dilated 2D covariance
 };
 
-__device__ __forceinline__ void ewa_project(const float pv[3], const float* vm, const float S6[6], float fx, float fy,
-                                            float limx, float limy, Ewa& e) {
+// first half of the EWA projection: clamped view-space mean and T = J * W
+__device__ __forceinline__ void ewa_T(const float pv[3], const float* vm, float fx, float fy, float limx, float limy, Ewa& e) {
   float tz = pv[2];
   float txtz = pv[0] / tz, tytz = pv[1] / tz;
   e.clamp_x = (txtz < -limx) || (txtz > limx);
@@ -72,6 +72,11 @@ __device__ __forceinline__ void ewa_project(const float pv[3], const float* vm, 
     e.T[0][k] = J00 * vm[k * 4 + 0] + J02 * vm[k * 4 + 2];
     e.T[1][k] = J11 * vm[k * 4 + 1] + J12 * vm[k * 4 + 2];
   }
+}
+
+__device__ __forceinline__ void ewa_project(const float pv[3], const float* vm, const float S6[6], float fx, float fy,
+                                            float limx, float limy, Ewa& e) {
+  ewa_T(pv, vm, fx, fy, limx, limy, e);
   float S[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
   float TS[2][3];
 #pragma unroll
@@ -119,12 +124,6 @@ struct PreOut {
   unsigned clamped;
 };
 
-// K1: per-Gaussian projection + footprint + 8x8 bin rectangle, and the first half of the binning:
-//   * per-tile pair counts (one fire-and-forget atomic per (tile, Gaussian) pair),
-//   * in-block exclusive prefixes of `touched` and `visible` + the block totals (finished by tile_scan_kernel: a
-//     deterministic two-level scan instead of a device-wide scan library call).
-// grid = (ceil(N/256), views): blockIdx.y selects the view.  (Walking the views inside one block to share the
-// per-Gaussian loads was measured slower: 12x fewer waves cannot hide the latency of the load -> atomic -> scan chain.)
 struct PreIn {
   float p[3], opac, S6[6], c_in[3];
 };
@@ -212,72 +211,156 @@ __device__ __forceinline__ void preprocess_view(const PreIn& in, int i, int H, i
   o.x0 = x0; o.y0 = y0; o.x1 = x1; o.y1 = y1;
 }
 
+// Cheap, CONSERVATIVE visibility test (phase A of K1): false only if preprocess_view is certain to reject the Gaussian.
+// Same near-plane test; the reference-tile rectangle is evaluated with a radius bound rad_b >= rad + 1:
+//   lam = mid + sqrt(max(0.1, mid^2 - det)) <= a + c + 0.317,   a + c = tr(T Sigma T^T) + 0.6 <= |T|_F^2 tr(Sigma) + 0.6
+// (trS = an upper bound of tr(Sigma)); a larger radius only grows the rectangle, so "empty with rad_b" implies "empty".
+__device__ __forceinline__ bool maybe_visible(const float p[3], float trS, int H, int W, float tanfovx, float tanfovy,
+                                              const float* vm, const float* pm, int sgx, int sgy) {
+  float pv[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) pv[r] = vm[r] * p[0] + vm[4 + r] * p[1] + vm[8 + r] * p[2] + vm[12 + r];
+  if (!(pv[2] > kNearPlane)) return false;
+  float ph0 = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
+  float ph1 = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
+  float ph3 = pm[3] * p[0] + pm[7] * p[1] + pm[11] * p[2] + pm[15];
+  float pw = 1.f / (ph3 + 1e-7f);
+  float px = ((ph0 * pw + 1.f) * W - 1.f) * 0.5f, py = ((ph1 * pw + 1.f) * H - 1.f) * 0.5f;
+  float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
+  Ewa e;
+  ewa_T(pv, vm, fx, fy, 1.3f * tanfovx, 1.3f * tanfovy, e);
+  float tn = e.T[0][0] * e.T[0][0] + e.T[0][1] * e.T[0][1] + e.T[0][2] * e.T[0][2] + e.T[1][0] * e.T[1][0] +
+             e.T[1][1] * e.T[1][1] + e.T[1][2] * e.T[1][2];
+  float rad_b = ceilf(3.f * sqrtf(tn * trS * 1.001f + 1.0f)) + 1.f;
+  if (!(isfinite(px) && isfinite(py) && isfinite(rad_b))) return true;      // let the exact path decide
+  int rx0 = min(sgx, max(0, (int)((px - rad_b) / (float)kRefTile)));
+  int ry0 = min(sgy, max(0, (int)((py - rad_b) / (float)kRefTile)));
+  int rx1 = min(sgx, max(0, (int)((px + rad_b + (kRefTile - 1)) / (float)kRefTile)));
+  int ry1 = min(sgy, max(0, (int)((py + rad_b + (kRefTile - 1)) / (float)kRefTile)));
+  return (rx1 - rx0) * (ry1 - ry0) != 0;
+}
+
+// K1.  grid = (ceil(N/1024), views); one 256-thread block owns a SEGMENT of 1024 consecutive Gaussians of one view.
+//   phase A  every thread tests 4 Gaussians with maybe_visible() (a few % survive in a SLAM map: most of the map is
+//            behind or beside the camera) and the survivors are compacted, in Gaussian order, into an LDS list;
+//   phase B  the survivors run the full projection with dense lanes (the old one-thread-per-Gaussian form ran the
+//            ~500-instruction footprint code with ~6 % of the lanes alive), count their (tile, Gaussian) pairs per
+//            tile (fire-and-forget atomics), and get, in list order: the in-segment prefix of their pair count
+//            (-> partial-slot offsets, finished by tile_scan_kernel) and their slot in the segment's visible list
+//            vis_list[seg*1024 + k] (vis_pos[i] = that index; later stages walk these lists, one block per segment).
+// Everything is fixed-order: results are bitwise reproducible.
+
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     ViewTab tab, int nviews, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp) {
+  __shared__ uint16_t cand[kSeg];
   __shared__ uint32_t red[4];
+  (void)nviews;
   const int N = L.N;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in_range = i < N;
-  PreIn in;
-  if (in_range) {      // every per-Gaussian load up front: one HBM round trip, shared by all views
-    in.p[0] = means3D[3 * i]; in.p[1] = means3D[3 * i + 1]; in.p[2] = means3D[3 * i + 2];
-    in.opac = opacities[i];
-    if (cov3D_precomp) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) in.S6[k] = cov3D_precomp[6 * i + k];
-    } else {
-      float s_in[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-      float q_in[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
-      cov3d_from_scale_rot(s_in, cm.mod, q_in, in.S6);
+  const int v = blockIdx.y, seg = blockIdx.x, seg0 = seg * kSeg;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  char* saved = tab.saved[v];
+  float vm[16], pm[16];
+  load16(tab.viewmatrix[v], vm);
+  load16(tab.projmatrix[v], pm);
+
+  // ---- phase A
+  uint32_t ncand = 0;
+#pragma unroll 1
+  for (int k = 0; k < kSeg / 256; ++k) {
+    const int li = k * 256 + (int)threadIdx.x;
+    const int i = seg0 + li;
+    bool pass = false;
+    if (i < N) {
+      tab.radii[v][i] = 0;                 // outputs of the culled majority; phase B overwrites the visible ones
+      tab.n_touched[v][i] = 0;
+      const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+      float trS;
+      if (cov3D_precomp) {
+        trS = cov3D_precomp[6 * i] + cov3D_precomp[6 * i + 3] + cov3D_precomp[6 * i + 5];
+      } else {
+        const float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+        const float4 q = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]);
+        const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+        if (fabsf(n2 - 1.f) < 1e-3f) {     // R(q) = (1-n2) I + n2 R(q/|q|): column norms <= 1.002
+          trS = cm.mod * cm.mod * (s0 * s0 + s1 * s1 + s2 * s2) * 1.01f;
+        } else {
+          float s_in[3] = {s0, s1, s2}, q_in[4] = {q.x, q.y, q.z, q.w}, S6[6];
+          cov3d_from_scale_rot(s_in, cm.mod, q_in, S6);
+          trS = (S6[0] + S6[3] + S6[5]) * 1.001f;
+        }
+      }
+      pass = maybe_visible(p, trS, L.H, L.W, cm.tanfovx, cm.tanfovy, vm, pm, L.sgx, L.sgy);
     }
-    in.c_in[0] = in.c_in[1] = in.c_in[2] = 0.f;
-    if (colors_precomp) { in.c_in[0] = colors_precomp[3 * i]; in.c_in[1] = colors_precomp[3 * i + 1]; in.c_in[2] = colors_precomp[3 * i + 2]; }
-    else if (cm.deg == 0) { in.c_in[0] = shs[(size_t)i * cm.M * 3]; in.c_in[1] = shs[(size_t)i * cm.M * 3 + 1]; in.c_in[2] = shs[(size_t)i * cm.M * 3 + 2]; }
+    const unsigned long long m = __ballot(pass);
+    if (lane == 0) red[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    const uint32_t w0 = red[0], w1 = red[1], w2 = red[2], w3 = red[3];
+    __syncthreads();
+    const uint32_t base = ncand + (wv > 0 ? w0 : 0u) + (wv > 1 ? w1 : 0u) + (wv > 2 ? w2 : 0u);
+    if (pass) cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)li;
+    ncand += w0 + w1 + w2 + w3;
   }
-  {
-    const int v = blockIdx.y;
-    (void)nviews;
-    char* saved = tab.saved[v];
+  __syncthreads();
+
+  // ---- phase B
+  uint32_t carry_t = 0, carry_v = 0;
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < ncand; c0 += 256) {
+    const uint32_t c = c0 + threadIdx.x;
     PreOut o;
     o.visible = false;
     o.x0 = o.x1 = o.y0 = o.y1 = 0;
-    if (in_range) {
-      float vm[16], pm[16];
-      load16(tab.viewmatrix[v], vm);
-      load16(tab.projmatrix[v], pm);
+    int i = 0;
+    if (c < ncand) {
+      i = seg0 + (int)cand[c];
+      PreIn in;
+      in.p[0] = means3D[3 * i]; in.p[1] = means3D[3 * i + 1]; in.p[2] = means3D[3 * i + 2];
+      in.opac = opacities[i];
+      if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) in.S6[k] = cov3D_precomp[6 * i + k];
+      } else {
+        float s_in[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        float q_in[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        cov3d_from_scale_rot(s_in, cm.mod, q_in, in.S6);
+      }
+      in.c_in[0] = in.c_in[1] = in.c_in[2] = 0.f;
+      if (colors_precomp) { in.c_in[0] = colors_precomp[3 * i]; in.c_in[1] = colors_precomp[3 * i + 1]; in.c_in[2] = colors_precomp[3 * i + 2]; }
+      else if (cm.deg == 0) { in.c_in[0] = shs[(size_t)i * cm.M * 3]; in.c_in[1] = shs[(size_t)i * cm.M * 3 + 1]; in.c_in[2] = shs[(size_t)i * cm.M * 3 + 2]; }
       preprocess_view(in, i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, vm, pm, tab.campos[v], shs,
                       colors_precomp != nullptr, L.gx, L.gy, L.sgx, L.sgy, o);
     }
-    uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
-    if (in_range) {
-      tab.radii[v][i] = o.visible ? (int32_t)o.rad : 0;
-      tab.n_touched[v][i] = 0;
+    const uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
+    if (o.visible) {
+      tab.radii[v][i] = (int32_t)o.rad;
       ((uint32_t*)(saved + L.o_touched))[i] = cnt;
-      if (o.visible) {
-        ((float2*)(saved + L.o_xy))[i] = make_float2(o.px, o.py);
-        ((float4*)(saved + L.o_conic_o))[i] = make_float4(o.A, o.B, o.C, o.opac);
-        ((float4*)(saved + L.o_rgbd))[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
-        ((ushort4*)(saved + L.o_rect))[i] =
-            make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
-        ((uint8_t*)(saved + L.o_clamped))[i] = (uint8_t)o.clamped;
-        uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
-        for (int y = o.y0; y < o.y1; ++y)
-          for (int x = o.x0; x < o.x1; ++x) atomicAdd(&tile_count[y * L.gx + x], 1u);
-      }
+      ((float2*)(saved + L.o_xy))[i] = make_float2(o.px, o.py);
+      ((float4*)(saved + L.o_conic_o))[i] = make_float4(o.A, o.B, o.C, o.opac);
+      ((float4*)(saved + L.o_rgbd))[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+      ((ushort4*)(saved + L.o_rect))[i] =
+          make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
+      ((uint8_t*)(saved + L.o_clamped))[i] = (uint8_t)o.clamped;
+      uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
+      for (int y = o.y0; y < o.y1; ++y)
+        for (int x = o.x0; x < o.x1; ++x) atomicAdd(&tile_count[y * L.gx + x], 1u);
     }
     uint32_t tot_t, tot_v;
-    uint32_t ex = block256_exclusive_scan(cnt, red, tot_t);
-    uint32_t exv = block256_exclusive_scan(o.visible ? 1u : 0u, red, tot_v);
-    if (in_range) {
-      ((uint32_t*)(saved + L.o_offsets))[i] = ex;              // relative; abs_offset() adds the block base
-      if (o.visible) ((uint32_t*)(saved + L.o_vis_pos))[i] = exv;   // relative; scatter_kernel makes it absolute
+    const uint32_t ex = block256_exclusive_scan(cnt, red, tot_t);
+    const uint32_t exv = block256_exclusive_scan(o.visible ? 1u : 0u, red, tot_v);
+    if (o.visible) {
+      ((uint32_t*)(saved + L.o_offsets))[i] = carry_t + ex;        // relative; abs_offset() adds the segment base
+      const uint32_t vp = (uint32_t)seg0 + carry_v + exv;
+      ((uint32_t*)(saved + L.o_vis_pos))[i] = vp;
+      ((uint32_t*)(saved + L.o_vis_list))[vp] = (uint32_t)i;
     }
-    if (threadIdx.x == 0) {
-      ((uint32_t*)(saved + L.o_block_touched))[blockIdx.x] = tot_t;
-      ((uint32_t*)(saved + L.o_block_vis))[blockIdx.x] = tot_v;
-    }
+    carry_t += tot_t;
+    carry_v += tot_v;
+  }
+  if (threadIdx.x == 0) {
+    ((uint32_t*)(saved + L.o_block_touched))[seg] = carry_t;
+    ((uint32_t*)(saved + L.o_block_vis))[seg] = carry_v;
   }
 }
 
@@ -514,29 +597,29 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
   acc.m2[0] = g_m2[0]; acc.m2[1] = g_m2[1];     // per view (densification statistics use the per-view norm)
 }
 
-// Phase 1 (dense): thread = entry of a view's compact visible list; grid = (ceil(N/256), views), blocks beyond the
-// list exit at once.  Writes one 64-byte gradient record per (view, visible Gaussian) and the view's pose partials.
-// With a single view the rarely used extras (SH degree > 0, precomputed colour / covariance) go straight to the outputs.
+// Phase 1 (dense): one block per (segment, view) walks the segment's visible list (see K1), thread = visible Gaussian.
+// Writes one 64-byte gradient record per (view, visible Gaussian) at the Gaussian's list slot, and the view's pose
+// partials.  With a single view the rarely used extras (SH degree > 0, precomputed colour / covariance) go straight to
+// the outputs.
 __global__ void __launch_bounds__(256) preprocess_bwd_dense_kernel(
     ViewTab tab, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, float* __restrict__ dshs, float* __restrict__ dcov3D, int accumulate) {
   const int v = blockIdx.y;
   const char* saved = tab.saved[v];
-  const int V = (int)((const SavedHeader*)(saved + L.o_hdr))->num_visible;
-  if ((int)(blockIdx.x * blockDim.x) >= V) return;             // whole block beyond the list (uniform)
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = t < V;
-  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (live) {
+  const int nvis = (int)((const uint32_t*)(saved + L.o_block_vis))[blockIdx.x];
+#pragma unroll 1
+  for (int k = threadIdx.x; k < nvis; k += 256) {
+    const int t = blockIdx.x * kSeg + k;
+    float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int i = (int)((const uint32_t*)(saved + L.o_vis_list))[t];
     GaussGrad acc;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { acc.p[k] = 0.f; acc.s[k] = 0.f; acc.rgb_or_sh0[k] = 0.f; }
+    for (int j = 0; j < 3; ++j) { acc.p[j] = 0.f; acc.s[j] = 0.f; acc.rgb_or_sh0[j] = 0.f; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc.q[k] = 0.f;
+    for (int j = 0; j < 4; ++j) acc.q[j] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc.S6[k] = 0.f;
+    for (int j = 0; j < 6; ++j) acc.S6[j] = 0.f;
     acc.op = 0.f; acc.m2[0] = 0.f; acc.m2[1] = 0.f;
     preprocess_bwd_one_view(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, tab.viewmatrix[v], tab.projmatrix[v],
                             cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
@@ -550,13 +633,13 @@ __global__ void __launch_bounds__(256) preprocess_bwd_dense_kernel(
     rec[3] = make_float4(acc.q[2], acc.q[3], acc.m2[0], acc.m2[1]);
     if (dcov3D) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { if (accumulate) dcov3D[6 * i + k] += acc.S6[k]; else dcov3D[6 * i + k] = acc.S6[k]; }
+      for (int j = 0; j < 6; ++j) { if (accumulate) dcov3D[6 * i + j] += acc.S6[j]; else dcov3D[6 * i + j] = acc.S6[j]; }
     }
-  }
-  if (tab.dL_dtau[v] && live) {      // pose gradient requested: keep this Gaussian's 6 terms for the ordered reduction
-    float* tr = (float*)(tab.scratch[v] + L.o_taurec) + (size_t)t * 6;
+    if (tab.dL_dtau[v]) {            // pose gradient requested: keep this Gaussian's 6 terms for the ordered reduction
+      float* tr = (float*)(tab.scratch[v] + L.o_taurec) + (size_t)t * 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) tr[k] = tau[k];
+      for (int j = 0; j < 6; ++j) tr[j] = tau[j];
+    }
   }
 }
 
@@ -664,7 +747,7 @@ __global__ void __launch_bounds__(384) tau_reduce_kernel(ViewTab tab, LOff L) {
 void launch_preprocess_fwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_FWD, st);
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.nseg, nviews), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
                      in.shs, in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp);
 }
 
@@ -672,7 +755,7 @@ void launch_preprocess_bwd(const ViewTab& tab, int nviews, const LOff& L, const 
                            const SgrGradInputs& g, const FusedAdam* fused, hipStream_t st) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_BWD, st);
-  hipLaunchKernelGGL(preprocess_bwd_dense_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
+  hipLaunchKernelGGL(preprocess_bwd_dense_kernel, dim3(L.nseg, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
                      in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, g.dL_dshs, g.dL_dcov3D_precomp, g.accumulate);
   if (fused) {               // single-GPU mapping iteration: the gather rides in the optimiser pass (no gradient round trip)
     launch_gather_adam(tab, nviews, L, *fused, st);
