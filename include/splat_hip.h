@@ -208,7 +208,8 @@ int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1,
  * host cost of a mapping iteration is the kernel launches only. */
 typedef struct SgrMapView {
   SgrSettings settings;
-  SgrOutputs out;
+  SgrOutputs out;              /* color / depth / opacity may ALL be NULL when only loss + gradients are wanted;
+                                  n_touched may be NULL (not counted) */
   SgrWorkspace ws;
   const float* gt_image;       /* [3,H,W] */
   const float* gt_depth;       /* [H,W]   */
@@ -281,6 +282,7 @@ typedef struct SgrMapRun {
   const float* lr0;             /* host, [num_iters] or NULL (keep adam_groups[0].lr) */
   SgrAdamGroup* adam_groups;    /* host, [5] or NULL */
   const int32_t* pool_exp_row;  /* host, [pool_size] or NULL */
+  int32_t n_touched_last_only;  /* != 0: n_touched is only produced by the last iteration (nobody can observe the others) */
 } SgrMapRun;
 int sgr_map_run(const SgrMapRun* run, void* stream);
 

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -32,6 +33,12 @@ int set_error(int code, const char* fmt, ...) {
     hipError_t _e = (expr);                                                                             \
     if (_e != hipSuccess) return set_error(SGR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
   } while (0)
+
+int debug_flags() {
+  static int f = -1;
+  if (f < 0) { const char* e = getenv("SGR_DEBUG"); f = e ? atoi(e) : 0; }
+  return f;
+}
 
 static Layout make_layout(int N, int H, int W, int64_t cap) { return Layout(N, H, W, cap); }
 
@@ -78,7 +85,7 @@ __global__ void __launch_bounds__(256) stats_kernel(int N, int ntiles, const int
   unsigned long long v = 0, r = 0, re = 0, ne = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) v += radii[i] > 0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
-    uint32_t c = ranges[t].y - ranges[t].x;
+    uint32_t c = ranges[(size_t)t * kRngStride].y - ranges[(size_t)t * kRngStride].x;
     r += c; re += min(c, tile_maxc[t]); ne += c > 0;
   }
   atomicAdd(&out[0], v); atomicAdd(&out[1], r); atomicAdd(&out[2], re); atomicAdd(&out[3], ne);
@@ -237,6 +244,8 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
   if (!uniform || f.settings.num_gaussians == 0) {       // heterogeneous views: one after the other (shared scratch is fine)
     for (int v = 0; v < num_views; ++v) {
       const SgrMapView& mv = views[v];
+      if (!mv.out.color || !mv.out.depth || !mv.out.opacity || !mv.out.n_touched)
+        return set_error(SGR_ERR_INVALID, "map_views: outputs may only be omitted in uniform batches");
       if (int rc = sgr_forward(&mv.settings, in, &mv.out, &mv.ws, nullptr, stream)) return rc;
       if (forward_only) continue;
       if (int rc = sgr_mapping_loss(mv.settings.image_height, mv.settings.image_width, mv.out.color, mv.out.depth, mv.gt_image,
@@ -262,7 +271,8 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
     for (int v = 0; v < nv; ++v) {
       const SgrMapView& m = views[base + v];
       if (int rc = check_workspace(&m.ws, L)) return rc;
-      if (!m.out.color || !m.out.depth || !m.out.opacity || !m.out.radii || !m.out.n_touched)
+      const bool no_images = !m.out.color && !m.out.depth && !m.out.opacity && !forward_only;   // loss-only iteration
+      if ((!no_images && (!m.out.color || !m.out.depth || !m.out.opacity)) || !m.out.radii)
         return set_error(SGR_ERR_INVALID, "map_views: null output pointer");
       tab_set_view(tab, v, &m.settings, &m.out, &m.ws);
       if (!forward_only) {
@@ -271,6 +281,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
           return set_error(SGR_ERR_INVALID, "map_views: loss buffers missing (loss_scratch needs 16 B per 8x8 tile = %zu)",
                            (size_t)L.ntiles * sizeof(LossPart));
         tab.dL_dcolor[v] = m.dL_dimage; tab.dL_ddepth[v] = m.dL_ddepth; tab.dL_dtau[v] = m.dL_dtau;
+        // (image / depth are unused by the fused epilogue: it has the pixel in registers)
         lt.image[v] = m.out.color; lt.depth[v] = m.out.depth; lt.gt_image[v] = m.gt_image; lt.gt_depth[v] = m.gt_depth;
         lt.exp_a[v] = m.exposure_a; lt.exp_b[v] = m.exposure_b; lt.loss[v] = m.loss; lt.dimage[v] = m.dL_dimage;
         lt.ddepth[v] = m.dL_ddepth; lt.da[v] = m.dL_dexposure; lt.db[v] = m.dL_dexposure ? m.dL_dexposure + 1 : nullptr;
@@ -373,6 +384,12 @@ int sgr_map_run(const SgrMapRun* r, void* stream) {
       const int32_t k = r->picks[(size_t)it * r->picks_per_iter + j];
       if (k < 0 || k >= r->pool_size) return set_error(SGR_ERR_INVALID, "map_run: pick %d outside the pool", k);
       views[r->num_window + j] = r->pool[k];
+    }
+    if (r->n_touched_last_only) {       // the per-Gaussian "touched" counters only matter after the run (mapper.py:494-498)
+      const bool last = it == r->num_iters - 1;
+      for (int v = 0; v < r->num_window; ++v) views[v].out.n_touched = last ? r->window[v].out.n_touched : nullptr;
+      if (!last)
+        for (int j = 0; j < r->picks_per_iter; ++j) views[r->num_window + j].out.n_touched = nullptr;
     }
     if (r->adam_groups) {
       if (r->lr0) r->adam_groups[0].lr = r->lr0[it];

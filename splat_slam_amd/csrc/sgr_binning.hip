@@ -12,14 +12,15 @@
 namespace sgr {
 
 // exclusive scan of in[0..n) by ONE 1024-thread block, 4 items per thread per pass; returns the total
-__device__ uint32_t block1024_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, uint32_t* red) {
+__device__ uint32_t block1024_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, uint32_t* red,
+                                   int in_stride = 1) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;   // 16 waves
   uint32_t carry = 0;
   for (int base = 0; base < n; base += 4096) {
     int i0 = base + threadIdx.x * 4;
     uint32_t v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (i0 + k) < n ? in[i0 + k] : 0u;
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k) < n ? in[(size_t)(i0 + k) * in_stride] : 0u;
     uint32_t s4 = v[0] + v[1] + v[2] + v[3];
     uint32_t inc = wave_scan_add_u32(s4);
     if (lane == 63) red[wv] = inc;
@@ -37,7 +38,7 @@ __device__ uint32_t block1024_scan(const uint32_t* __restrict__ in, uint32_t* __
 }
 
 // K2: three independent scans per view, one 1024-thread block each (grid = (3, views)): (0) tile starts, (1) segment
-// bases of the partial-slot offsets, (2) the number of visible Gaussians (sum of the segments' list lengths).  ranges[t] = (start, start): scatter uses .y
+// bases of the partial-slot offsets, (2) segment bases of the compact visible list.  ranges[t] = (start, start): scatter uses .y
 // as the fill cursor, so after K3 it is the end of the tile's run.
 __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   __shared__ uint32_t red[16];
@@ -46,9 +47,9 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   if (blockIdx.x == 0) {
     uint32_t* tmp = (uint32_t*)(saved + L.o_tile_maxc);      // free until blend_fwd overwrites it
     uint2* ranges = (uint2*)(saved + L.o_ranges);
-    uint32_t R = block1024_scan((const uint32_t*)(saved + L.o_tile_count), tmp, L.ntiles, red);
+    uint32_t R = block1024_scan((const uint32_t*)(saved + L.o_tile_count), tmp, L.ntiles, red, kCntStride);
     __syncthreads();
-    for (int t = threadIdx.x; t < L.ntiles; t += 1024) { uint32_t s0 = tmp[t]; ranges[t] = make_uint2(s0, s0); }
+    for (int t = threadIdx.x; t < L.ntiles; t += 1024) { uint32_t s0 = tmp[t]; ranges[(size_t)t * kRngStride] = make_uint2(s0, s0); }
     if (threadIdx.x == 0) {
       hdr->num_rendered = R;
       hdr->overflow = (int64_t)R > L.cap ? 1u : 0u;
@@ -62,18 +63,36 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   }
 }
 
-// K3: grid = (segments, views); the block walks its segment's visible list (K1) and scatters one (depth bits | Gaussian)
-// key per (tile, Gaussian) pair into the tile's run.  Order inside a run is arbitrary; K4 sorts it.  Waves beyond the
-// list leave at once (a SLAM view sees a few % of the map: typically one live wave per segment, all lanes busy).
+// K3: grid = (ceil(N/1024), views); the block concatenates the visible lists of its four 256-Gaussian segments (K1)
+// into the view's compact visible list (absolute position = segment base from K2 + position in the segment list) and
+// scatters one (depth bits | Gaussian) key per (tile, Gaussian) pair into the tile's run.  Order inside a run is
+// arbitrary; K4 sorts it.  Waves beyond the lists leave at once (a SLAM view sees a few % of the map: typically one
+// live wave per block, all lanes busy).
 __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
   const int v = blockIdx.y;
   char* saved = tab.saved[v];
-  const int nvis = (int)((const uint32_t*)(saved + L.o_block_vis))[blockIdx.x];
+  const uint32_t* block_vis = (const uint32_t*)(saved + L.o_block_vis);
+  const uint32_t* base_v = (const uint32_t*)(saved + L.o_block_base_v);
+  const int s0 = blockIdx.x * 4;
+  uint32_t c[4], b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool in = s0 + j < L.nseg;
+    c[j] = in ? block_vis[s0 + j] : 0u;
+    b[j] = in ? base_v[s0 + j] : 0u;
+  }
+  const uint32_t e1 = c[0], e2 = e1 + c[1], e3 = e2 + c[2], nvis = e3 + c[3];
   uint2* ranges = (uint2*)(saved + L.o_ranges);
   uint64_t* entries = (uint64_t*)(tab.scratch[v] + L.o_entries);
+  if (L.dbg & 4) return;
 #pragma unroll 1
-  for (int t = threadIdx.x; t < nvis; t += 256) {
-    const uint32_t i = ((const uint32_t*)(saved + L.o_vis_list))[blockIdx.x * kSeg + t];
+  for (uint32_t t = threadIdx.x; t < nvis; t += 256) {
+    const int j = (t >= e1) + (t >= e2) + (t >= e3);
+    const uint32_t k = t - (j == 0 ? 0u : (j == 1 ? e1 : (j == 2 ? e2 : e3)));
+    const uint32_t i = ((const uint32_t*)(saved + L.o_seg_list))[(s0 + j) * kSeg + k];
+    const uint32_t vp = (j == 0 ? b[0] : (j == 1 ? b[1] : (j == 2 ? b[2] : b[3]))) + k;
+    ((uint32_t*)(saved + L.o_vis_pos))[i] = vp;
+    ((uint32_t*)(saved + L.o_vis_list))[vp] = i;
     const int cnt = (int)((const uint32_t*)(saved + L.o_touched))[i];
     if (cnt == 0) continue;
     ushort4 r = ((const ushort4*)(saved + L.o_rect))[i];
@@ -83,13 +102,14 @@ __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
     for (int k0 = 0; k0 < cnt; k0 += 4) {
       uint32_t pos[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int kk = k0 + j;
-        if (kk < cnt) pos[j] = atomicAdd(&ranges[((int)r.y + kk / w) * L.gx + (int)r.x + kk % w].y, 1u);
+      for (int jj = 0; jj < 4; ++jj) {
+        int kk = k0 + jj;
+        if (kk < cnt) pos[jj] = (L.dbg & 8) ? ranges[(size_t)(((int)r.y + kk / w) * L.gx + (int)r.x + kk % w) * kRngStride].x + (i & 7u)
+                                            : atomicAdd(&ranges[(size_t)(((int)r.y + kk / w) * L.gx + (int)r.x + kk % w) * kRngStride].y, 1u);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (k0 + j < cnt && (int64_t)pos[j] < L.cap) entries[pos[j]] = key;
+      for (int jj = 0; jj < 4; ++jj)
+        if (k0 + jj < cnt && (int64_t)pos[jj] < L.cap) entries[pos[jj]] = key;
     }
   }
 }
@@ -114,7 +134,7 @@ void launch_binning(const ViewTab& tab, int nviews, const LOff& L, hipStream_t s
   }
   if (L.N > 0) {
     ProfScope prof(PK_SCATTER, st);
-    hipLaunchKernelGGL(scatter_kernel, dim3(L.nseg, nviews), dim3(256), 0, st, tab, L);
+    hipLaunchKernelGGL(scatter_kernel, dim3((L.nseg + 3) / 4, nviews), dim3(256), 0, st, tab, L);
   }
 }
 

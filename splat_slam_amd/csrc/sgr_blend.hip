@@ -115,7 +115,18 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   uint64_t* keys = (uint64_t*)slice;
   float4* lds = (float4*)(slice + SORT_MAX * 8);
 
-  const uint2 rng = ranges[tile];
+  // ground truth of the fused loss epilogue: fetched NOW so that the round trip hides behind sorting and blending
+  const float* __restrict__ gt_image = lt.gt_image[vw];
+  float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, gtd = 0.f, ea = 1.f, eb = 0.f;
+  if (gt_image && inside) {
+    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+    gt0 = gt_image[pix]; gt1 = gt_image[hw + pix]; gt2 = gt_image[2 * hw + pix];
+    gtd = lt.gt_depth[vw][pix];
+    ea = lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f;
+    eb = lt.exp_b[vw] ? lt.exp_b[vw][0] : 0.f;
+  }
+
+  const uint2 rng = ranges[(size_t)tile * kRngStride];
   const int64_t begin = rng.x;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
   const int count = endc > begin ? (int)(endc - begin) : 0;
@@ -182,7 +193,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
       C2 = __fmaf_rn(e2.z, w, C2);
       D = __fmaf_rn(e1.z, w, D);
       unsigned long long tm = __builtin_amdgcn_ballot_w64(comp && testT > kTouchedT);
-      if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(e1.w)], (int)__popcll(tm));
+      if (n_touched && tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(e1.w)], (int)__popcll(tm));
       if (comp) { T = testT; last = (uint32_t)(base + j + 1); }
     }
     __builtin_amdgcn_wave_barrier();
@@ -196,23 +207,22 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   if (lane == 0) tile_maxc[tile] = mx;
 
   float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;
-  const float* __restrict__ gt_image = lt.gt_image[vw];
   if (inside) {
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
     final_T[pix] = T;
     n_contrib[pix] = last;
     const float I[3] = {C0 + T * bg[0], C1 + T * bg[1], C2 + T * bg[2]};
-    out_color[pix] = I[0];
-    out_color[hw + pix] = I[1];
-    out_color[2 * hw + pix] = I[2];
-    out_depth[pix] = D;
-    out_opacity[pix] = 1.f - T;
+    if (out_color) {            // (a training iteration that only needs the loss passes no image buffers)
+      out_color[pix] = I[0];
+      out_color[hw + pix] = I[1];
+      out_color[2 * hw + pix] = I[2];
+      out_depth[pix] = D;
+      out_opacity[pix] = 1.f - T;
+    }
     if (gt_image) {
       // fused mapping loss (slam_utils.py:71-105): this pixel's residuals, the gradients the backward consumes, and
       // its share of the four sums (|rgb|, |depth|, d/da, d/db)
-      const float ea = lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f;
-      const float eb = lt.exp_b[vw] ? lt.exp_b[vw][0] : 0.f;
-      const float g[3] = {gt_image[pix], gt_image[hw + pix], gt_image[2 * hw + pix]};
+      const float g[3] = {gt0, gt1, gt2};
       const bool m = (g[0] + g[1] + g[2]) > lc.thr;
       float* __restrict__ dimage = lt.dimage[vw];
 #pragma unroll
@@ -225,7 +235,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
         l_da += dab * ea * I[c];
         l_db += dab;
       }
-      const float gd = lt.gt_depth[vw][pix];
+      const float gd = gtd;
       const float rd = (gd > 0.01f) ? D - gd : 0.f;
       l_dep = fabsf(rd);
       lt.ddepth[vw][pix] = lc.w_dep * ((rd > 0.f) ? 1.f : ((rd < 0.f) ? -1.f : 0.f));
@@ -395,7 +405,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
   if (tx >= gx || ty >= gy) return;
   const int tile = ty * gx + tx;
-  const uint2 rng = ranges[tile];
+  const uint2 rng = ranges[(size_t)tile * kRngStride];
   const int64_t begin = rng.x;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
   const int count = endc > begin ? (int)(endc - begin) : 0;

@@ -19,8 +19,12 @@ constexpr float kTouchedT = 0.5f;
 constexpr int kRefTile = 16;           // upstream tile edge: defines which pixels a splat may reach
 constexpr int kTile = 8;               // our binning tile = one wave64 = 8x8 pixels
 constexpr int kWave = 64;
-constexpr int kSeg = 1024;             // Gaussians per preprocess segment (one 256-thread block), see preprocess_fwd_kernel
-constexpr int kSegShift = 10;
+// per-tile atomic counters live on their own 64-byte line: ~200 atomics per line (16 counters x 12 hits) serialised the
+// binning kernels, one counter per line does not
+constexpr int kCntStride = 4;          // uint32 units between two tiles' pair counters
+constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
+constexpr int kSeg = 256;              // Gaussians per preprocess segment (one 256-thread block), see preprocess_fwd_kernel
+constexpr int kSegShift = 8;
 
 constexpr float SH_C0 = 0.28209479177387814f;
 constexpr float SH_C1 = 0.4886025119029199f;
@@ -61,11 +65,11 @@ struct ViewTab {
 };
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {
-  int N, H, W, gx, gy, sgx, sgy, ntiles, pre_blocks, nseg;
+  int N, H, W, gx, gy, sgx, sgy, ntiles, pre_blocks, nseg, dbg;
   int64_t cap;
   size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_vis_pos, o_entries, o_partials, o_tau_part, o_gradrec, o_taurec;
+      o_vis_pos, o_seg_list, o_entries, o_partials, o_tau_part, o_gradrec, o_taurec;
 };
 // shared (view independent) scalars of a batch
 struct Common {
@@ -74,6 +78,8 @@ struct Common {
   const float* bg;
   const float* projraw;
 };
+
+int debug_flags();   // SGR_DEBUG environment variable (timing experiments only; 0 in production)
 
 // Carves the two workspaces. Pure function of (N, H, W, capacity): forward and backward agree by construction.
 struct Layout {
@@ -85,7 +91,7 @@ struct Layout {
   // saved
   size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_vis_pos, saved_bytes, zero_bytes;
+      o_vis_pos, o_seg_list, saved_bytes, zero_bytes;
   // scratch (forward)
   size_t o_entries;
   // scratch (backward) -- aliases the forward scratch
@@ -107,7 +113,7 @@ struct Layout {
     nseg = (N + kSeg - 1) / kSeg;
     size_t nb = (size_t)(pre_blocks > 0 ? pre_blocks : 1);
     o_hdr = take(sizeof(SavedHeader));
-    o_tile_count = take((size_t)ntiles * 4);     // hdr + tile_count are zeroed by ONE memset per forward
+    o_tile_count = take((size_t)ntiles * 4 * kCntStride);     // hdr + tile_count are zeroed by ONE launch per forward
     zero_bytes = o;
     o_xy = take(n * 8);
     o_conic_o = take(n * 16);
@@ -117,7 +123,7 @@ struct Layout {
     o_touched = take(n * 4);
     o_clamped = take(n);
     o_point_list = take(c * 4);
-    o_ranges = take((size_t)ntiles * 8);
+    o_ranges = take((size_t)ntiles * 8 * kRngStride);
     o_tile_maxc = take((size_t)ntiles * 4);
     o_final_T = take(hw * 4);
     o_n_contrib = take(hw * 4);
@@ -127,6 +133,7 @@ struct Layout {
     o_block_base_v = take(nb * 4);
     o_vis_list = take(n * 4);
     o_vis_pos = take(n * 4);
+    o_seg_list = take(n * 4);        // per-segment visible lists written by K1; K3 turns them into the compact o_vis_list
     saved_bytes = o;
 
     o = 0;
@@ -141,14 +148,14 @@ struct Layout {
   }
   __host__ LOff dev() const {
     LOff d;
-    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg;
+    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags();
     d.cap = cap;
     d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_xy = o_xy; d.o_conic_o = o_conic_o; d.o_rgbd = o_rgbd;
     d.o_rect = o_rect; d.o_offsets = o_offsets; d.o_touched = o_touched; d.o_clamped = o_clamped;
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;
     d.o_n_contrib = o_n_contrib; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
     d.o_block_base_t = o_block_base_t; d.o_block_base_v = o_block_base_v; d.o_vis_list = o_vis_list;
-    d.o_vis_pos = o_vis_pos; d.o_entries = o_entries; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
+    d.o_vis_pos = o_vis_pos; d.o_seg_list = o_seg_list; d.o_entries = o_entries; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
     d.o_gradrec = o_gradrec; d.o_taurec = o_taurec;
     return d;
   }

@@ -224,64 +224,84 @@ __device__ __forceinline__ bool maybe_visible(const float p[3], float trS, int H
   float ph0 = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
   float ph1 = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
   float ph3 = pm[3] * p[0] + pm[7] * p[1] + pm[11] * p[2] + pm[15];
-  float pw = 1.f / (ph3 + 1e-7f);
+  float pw = __builtin_amdgcn_rcpf(ph3 + 1e-7f);            // (approximate: the +1 pixel / 0.1 % margins absorb it)
   float px = ((ph0 * pw + 1.f) * W - 1.f) * 0.5f, py = ((ph1 * pw + 1.f) * H - 1.f) * 0.5f;
   float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
-  Ewa e;
-  ewa_T(pv, vm, fx, fy, 1.3f * tanfovx, 1.3f * tanfovy, e);
-  float tn = e.T[0][0] * e.T[0][0] + e.T[0][1] * e.T[0][1] + e.T[0][2] * e.T[0][2] + e.T[1][0] * e.T[1][0] +
-             e.T[1][1] * e.T[1][1] + e.T[1][2] * e.T[1][2];
-  float rad_b = ceilf(3.f * sqrtf(tn * trS * 1.001f + 1.0f)) + 1.f;
+  // |T|_F^2 of T = J W with the reference's clamped Jacobian, W rows from the view matrix
+  const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+  const float itz = __builtin_amdgcn_rcpf(pv[2]);
+  const float cx = fminf(limx, fmaxf(-limx, pv[0] * itz)), cy = fminf(limy, fmaxf(-limy, pv[1] * itz));
+  const float J00 = fx * itz, J02 = -J00 * cx, J11 = fy * itz, J12 = -J11 * cy;
+  float tn = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float t0 = J00 * vm[k * 4 + 0] + J02 * vm[k * 4 + 2], t1 = J11 * vm[k * 4 + 1] + J12 * vm[k * 4 + 2];
+    tn += t0 * t0 + t1 * t1;
+  }
+  float rad_b = ceilf(3.f * __builtin_amdgcn_sqrtf(tn * trS * 1.002f + 1.0f)) + 1.f;
   if (!(isfinite(px) && isfinite(py) && isfinite(rad_b))) return true;      // let the exact path decide
-  int rx0 = min(sgx, max(0, (int)((px - rad_b) / (float)kRefTile)));
-  int ry0 = min(sgy, max(0, (int)((py - rad_b) / (float)kRefTile)));
-  int rx1 = min(sgx, max(0, (int)((px + rad_b + (kRefTile - 1)) / (float)kRefTile)));
-  int ry1 = min(sgy, max(0, (int)((py + rad_b + (kRefTile - 1)) / (float)kRefTile)));
+  int rx0 = min(sgx, max(0, (int)((px - rad_b) * (1.f / kRefTile))));
+  int ry0 = min(sgy, max(0, (int)((py - rad_b) * (1.f / kRefTile))));
+  int rx1 = min(sgx, max(0, (int)((px + rad_b + (kRefTile - 1)) * (1.f / kRefTile))));
+  int ry1 = min(sgy, max(0, (int)((py + rad_b + (kRefTile - 1)) * (1.f / kRefTile))));
   return (rx1 - rx0) * (ry1 - ry0) != 0;
 }
 
-// K1.  grid = (ceil(N/1024), views); one 256-thread block owns a SEGMENT of 1024 consecutive Gaussians of one view.
-//   phase A  every thread tests 4 Gaussians with maybe_visible() (a few % survive in a SLAM map: most of the map is
-//            behind or beside the camera) and the survivors are compacted, in Gaussian order, into an LDS list;
-//   phase B  the survivors run the full projection with dense lanes (the old one-thread-per-Gaussian form ran the
-//            ~500-instruction footprint code with ~6 % of the lanes alive), count their (tile, Gaussian) pairs per
-//            tile (fire-and-forget atomics), and get, in list order: the in-segment prefix of their pair count
-//            (-> partial-slot offsets, finished by tile_scan_kernel) and their slot in the segment's visible list
-//            vis_list[seg*1024 + k] (vis_pos[i] = that index; later stages walk these lists, one block per segment).
+// K1.  grid = ceil(N/256) blocks of 256 threads; a block owns a SEGMENT of 256 consecutive Gaussians for ALL views of
+// the batch (<= 16):
+//   phase A  thread = Gaussian: its position / scale / rotation are loaded ONCE and tested against every view with
+//            maybe_visible() (per-view launches re-read the map once per view: 12 x 40 B x N was the kernel's HBM
+//            floor).  A SLAM view sees a few % of the map, so the survivors are compacted (wave ballots + one LDS
+//            exchange, deterministic order) into one candidate list per view;
+//   phase B  thread = (view, candidate) pair, all views back to back, so the lanes are dense: full projection,
+//            footprint, 8x8 bin rectangle, per-tile pair counts (fire-and-forget atomics).  A block-wide scan over the
+//            flattened pairs, rebased at every view boundary, gives each visible Gaussian its in-segment prefix of
+//            pairs (-> partial-slot offsets, finished by tile_scan_kernel) and its slot in the (view, segment) visible
+//            list seg_list[seg*256 + k]; scatter_kernel later concatenates those lists.
 // Everything is fixed-order: results are bitwise reproducible.
-
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) preprocess_fwd_kernel(
     ViewTab tab, int nviews, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp) {
-  __shared__ uint16_t cand[kSeg];
+  __shared__ float mats[kMaxViews][32];            // viewmatrix | projmatrix of every view
+  __shared__ char* p_saved[kMaxViews];
+  __shared__ int32_t* p_radii[kMaxViews];
+  __shared__ int32_t* p_ntouched[kMaxViews];
+  __shared__ const float* p_campos[kMaxViews];
+  __shared__ uint8_t cand[kMaxViews][kSeg];
+  __shared__ uint32_t wtot[kMaxViews][4];
+  __shared__ uint32_t vstart[kMaxViews + 1];
+  __shared__ uint32_t vbase_t[kMaxViews + 1], vbase_v[kMaxViews + 1];
   __shared__ uint32_t red[4];
-  (void)nviews;
   const int N = L.N;
-  const int v = blockIdx.y, seg = blockIdx.x, seg0 = seg * kSeg;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  char* saved = tab.saved[v];
-  float vm[16], pm[16];
-  load16(tab.viewmatrix[v], vm);
-  load16(tab.projmatrix[v], pm);
+  const int seg = blockIdx.x, seg0 = seg * kSeg;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+  // ---- per-view constants into LDS (constant indices only: a dynamically indexed by-value struct would go to scratch)
+#pragma unroll
+  for (int u = 0; u < kMaxViews; ++u) {
+    if (u < nviews) {
+      if (tid < 16) mats[u][tid] = tab.viewmatrix[u][tid];
+      else if (tid < 32) mats[u][tid] = tab.projmatrix[u][tid - 16];
+      if (tid == 32) { p_saved[u] = tab.saved[u]; p_radii[u] = tab.radii[u]; p_ntouched[u] = tab.n_touched[u]; p_campos[u] = tab.campos[u]; }
+    }
+  }
+  if (tid <= kMaxViews) { vbase_t[tid] = 0u; vbase_v[tid] = 0u; }
+  __syncthreads();
 
   // ---- phase A
-  uint32_t ncand = 0;
-#pragma unroll 1
-  for (int k = 0; k < kSeg / 256; ++k) {
-    const int li = k * 256 + (int)threadIdx.x;
-    const int i = seg0 + li;
-    bool pass = false;
-    if (i < N) {
-      tab.radii[v][i] = 0;                 // outputs of the culled majority; phase B overwrites the visible ones
-      tab.n_touched[v][i] = 0;
-      const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
-      float trS;
+  const int ia = seg0 + tid;
+  uint32_t passbits = 0, ranks[4] = {0u, 0u, 0u, 0u};      // rank of this lane among its wave's survivors, 8 bits per view
+  {
+    float p[3] = {0.f, 0.f, 0.f};
+    float trS = 0.f;
+    if (ia < N) {
+      p[0] = means3D[3 * ia]; p[1] = means3D[3 * ia + 1]; p[2] = means3D[3 * ia + 2];
       if (cov3D_precomp) {
-        trS = cov3D_precomp[6 * i] + cov3D_precomp[6 * i + 3] + cov3D_precomp[6 * i + 5];
+        trS = cov3D_precomp[6 * ia] + cov3D_precomp[6 * ia + 3] + cov3D_precomp[6 * ia + 5];
       } else {
-        const float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
-        const float4 q = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]);
+        const float s0 = scales[3 * ia], s1 = scales[3 * ia + 1], s2 = scales[3 * ia + 2];
+        const float4 q = make_float4(rotations[4 * ia], rotations[4 * ia + 1], rotations[4 * ia + 2], rotations[4 * ia + 3]);
         const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
         if (fabsf(n2 - 1.f) < 1e-3f) {     // R(q) = (1-n2) I + n2 R(q/|q|): column norms <= 1.002
           trS = cm.mod * cm.mod * (s0 * s0 + s1 * s1 + s2 * s2) * 1.01f;
@@ -291,30 +311,62 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
           trS = (S6[0] + S6[3] + S6[5]) * 1.001f;
         }
       }
-      pass = maybe_visible(p, trS, L.H, L.W, cm.tanfovx, cm.tanfovy, vm, pm, L.sgx, L.sgy);
     }
-    const unsigned long long m = __ballot(pass);
-    if (lane == 0) red[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    const uint32_t w0 = red[0], w1 = red[1], w2 = red[2], w3 = red[3];
-    __syncthreads();
-    const uint32_t base = ncand + (wv > 0 ? w0 : 0u) + (wv > 1 ? w1 : 0u) + (wv > 2 ? w2 : 0u);
-    if (pass) cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)li;
-    ncand += w0 + w1 + w2 + w3;
+#pragma unroll 2
+    for (int v = 0; v < nviews; ++v) {
+      bool pass = false;
+      if (ia < N) {
+        p_radii[v][ia] = 0;                // outputs of the culled majority; phase B overwrites the visible ones
+        if (p_ntouched[v]) p_ntouched[v][ia] = 0;
+        if (L.dbg & 2) pass = (p[0] + trS == 12345.678f);
+        else pass = maybe_visible(p, trS, L.H, L.W, cm.tanfovx, cm.tanfovy, mats[v], mats[v] + 16, L.sgx, L.sgy);
+      }
+      const unsigned long long m = __ballot(pass);
+      if (lane == 0) wtot[v][wv] = (uint32_t)__popcll(m);
+      if (pass) {
+        passbits |= 1u << v;
+        ranks[v >> 2] |= (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) << ((v & 3) * 8);
+      }
+    }
   }
   __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int v = 0; v < nviews; ++v) {
+      vstart[v] = run;
+      run += wtot[v][0] + wtot[v][1] + wtot[v][2] + wtot[v][3];
+    }
+    for (int v = nviews; v <= kMaxViews; ++v) vstart[v] = run;
+  }
+#pragma unroll 1
+  for (int v = 0; v < nviews; ++v) {
+    if (passbits & (1u << v)) {
+      const uint32_t base = (wv > 0 ? wtot[v][0] : 0u) + (wv > 1 ? wtot[v][1] : 0u) + (wv > 2 ? wtot[v][2] : 0u);
+      cand[v][base + ((ranks[v >> 2] >> ((v & 3) * 8)) & 0xffu)] = (uint8_t)tid;
+    }
+  }
+  __syncthreads();
+  const uint32_t total = (L.dbg & 1) ? 0u : vstart[kMaxViews];
 
   // ---- phase B
   uint32_t carry_t = 0, carry_v = 0;
 #pragma unroll 1
-  for (uint32_t c0 = 0; c0 < ncand; c0 += 256) {
-    const uint32_t c = c0 + threadIdx.x;
+  for (uint32_t f0 = 0; f0 < total; f0 += 256) {
+    const uint32_t f = f0 + tid;
+    const bool live = f < total;
+    int v = 0;
+#pragma unroll
+    for (int u = 1; u < kMaxViews; ++u) v += (f >= vstart[u] && u < nviews) ? 1 : 0;
     PreOut o;
     o.visible = false;
     o.x0 = o.x1 = o.y0 = o.y1 = 0;
     int i = 0;
-    if (c < ncand) {
-      i = seg0 + (int)cand[c];
+    char* saved = p_saved[v];
+    if (live) {
+      i = seg0 + (int)cand[v][f - vstart[v]];
+      float vm[16], pm[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { vm[k] = mats[v][k]; pm[k] = mats[v][16 + k]; }
       PreIn in;
       in.p[0] = means3D[3 * i]; in.p[1] = means3D[3 * i + 1]; in.p[2] = means3D[3 * i + 2];
       in.opac = opacities[i];
@@ -329,12 +381,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       in.c_in[0] = in.c_in[1] = in.c_in[2] = 0.f;
       if (colors_precomp) { in.c_in[0] = colors_precomp[3 * i]; in.c_in[1] = colors_precomp[3 * i + 1]; in.c_in[2] = colors_precomp[3 * i + 2]; }
       else if (cm.deg == 0) { in.c_in[0] = shs[(size_t)i * cm.M * 3]; in.c_in[1] = shs[(size_t)i * cm.M * 3 + 1]; in.c_in[2] = shs[(size_t)i * cm.M * 3 + 2]; }
-      preprocess_view(in, i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, vm, pm, tab.campos[v], shs,
+      preprocess_view(in, i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, vm, pm, p_campos[v], shs,
                       colors_precomp != nullptr, L.gx, L.gy, L.sgx, L.sgy, o);
     }
     const uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
+    const uint32_t vis = o.visible ? 1u : 0u;
     if (o.visible) {
-      tab.radii[v][i] = (int32_t)o.rad;
+      p_radii[v][i] = (int32_t)o.rad;
       ((uint32_t*)(saved + L.o_touched))[i] = cnt;
       ((float2*)(saved + L.o_xy))[i] = make_float2(o.px, o.py);
       ((float4*)(saved + L.o_conic_o))[i] = make_float4(o.A, o.B, o.C, o.opac);
@@ -343,24 +396,37 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
           make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
       ((uint8_t*)(saved + L.o_clamped))[i] = (uint8_t)o.clamped;
       uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
+      if (!(L.dbg & 16))
       for (int y = o.y0; y < o.y1; ++y)
-        for (int x = o.x0; x < o.x1; ++x) atomicAdd(&tile_count[y * L.gx + x], 1u);
+        for (int x = o.x0; x < o.x1; ++x) {
+          if (L.dbg & 64) __hip_atomic_fetch_add(&tile_count[(size_t)(y * L.gx + x) * kCntStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else atomicAdd(&tile_count[(size_t)(y * L.gx + x) * kCntStride], 1u);
+        }
     }
     uint32_t tot_t, tot_v;
-    const uint32_t ex = block256_exclusive_scan(cnt, red, tot_t);
-    const uint32_t exv = block256_exclusive_scan(o.visible ? 1u : 0u, red, tot_v);
+    const uint32_t ex_t = carry_t + block256_exclusive_scan(cnt, red, tot_t);
+    const uint32_t ex_v = carry_v + block256_exclusive_scan(vis, red, tot_v);
+    // the running sums just after the last pair of a view are the next view's bases (empty views inherit them)
+    if (live) {
+#pragma unroll
+      for (int u = 1; u <= kMaxViews; ++u)
+        if (u > v && vstart[u] == f + 1) { vbase_t[u] = ex_t + cnt; vbase_v[u] = ex_v + vis; }
+    }
+    __syncthreads();
     if (o.visible) {
-      ((uint32_t*)(saved + L.o_offsets))[i] = carry_t + ex;        // relative; abs_offset() adds the segment base
-      const uint32_t vp = (uint32_t)seg0 + carry_v + exv;
-      ((uint32_t*)(saved + L.o_vis_pos))[i] = vp;
-      ((uint32_t*)(saved + L.o_vis_list))[vp] = (uint32_t)i;
+      ((uint32_t*)(saved + L.o_offsets))[i] = ex_t - vbase_t[v];      // relative; abs_offset() adds the segment base
+      const uint32_t k = ex_v - vbase_v[v];
+      ((uint32_t*)(saved + L.o_vis_pos))[i] = k;                       // relative; scatter_kernel makes it absolute
+      ((uint32_t*)(saved + L.o_seg_list))[seg0 + k] = (uint32_t)i;
     }
     carry_t += tot_t;
     carry_v += tot_v;
   }
-  if (threadIdx.x == 0) {
-    ((uint32_t*)(saved + L.o_block_touched))[seg] = carry_t;
-    ((uint32_t*)(saved + L.o_block_vis))[seg] = carry_v;
+  __syncthreads();
+  if (tid < nviews) {
+    char* saved = p_saved[tid];
+    ((uint32_t*)(saved + L.o_block_touched))[seg] = vbase_t[tid + 1] - vbase_t[tid];
+    ((uint32_t*)(saved + L.o_block_vis))[seg] = vbase_v[tid + 1] - vbase_v[tid];
   }
 }
 
@@ -597,49 +663,47 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
   acc.m2[0] = g_m2[0]; acc.m2[1] = g_m2[1];     // per view (densification statistics use the per-view norm)
 }
 
-// Phase 1 (dense): one block per (segment, view) walks the segment's visible list (see K1), thread = visible Gaussian.
-// Writes one 64-byte gradient record per (view, visible Gaussian) at the Gaussian's list slot, and the view's pose
-// partials.  With a single view the rarely used extras (SH degree > 0, precomputed colour / covariance) go straight to
-// the outputs.
+// Phase 1 (dense): thread = entry of a view's compact visible list; grid = (ceil(N/256), views), blocks beyond the
+// list exit at once.  Writes one 64-byte gradient record per (view, visible Gaussian) and the view's pose partials.
+// With a single view the rarely used extras (SH degree > 0, precomputed colour / covariance) go straight to the outputs.
 __global__ void __launch_bounds__(256) preprocess_bwd_dense_kernel(
     ViewTab tab, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, float* __restrict__ dshs, float* __restrict__ dcov3D, int accumulate) {
   const int v = blockIdx.y;
   const char* saved = tab.saved[v];
-  const int nvis = (int)((const uint32_t*)(saved + L.o_block_vis))[blockIdx.x];
-#pragma unroll 1
-  for (int k = threadIdx.x; k < nvis; k += 256) {
-    const int t = blockIdx.x * kSeg + k;
-    float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int i = (int)((const uint32_t*)(saved + L.o_vis_list))[t];
-    GaussGrad acc;
+  const int V = (int)((const SavedHeader*)(saved + L.o_hdr))->num_visible;
+  if ((int)(blockIdx.x * blockDim.x) >= V) return;             // whole block beyond the list (uniform)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V) return;
+  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int i = (int)((const uint32_t*)(saved + L.o_vis_list))[t];
+  GaussGrad acc;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { acc.p[j] = 0.f; acc.s[j] = 0.f; acc.rgb_or_sh0[j] = 0.f; }
+  for (int j = 0; j < 3; ++j) { acc.p[j] = 0.f; acc.s[j] = 0.f; acc.rgb_or_sh0[j] = 0.f; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc.q[j] = 0.f;
+  for (int j = 0; j < 4; ++j) acc.q[j] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) acc.S6[j] = 0.f;
-    acc.op = 0.f; acc.m2[0] = 0.f; acc.m2[1] = 0.f;
-    preprocess_bwd_one_view(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, tab.viewmatrix[v], tab.projmatrix[v],
-                            cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                            abs_offset(saved, L, (uint32_t)i), (const uint32_t*)(saved + L.o_touched),
-                            (const uint8_t*)(saved + L.o_clamped), (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
-                            dshs, accumulate, acc, tau);
-    float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)t * 4;
-    rec[0] = make_float4(acc.p[0], acc.p[1], acc.p[2], acc.rgb_or_sh0[0]);
-    rec[1] = make_float4(acc.rgb_or_sh0[1], acc.rgb_or_sh0[2], acc.op, acc.s[0]);
-    rec[2] = make_float4(acc.s[1], acc.s[2], acc.q[0], acc.q[1]);
-    rec[3] = make_float4(acc.q[2], acc.q[3], acc.m2[0], acc.m2[1]);
-    if (dcov3D) {
+  for (int j = 0; j < 6; ++j) acc.S6[j] = 0.f;
+  acc.op = 0.f; acc.m2[0] = 0.f; acc.m2[1] = 0.f;
+  preprocess_bwd_one_view(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, tab.viewmatrix[v], tab.projmatrix[v],
+                          cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                          abs_offset(saved, L, (uint32_t)i), (const uint32_t*)(saved + L.o_touched),
+                          (const uint8_t*)(saved + L.o_clamped), (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
+                          dshs, accumulate, acc, tau);
+  float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)t * 4;
+  rec[0] = make_float4(acc.p[0], acc.p[1], acc.p[2], acc.rgb_or_sh0[0]);
+  rec[1] = make_float4(acc.rgb_or_sh0[1], acc.rgb_or_sh0[2], acc.op, acc.s[0]);
+  rec[2] = make_float4(acc.s[1], acc.s[2], acc.q[0], acc.q[1]);
+  rec[3] = make_float4(acc.q[2], acc.q[3], acc.m2[0], acc.m2[1]);
+  if (dcov3D) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) { if (accumulate) dcov3D[6 * i + j] += acc.S6[j]; else dcov3D[6 * i + j] = acc.S6[j]; }
-    }
-    if (tab.dL_dtau[v]) {            // pose gradient requested: keep this Gaussian's 6 terms for the ordered reduction
-      float* tr = (float*)(tab.scratch[v] + L.o_taurec) + (size_t)t * 6;
+    for (int j = 0; j < 6; ++j) { if (accumulate) dcov3D[6 * i + j] += acc.S6[j]; else dcov3D[6 * i + j] = acc.S6[j]; }
+  }
+  if (tab.dL_dtau[v]) {              // pose gradient requested: keep this Gaussian's 6 terms for the ordered reduction
+    float* tr = (float*)(tab.scratch[v] + L.o_taurec) + (size_t)t * 6;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) tr[j] = tau[j];
-    }
+    for (int j = 0; j < 6; ++j) tr[j] = tau[j];
   }
 }
 
@@ -747,7 +811,7 @@ __global__ void __launch_bounds__(384) tau_reduce_kernel(ViewTab tab, LOff L) {
 void launch_preprocess_fwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_FWD, st);
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.nseg, nviews), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.nseg), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
                      in.shs, in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp);
 }
 
@@ -755,7 +819,7 @@ void launch_preprocess_bwd(const ViewTab& tab, int nviews, const LOff& L, const 
                            const SgrGradInputs& g, const FusedAdam* fused, hipStream_t st) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_BWD, st);
-  hipLaunchKernelGGL(preprocess_bwd_dense_kernel, dim3(L.nseg, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
+  hipLaunchKernelGGL(preprocess_bwd_dense_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
                      in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, g.dL_dshs, g.dL_dcov3D_precomp, g.accumulate);
   if (fused) {               // single-GPU mapping iteration: the gather rides in the optimiser pass (no gradient round trip)
     launch_gather_adam(tab, nviews, L, *fused, st);

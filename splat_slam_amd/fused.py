@@ -241,18 +241,22 @@ class FusedMappingLoop(MappingLoop):
                                  gm.xyz_gradient_accum.data_ptr() if stats else None,
                                  gm.denom.data_ptr() if stats else None, gm.max_radii2D.data_ptr() if stats else None)
 
-    def _map_view(self, cam, initialization=False):
-        """The cached SgrMapView of a camera: pointers into its persistent buffers, sized for the shared capacity."""
+    def _map_view(self, cam, initialization=False, images=True):
+        """The cached SgrMapView of a camera: pointers into its persistent buffers, sized for the shared capacity.
+        images=False: loss + gradients only (the rendered colour / depth / opacity are not written to HBM)."""
         vb = self._view(cam)
         key = (cam._version, self._cap, id(cam.exposure_a), id(cam.original_image), initialization,
                self.keyframe_optimizers is not None)
-        if vb.mv is not None and vb.mv_key == key:
-            return vb.mv
+        if vb.mv is None:
+            vb.mv = {}
+        hit = vb.mv.get(images)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         gm = self.gaussians
         N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
         s = self._settings(cam, N)
-        out = nat.SgrOutputs(vb.color.data_ptr(), vb.depth.data_ptr(), vb.opacity.data_ptr(), vb.radii.data_ptr(),
-                             vb.n_touched.data_ptr())
+        out = nat.SgrOutputs(vb.color.data_ptr() if images else None, vb.depth.data_ptr() if images else None,
+                             vb.opacity.data_ptr() if images else None, vb.radii.data_ptr(), vb.n_touched.data_ptr())
         ws = self._workspace(vb, N, H, W, self._cap)
         mv = nat.SgrMapView()
         mv.settings, mv.out, mv.ws = s, out, ws
@@ -264,10 +268,10 @@ class FusedMappingLoop(MappingLoop):
         mv.dL_dexposure = vb.d_exp.data_ptr() if row is None else self._exp.grad.data_ptr() + 8 * row
         mv.dL_dtau = vb.d_tau.data_ptr() if self.keyframe_optimizers is not None else None
         mv.loss_scratch, mv.loss_scratch_bytes = vb.loss_scratch.data_ptr(), vb.loss_scratch.numel()
-        vb.mv, vb.mv_key = mv, key
+        vb.mv[images] = (key, mv)
         return mv
 
-    def _views_array(self, cams, initialization):
+    def _views_array(self, cams, initialization, images=True):
         n = len(cams)
         need = self._cap
         for c in cams:                                # cameras new at this map size: learn their pair count once
@@ -278,7 +282,7 @@ class FusedMappingLoop(MappingLoop):
         if need != self._cap:                         # ONE capacity for all cameras: batched launches share a layout
             self._cap = need
             self._views_dirty()
-        return (nat.SgrMapView * n)(*[self._map_view(c, initialization) for c in cams])
+        return (nat.SgrMapView * n)(*[self._map_view(c, initialization, images) for c in cams])
 
     def _plan(self):
         """Structs that only change when the parameter tensors do (new N, opacity reset, ...)."""
@@ -363,8 +367,8 @@ class FusedMappingLoop(MappingLoop):
             raise RuntimeError("_run_span is the single-GPU fast path")
         pl = self._plan()
         self._views_array(list(window_cams) + list(pool_cams), False)      # probes new cameras, settles the capacity
-        win = self._views_array(window_cams, False) if window_cams else None
-        pool = self._views_array(pool_cams, False) if pool_cams else None
+        win = self._views_array(window_cams, False, images=False) if window_cams else None
+        pool = self._views_array(pool_cams, False, images=False) if pool_cams else None
         st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
         per = len(picks) // n_it if picks else 0
         run = nat.SgrMapRun()
@@ -377,6 +381,7 @@ class FusedMappingLoop(MappingLoop):
         pk = (C.c_int32 * max(1, len(picks)))(*picks)
         lr = (C.c_float * n_it)(*lrs)
         run.picks, run.lr0, run.adam_groups = pk, lr, pl.groups
+        run.n_touched_last_only = 1
         rows = None
         if exposure == "per_pick":
             rows = (C.c_int32 * max(1, len(pool_cams)))(*[
@@ -510,7 +515,7 @@ class FusedMappingLoop(MappingLoop):
         self._since_check = 0
         worst = 0
         for uid, vb in self._views.items():
-            if vb.saved is None or vb.mv is None:
+            if vb.saved is None or not vb.mv:
                 continue
             R, ov = C.c_int64(0), C.c_int32(0)
             nat.check(self.lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), self._stream()), "sgr_query")
