@@ -20,6 +20,8 @@
 //     waste lanes: with <= 16 (<= 32) splats the wave processes 4 (2) pixels at once, one per 16- (32-)lane group.
 //     Each (tile, splat) pair writes its 48-byte partial to a slot owned by the Gaussian: no atomics, bitwise
 //     run-to-run deterministic; preprocess_bwd gathers the slots in fixed order.
+#include <type_traits>
+
 #include "sgr_common.h"
 
 namespace sgr {
@@ -380,6 +382,143 @@ __device__ __forceinline__ void bwd_chunk(
   }
 }
 
+// The hot loop of the backward, TWO pixels per lane.  blend_bwd is bound by VALU issue (one wave64 op = 4 cycles), and
+// gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot), so every lane carries its splat
+// against a horizontally adjacent pixel PAIR in 2-vectors: the quadratic form, the colour dot product, alpha*T and all
+// ten accumulate FMAs issue once per pair; only the DPP scans, exp/rcp and the selects stay per pixel.  Every packed op
+// is the same IEEE operation sequence as eval_alpha(), so forward and backward still agree bit for bit on which pairs
+// contribute.  Branch free: a pair that does not contribute has alpha*T = 0 and G*dL/dalpha = 0.
+// (A matrix-core variant -- the 16-lane-group layout is exactly the A/B operand layout of v_mfma_f32_16x16x4_f32, the
+// ten sums being two small GEMMs over the pixels -- cut the instruction count by 20 % but ran 8 % slower: fp32 MFMA
+// passes contend with the VALU work of the other waves of the SIMD.)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
+
+// pixel pair g (0..31) of a tile for group width GW:  p0 = 2*PP*(g/PP) + g%PP,  p1 = p0 + PP   (PP = 64/GW)
+template <int GW>
+__device__ __forceinline__ int pair_first_pixel(int g) {
+  constexpr int PP = kWave / GW;
+  return 2 * PP * (g / PP) + (g % PP);
+}
+
+// One chunk of <= GW splats against the 64 pixels of the tile, 2*64/GW pixels per iteration.
+// Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix scan.
+// LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | nc0,nc1, -,-) for pair g.
+template <int GW>
+__device__ __forceinline__ void bwd_chunk2(
+    int lane, int c, int eff, int64_t begin, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/,
+    const uint32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
+    const float4* __restrict__ rgbd, const ushort4* __restrict__ rect, const char* __restrict__ saved, const LOff& L,
+    int tx, int ty, float halfW, float halfH, float4* __restrict__ partials, int64_t cap) {
+  constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
+  const int sub = lane / GW;                     // which of them this lane works on
+  const int sl = lane % GW;
+  const int idx = c * GW + (GW - 1 - sl);        // list position of this lane's splat
+  const bool valid = idx < eff;
+  uint32_t g = 0;
+  float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
+  uint32_t slot = 0xffffffffu;                   // this (tile, Gaussian) pair's slot inside the Gaussian's run of partials
+  if (valid) {
+    g = point_list[begin + idx];
+    // everything that depends on g in ONE round trip (the slot is only needed after the loop, its latency is not)
+    float2 m = xy[g];
+    float4 co = conic_o[g];
+    float4 cd = rgbd[g];
+    ushort4 r = rect[g];
+    uint64_t sl64 = (uint64_t)abs_offset(saved, L, g) + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
+    if ((int64_t)sl64 < cap) slot = (uint32_t)sl64;
+    mx = m.x; my = m.y; A = co.x; B = co.y; Cc = co.z; op = co.w; cr = cd.x; cg = cd.y; cb = cd.z; dep = cd.w;
+  }
+  v2f s_gx = {0.f, 0.f}, s_gy = {0.f, 0.f}, s_gxx = {0.f, 0.f}, s_gxy = {0.f, 0.f}, s_gyy = {0.f, 0.f};
+  v2f a_o = {0.f, 0.f}, a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
+
+#pragma unroll 1
+  for (int it = 0; it < 32 / PP; ++it) {
+    const int gp = it * PP + sub;                // this lane's pixel pair (same for the whole group)
+    const float4 a0 = pixA2[gp * 2], a1 = pixA2[gp * 2 + 1];     // LDS, broadcast inside the group
+    const float4 b0 = pixB2[gp * 2];
+    const float2 b1 = *(const float2*)&pixB2[gp * 2 + 1];
+    const int nc0 = __float_as_int(b1.x), nc1 = __float_as_int(b1.y);
+    if (GW == kWave && __builtin_amdgcn_readfirstlane(max(nc0, nc1)) <= c * kWave) continue;   // both ended before this chunk
+    const int p0 = pair_first_pixel<GW>(gp);
+    const float pxf = tx0 + (float)(p0 & 7);
+    const v2f dx = splat2(mx) - (v2f){pxf, pxf + (float)PP};
+    const float dy = my - (ty0 + (float)(p0 >> 3));
+    // eval_alpha() on the pair, same operation order
+    const v2f adx = splat2(A) * dx;
+    const float cdy2 = (Cc * dy) * dy;
+    const v2f qf = __builtin_elementwise_fma(adx, dx, splat2(cdy2));
+    const v2f bdxdy = (splat2(B) * dx) * splat2(dy);
+    const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
+    const v2f G = {__expf(power.x), __expf(power.y)};
+    const v2f og = splat2(op) * G;
+    const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
+    const bool ok0 = valid && (idx < nc0) && (power.x <= 0.0f) && (alpha.x >= kAlphaMin);
+    const bool ok1 = valid && (idx < nc1) && (power.y <= 0.0f) && (alpha.y >= kAlphaMin);
+    const v2f one_m = splat2(1.f) - alpha;
+    const float P0 = group_scan_mul<GW>(ok0 ? one_m.x : 1.f);      // prod over this splat and all behind it (in chunk)
+    const float P1 = group_scan_mul<GW>(ok1 ? one_m.y : 1.f);
+    const v2f E = {group_shr1<GW>(P0, 1.f, lane), group_shr1<GW>(P1, 1.f, lane)};   // prod over all strictly behind it
+    const v2f rP = {__builtin_amdgcn_rcpf(P0), __builtin_amdgcn_rcpf(P1)};
+    const v2f Tj = (v2f){b0.x, b0.y} * rP;               // transmittance in front of splat j
+    const v2f inv1ma = E * rP;                           // 1 / (1 - alpha_j)
+    const v2f dCr = {a0.x, a0.y}, dCg = {a0.z, a0.w}, dCb = {a1.x, a1.y}, dD = {a1.z, a1.w};
+    const v2f w = __builtin_elementwise_fma(dCr, splat2(cr), __builtin_elementwise_fma(dCg, splat2(cg),
+                  __builtin_elementwise_fma(dCb, splat2(cb), dD * splat2(dep))));
+    v2f aT = alpha * Tj;
+    aT.x = ok0 ? aT.x : 0.f;
+    aT.y = ok1 ? aT.y : 0.f;
+    const v2f q = w * aT;
+    const v2f Qi = {group_scan_add<GW>(q.x), group_scan_add<GW>(q.y)};   // inclusive: this splat and all behind it
+    const v2f Sc = {b0.z, b0.w};
+    const v2f Sx = (Qi - q) + Sc;                        // strictly behind (+ carried chunks + background term)
+    const v2f dL_dalpha = __builtin_elementwise_fma(Tj, w, -(Sx * inv1ma));
+    if (GW == kWave) {
+      // carry to the next (nearer) chunk: the last lane holds the nearest splat of this chunk
+      if (lane == kWave - 1) {
+        const v2f S2 = Qi + Sc;
+        pixB2[gp * 2] = make_float4(Tj.x, Tj.y, S2.x, S2.y);
+      }
+    }
+    a_r = __builtin_elementwise_fma(aT, dCr, a_r);
+    a_g = __builtin_elementwise_fma(aT, dCg, a_g);
+    a_b = __builtin_elementwise_fma(aT, dCb, a_b);
+    a_d = __builtin_elementwise_fma(aT, dD, a_d);
+    v2f gd = G * dL_dalpha;                              // dL/dopacity contribution; alpha clamp is straight-through
+    gd.x = ok0 ? gd.x : 0.f;
+    gd.y = ok1 ? gd.y : 0.f;
+    a_o += gd;
+    const v2f gg = gd * splat2(op);                      // G * dL/dG
+    const v2f gxv = gg * dx, gyv = gg * splat2(dy);
+    s_gx += gxv;
+    s_gy += gyv;
+    s_gxx = __builtin_elementwise_fma(gxv, dx, s_gxx);
+    s_gxy = __builtin_elementwise_fma(gxv, splat2(dy), s_gxy);
+    s_gyy = __builtin_elementwise_fma(gyv, splat2(dy), s_gyy);
+  }
+  float t_gx = s_gx.x + s_gx.y, t_gy = s_gy.x + s_gy.y, t_gxx = s_gxx.x + s_gxx.y, t_gxy = s_gxy.x + s_gxy.y,
+        t_gyy = s_gyy.x + s_gyy.y, t_o = a_o.x + a_o.y, t_r = a_r.x + a_r.y, t_g = a_g.x + a_g.y, t_b = a_b.x + a_b.y,
+        t_d = a_d.x + a_d.y;
+  if (GW < kWave) {
+    // the PP groups saw disjoint pixels: add them up (fixed order), result valid in every group
+#pragma unroll
+    for (int off = GW; off < kWave; off <<= 1) {
+      t_gx += __shfl_xor(t_gx, off); t_gy += __shfl_xor(t_gy, off); t_gxx += __shfl_xor(t_gxx, off);
+      t_gxy += __shfl_xor(t_gxy, off); t_gyy += __shfl_xor(t_gyy, off); t_o += __shfl_xor(t_o, off);
+      t_r += __shfl_xor(t_r, off); t_g += __shfl_xor(t_g, off); t_b += __shfl_xor(t_b, off); t_d += __shfl_xor(t_d, off);
+    }
+  }
+  if (sub == 0 && slot != 0xffffffffu) {
+    {
+      float dmx = (-(A * t_gx) - B * t_gy) * halfW;
+      float dmy = (-(Cc * t_gy) - B * t_gx) * halfH;
+      partials[(size_t)slot * 3 + 0] = make_float4(dmx, dmy, -0.5f * t_gxx, -t_gxy);
+      partials[(size_t)slot * 3 + 1] = make_float4(-0.5f * t_gyy, t_o, t_r, t_g);
+      partials[(size_t)slot * 3 + 2] = make_float4(t_b, t_d, 0.f, 0.f);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg) {
   const int vw = blockIdx.y;
   const char* saved = tab.saved[vw];
@@ -405,6 +544,18 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
   if (tx >= gx || ty >= gy) return;
   const int tile = ty * gx + tx;
+  // this pixel's state first: its six loads do not depend on the tile's list and overlap the range / list round trips
+  float pxA[4] = {0.f, 0.f, 0.f, 0.f}, pxB[3] = {1.f, 0.f, 0.f};
+  {
+    const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+    if (px < W && py < H) {
+      const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+      pxA[0] = dL_dcolor[pix]; pxA[1] = dL_dcolor[hw + pix]; pxA[2] = dL_dcolor[2 * hw + pix];
+      pxA[3] = dL_ddepth ? dL_ddepth[pix] : 0.f;
+      pxB[0] = final_T[pix];
+      pxB[2] = __int_as_float((int)n_contrib[pix]);
+    }
+  }
   const uint2 rng = ranges[(size_t)tile * kRngStride];
   const int64_t begin = rng.x;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
@@ -425,42 +576,39 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   }
   if (eff == 0) return;
 
-  // pixel state into the wave's LDS slice (lane p = pixel p of the tile)
+  // pixel state into the wave's LDS slice
   float4* pixA = pixbuf[wv][0];
   float4* pixB = pixbuf[wv][1];
-  {
-    const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
-    float dCr = 0.f, dCg = 0.f, dCb = 0.f, dD = 0.f, Tc = 1.f, Sc = 0.f;
-    int ncont = 0;
-    if (inside) {
-      dCr = dL_dcolor[pix]; dCg = dL_dcolor[hw + pix]; dCb = dL_dcolor[2 * hw + pix];
-      dD = dL_ddepth ? dL_ddepth[pix] : 0.f;
-      Tc = final_T[pix];
-      ncont = (int)n_contrib[pix];
-      // the background term -T_final/(1-alpha_j) * (bg . dL/dC) has the same shape as "colour behind splat j"
-      Sc = Tc * (bg[0] * dCr + bg[1] * dCg + bg[2] * dCb);
-    }
-    pixA[lane] = make_float4(dCr, dCg, dCb, dD);
-    pixB[lane] = make_float4(Tc, Sc, __int_as_float(ncont), 0.f);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  // the background term -T_final/(1-alpha_j) * (bg . dL/dC) has the same shape as "colour behind splat j"
+  pxB[1] = pxB[0] * (bg[0] * pxA[0] + bg[1] * pxA[1] + bg[2] * pxA[2]);
+  // pair layout depends on the group width (see bwd_chunk2): pixel p -> pair g, half h
+  auto stage = [&](auto gw_tag) {
+    constexpr int GW = decltype(gw_tag)::value, PP = kWave / GW;
+    const int q2 = lane % (2 * PP), h = q2 / PP, gidx = (lane / (2 * PP)) * PP + (q2 % PP);
+    float* fa = (float*)pixA + gidx * 8 + h;
+    float* fb = (float*)pixB + gidx * 8 + h;
+    fa[0] = pxA[0]; fa[2] = pxA[1]; fa[4] = pxA[2]; fa[6] = pxA[3];
+    fb[0] = pxB[0]; fb[2] = pxB[1]; fb[4] = pxB[2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
   const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
 
   if (eff <= 16) {
-    bwd_chunk<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty, halfW,
-                  halfH, partials, cap);
+    stage(std::integral_constant<int, 16>{});
+    bwd_chunk2<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty, halfW,
+                   halfH, partials, cap);
   } else if (eff <= 32) {
-    bwd_chunk<32>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty, halfW,
-                  halfH, partials, cap);
+    stage(std::integral_constant<int, 32>{});
+    bwd_chunk2<32>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty, halfW,
+                   halfH, partials, cap);
   } else {
+    stage(std::integral_constant<int, 64>{});
     const int nchunks = (eff + kWave - 1) / kWave;
     for (int c = nchunks - 1; c >= 0; --c) {
-      bwd_chunk<64>(lane, c, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty,
-                    halfW, halfH, partials, cap);
+      bwd_chunk2<64>(lane, c, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty,
+                     halfW, halfH, partials, cap);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
