@@ -37,8 +37,8 @@ def trace(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--camera", default="metric", choices=["metric", "replica", "tiny"])
     ap.add_argument("--views", type=int, default=16, help="keyframes in the map (10 window + pool of random views)")

@@ -148,8 +148,8 @@ __global__ void __launch_bounds__(256) activate_kernel(int64_t n, const float* _
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (s_out) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s_out[3 * i + k] = expf(scaling[3 * i + k]);
+    const F3 sc = ld3(scaling + 3 * i);
+    st3(s_out + 3 * i, F3{expf(sc.x), expf(sc.y), expf(sc.z)});
   }
   if (r_out) {
     float4 q = *(const float4*)(rotation + 4 * i);
@@ -185,19 +185,28 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
   // every product and sum below is rounded on its own: the three instantiations (and the separate activate_kernel)
   // must agree bit for bit, which fused multiply-adds chosen per instantiation would not guarantee
 #pragma clang fp contract(off)
-  // xyz and f_dc: identity activations
+  // xyz and f_dc: identity activations.  (3-float rows move as one 12-byte access per array: three dword accesses with a
+  // 12-byte lane stride use a third of every cache line they touch)
 #pragma unroll
   for (int grp = 0; grp < 2; ++grp) {
     const SgrAdamGroup& A = G.g[grp];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      int64_t j = 3 * i + k;
-      float g = take_grad<MODE>(A.grad, j, e[3 * grp + k]);
-      if (A.skip) continue;
-      float p = A.param[j], m = A.exp_avg[j], v = A.exp_avg_sq[j];
-      adam_update(p, g, m, v, grp, c);
-      A.param[j] = p; A.exp_avg[j] = m; A.exp_avg_sq[j] = v;
+    float g[3];
+    if (MODE == 2) {
+      g[0] = e[3 * grp]; g[1] = e[3 * grp + 1]; g[2] = e[3 * grp + 2];
+    } else {
+      F3 gs = ld3(A.grad + 3 * i);
+      st3(A.grad + 3 * i, F3{0.f, 0.f, 0.f});
+      g[0] = gs.x; g[1] = gs.y; g[2] = gs.z;
+      if (MODE == 1) { g[0] = g[0] + e[3 * grp]; g[1] = g[1] + e[3 * grp + 1]; g[2] = g[2] + e[3 * grp + 2]; }
     }
+    if (A.skip) continue;
+    F3 p3 = ld3(A.param + 3 * i), m3 = ld3(A.exp_avg + 3 * i), v3 = ld3(A.exp_avg_sq + 3 * i);
+    float p[3] = {p3.x, p3.y, p3.z}, m[3] = {m3.x, m3.y, m3.z}, v[3] = {v3.x, v3.y, v3.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) adam_update(p[k], g[k], m[k], v[k], grp, c);
+    st3(A.param + 3 * i, F3{p[0], p[1], p[2]});
+    st3(A.exp_avg + 3 * i, F3{m[0], m[1], m[2]});
+    st3(A.exp_avg_sq + 3 * i, F3{v[0], v[1], v[2]});
   }
   {   // opacity: sigmoid
     const SgrAdamGroup& A = G.g[2];
@@ -213,26 +222,37 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
   }
   {   // scaling: exp, plus d/ds of iso_weight * mean_{N,3} |s - mean_3(s)|
     const SgrAdamGroup& A = G.g[3];
-    float p[3], s[3];
+    const F3 p3 = ld3(A.param + 3 * i);
+    float p[3] = {p3.x, p3.y, p3.z}, s[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { p[k] = A.param[3 * i + k]; s[k] = expf(p[k]); }
+    for (int k = 0; k < 3; ++k) s[k] = expf(p[k]);
     float mean = (s[0] + s[1] + s[2]) / 3.f;
     float sg[3], ssum = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { float d = s[k] - mean; sg[k] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); ssum += sg[k]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      int64_t j = 3 * i + k;
-      float gs = take_grad<MODE>(A.grad, j, e[7 + k]) + iso_coef * (sg[k] - ssum / 3.f);
-      float g = gs * s[k];
-      if (!A.skip) {
-        float pp = p[k], m = A.exp_avg[j], v = A.exp_avg_sq[j];
-        adam_update(pp, g, m, v, 3, c);
-        A.param[j] = pp; A.exp_avg[j] = m; A.exp_avg_sq[j] = v;
-        p[k] = pp;
-      }
-      if (MODE != 0 && s_out) s_out[j] = expf(p[k]);
+    float gin[3];
+    if (MODE == 2) {
+      gin[0] = e[7]; gin[1] = e[8]; gin[2] = e[9];
+    } else {
+      F3 gs = ld3(A.grad + 3 * i);
+      st3(A.grad + 3 * i, F3{0.f, 0.f, 0.f});
+      gin[0] = gs.x; gin[1] = gs.y; gin[2] = gs.z;
+      if (MODE == 1) { gin[0] = gin[0] + e[7]; gin[1] = gin[1] + e[8]; gin[2] = gin[2] + e[9]; }
     }
+    if (!A.skip) {
+      F3 m3 = ld3(A.exp_avg + 3 * i), v3 = ld3(A.exp_avg_sq + 3 * i);
+      float m[3] = {m3.x, m3.y, m3.z}, v[3] = {v3.x, v3.y, v3.z};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float gs = gin[k] + iso_coef * (sg[k] - ssum / 3.f);
+        float g = gs * s[k];
+        adam_update(p[k], g, m[k], v[k], 3, c);
+      }
+      st3(A.param + 3 * i, F3{p[0], p[1], p[2]});
+      st3(A.exp_avg + 3 * i, F3{m[0], m[1], m[2]});
+      st3(A.exp_avg_sq + 3 * i, F3{v[0], v[1], v[2]});
+    }
+    if (MODE != 0 && s_out) st3(s_out + 3 * i, F3{expf(p[0]), expf(p[1]), expf(p[2])});
   }
   {   // rotation: x / max(|x|, 1e-12)
     const SgrAdamGroup& A = G.g[4];

@@ -213,6 +213,11 @@ __device__ __forceinline__ uint32_t abs_offset(const char* saved, const LOff& L,
   return ((const uint32_t*)(saved + L.o_offsets))[g] + ((const uint32_t*)(saved + L.o_block_base_t))[g >> kSegShift];
 }
 
+// 3-float rows as ONE 12-byte access (three dword accesses with a 12-byte lane stride use a third of each cache line)
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3(const float* p) { return *(const F3*)p; }
+__device__ __forceinline__ void st3(float* p, F3 v) { *(F3*)p = v; }
+
 // ---- tiny fixed-size linear algebra on registers
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {

@@ -296,12 +296,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     float p[3] = {0.f, 0.f, 0.f};
     float trS = 0.f;
     if (ia < N) {
-      p[0] = means3D[3 * ia]; p[1] = means3D[3 * ia + 1]; p[2] = means3D[3 * ia + 2];
+      { const F3 t = ld3(means3D + 3 * ia); p[0] = t.x; p[1] = t.y; p[2] = t.z; }
       if (cov3D_precomp) {
         trS = cov3D_precomp[6 * ia] + cov3D_precomp[6 * ia + 3] + cov3D_precomp[6 * ia + 5];
       } else {
-        const float s0 = scales[3 * ia], s1 = scales[3 * ia + 1], s2 = scales[3 * ia + 2];
-        const float4 q = make_float4(rotations[4 * ia], rotations[4 * ia + 1], rotations[4 * ia + 2], rotations[4 * ia + 3]);
+        const F3 sc3 = ld3(scales + 3 * ia);
+        const float s0 = sc3.x, s1 = sc3.y, s2 = sc3.z;
+        const float4 q = *(const float4*)(rotations + 4 * ia);
         const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
         if (fabsf(n2 - 1.f) < 1e-3f) {     // R(q) = (1-n2) I + n2 R(q/|q|): column norms <= 1.002
           trS = cm.mod * cm.mod * (s0 * s0 + s1 * s1 + s2 * s2) * 1.01f;
@@ -368,14 +369,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
 #pragma unroll
       for (int k = 0; k < 16; ++k) { vm[k] = mats[v][k]; pm[k] = mats[v][16 + k]; }
       PreIn in;
-      in.p[0] = means3D[3 * i]; in.p[1] = means3D[3 * i + 1]; in.p[2] = means3D[3 * i + 2];
+      { const F3 t = ld3(means3D + 3 * i); in.p[0] = t.x; in.p[1] = t.y; in.p[2] = t.z; }
       in.opac = opacities[i];
       if (cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) in.S6[k] = cov3D_precomp[6 * i + k];
       } else {
-        float s_in[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-        float q_in[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        const F3 sc3 = ld3(scales + 3 * i);
+        const float4 q4 = *(const float4*)(rotations + 4 * i);
+        float s_in[3] = {sc3.x, sc3.y, sc3.z};
+        float q_in[4] = {q4.x, q4.y, q4.z, q4.w};
         cov3d_from_scale_rot(s_in, cm.mod, q_in, in.S6);
       }
       in.c_in[0] = in.c_in[1] = in.c_in[2] = 0.f;
