@@ -180,24 +180,31 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < n; ++j) {
-      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-      float4 e0 = lds[j * 3 + 0], e1 = lds[j * 3 + 1], e2 = lds[j * 3 + 2];
-      AlphaEval a = eval_alpha(e0.x - pxf, e0.y - pyf, e0.z, e0.w, e1.x, e1.y);
-      float testT = T * (1.f - a.alpha);
-      bool live = !done && a.ok;
-      bool term = live && (testT < kTEps);
-      bool comp = live && !term;
-      done = done || term;
-      float w = comp ? a.alpha * T : 0.f;
-      C0 = __fmaf_rn(e2.x, w, C0);
-      C1 = __fmaf_rn(e2.y, w, C1);
-      C2 = __fmaf_rn(e2.z, w, C2);
-      D = __fmaf_rn(e1.z, w, D);
-      unsigned long long tm = __builtin_amdgcn_ballot_w64(comp && testT > kTouchedT);
-      if (n_touched && tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(e1.w)], (int)__popcll(tm));
-      if (comp) { T = testT; last = (uint32_t)(base + j + 1); }
-    }
+    // branch-free body (selects, no divergent control flow); the "every pixel finished" exit is polled every 4 splats
+    auto walk = [&](auto count_touched) {
+      for (int j = 0; j < n; ++j) {
+        if ((j & 3) == 0 && __builtin_amdgcn_ballot_w64(!done) == 0) break;
+        float4 e0 = lds[j * 3 + 0], e1 = lds[j * 3 + 1], e2 = lds[j * 3 + 2];
+        AlphaEval a = eval_alpha(e0.x - pxf, e0.y - pyf, e0.z, e0.w, e1.x, e1.y);
+        const float testT = T * (1.f - a.alpha);
+        const bool live = !done && a.ok;
+        const bool term = live && (testT < kTEps);
+        const bool comp = live && !term;
+        done = done || term;
+        const float w = comp ? a.alpha * T : 0.f;
+        C0 = __fmaf_rn(e2.x, w, C0);
+        C1 = __fmaf_rn(e2.y, w, C1);
+        C2 = __fmaf_rn(e2.z, w, C2);
+        D = __fmaf_rn(e1.z, w, D);
+        if (decltype(count_touched)::value) {
+          unsigned long long tm = __builtin_amdgcn_ballot_w64(comp && testT > kTouchedT);
+          if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(e1.w)], (int)__popcll(tm));
+        }
+        T = comp ? testT : T;
+        last = comp ? (uint32_t)(base + j + 1) : last;
+      }
+    };
+    if (n_touched) walk(std::true_type{}); else walk(std::false_type{});
     __builtin_amdgcn_wave_barrier();
     if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
   }
