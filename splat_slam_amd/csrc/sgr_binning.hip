@@ -91,21 +91,24 @@ __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
     const uint32_t k = t - (j == 0 ? 0u : (j == 1 ? e1 : (j == 2 ? e2 : e3)));
     const uint32_t i = ((const uint32_t*)(saved + L.o_seg_list))[(s0 + j) * kSeg + k];
     const uint32_t vp = (j == 0 ? b[0] : (j == 1 ? b[1] : (j == 2 ? b[2] : b[3]))) + k;
-    ((uint32_t*)(saved + L.o_vis_pos))[i] = vp;
+    GRec* rec = (GRec*)(saved + L.o_grec) + i;
+    const float4 q0 = ((const float4*)rec)[0];
+    const uint32_t dbits = __float_as_uint(rec->depth);
+    const int cnt = (int)rec->touched;
+    rec->vis_pos = vp;
     ((uint32_t*)(saved + L.o_vis_list))[vp] = i;
-    const int cnt = (int)((const uint32_t*)(saved + L.o_touched))[i];
     if (cnt == 0) continue;
-    ushort4 r = ((const ushort4*)(saved + L.o_rect))[i];
-    uint64_t key = ((uint64_t)__float_as_uint(((const float4*)(saved + L.o_rgbd))[i].w) << 32) | i;
-    const int w = (int)r.z - (int)r.x;
+    const Rect r = unpack_rect(__float_as_uint(q0.z), __float_as_uint(q0.w));
+    uint64_t key = ((uint64_t)dbits << 32) | i;
+    const int w = r.x1 - r.x0;
     // returning atomics are latency-bound: keep 4 in flight (most splats cover <= 4 bins)
     for (int k0 = 0; k0 < cnt; k0 += 4) {
       uint32_t pos[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         int kk = k0 + jj;
-        if (kk < cnt) pos[jj] = (L.dbg & 8) ? ranges[(size_t)(((int)r.y + kk / w) * L.gx + (int)r.x + kk % w) * kRngStride].x + (i & 7u)
-                                            : atomicAdd(&ranges[(size_t)(((int)r.y + kk / w) * L.gx + (int)r.x + kk % w) * kRngStride].y, 1u);
+        if (kk < cnt) pos[jj] = (L.dbg & 8) ? ranges[(size_t)((r.y0 + kk / w) * L.gx + r.x0 + kk % w) * kRngStride].x + (i & 7u)
+                                            : atomicAdd(&ranges[(size_t)((r.y0 + kk / w) * L.gx + r.x0 + kk % w) * kRngStride].y, 1u);
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)

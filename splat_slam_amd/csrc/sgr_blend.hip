@@ -91,9 +91,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
   uint64_t* __restrict__ entries = (uint64_t*)(tab.scratch[vw] + L.o_entries);
   uint32_t* __restrict__ point_list = (uint32_t*)(saved + L.o_point_list);
-  const float2* __restrict__ xy = (const float2*)(saved + L.o_xy);
-  const float4* __restrict__ conic_o = (const float4*)(saved + L.o_conic_o);
-  const float4* __restrict__ rgbd = (const float4*)(saved + L.o_rgbd);
+  const GRec* __restrict__ grec = grec_of(saved, L);
   float* __restrict__ out_color = tab.color[vw];
   float* __restrict__ out_depth = tab.depth[vw];
   float* __restrict__ out_opacity = tab.opacity[vw];
@@ -171,9 +169,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
       if (mode == 0) g = g_first;
       else if (mode == 1) g = (uint32_t)keys[base + lane];
       else g = (uint32_t)__hip_atomic_load(entries + begin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      float2 m = xy[g];
-      float4 co = conic_o[g];
-      float4 cd = rgbd[g];
+      const float4* rec = (const float4*)(grec + g);       // one 64-byte record: centre | conic, opacity | colour, depth
+      float4 m = rec[0];
+      float4 co = rec[1];
+      float4 cd = rec[2];
       lds[lane * 3 + 0] = make_float4(m.x, m.y, co.x, co.y);
       lds[lane * 3 + 1] = make_float4(co.z, co.w, cd.w, __uint_as_float(g));
       lds[lane * 3 + 2] = make_float4(cd.x, cd.y, cd.z, 0.f);
@@ -300,95 +299,6 @@ __device__ __forceinline__ float group_shr1(float v, float fill, int lane) {
   return r;
 }
 
-// One chunk of <= GW splats against the 64 pixels of the tile, 64/GW pixels per iteration.
-// Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix scan.
-template <int GW>
-__device__ __forceinline__ void bwd_chunk(
-    int lane, int c, int eff, int64_t begin, float tx0, float ty0, const float4* pixA /*LDS*/, float4* pixB /*LDS*/,
-    const uint32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
-    const float4* __restrict__ rgbd, const ushort4* __restrict__ rect, const char* __restrict__ saved, const LOff& L,
-    int tx, int ty, float halfW, float halfH, float4* __restrict__ partials, int64_t cap) {
-  constexpr int PP = kWave / GW;                 // pixels processed per iteration
-  const int sub = lane / GW;                     // which of them this lane works on
-  const int sl = lane % GW;
-  const int idx = c * GW + (GW - 1 - sl);        // list position of this lane's splat
-  const bool valid = idx < eff;
-  uint32_t g = 0;
-  float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
-  if (valid) {
-    g = point_list[begin + idx];
-    float2 m = xy[g];
-    float4 co = conic_o[g];
-    float4 cd = rgbd[g];
-    mx = m.x; my = m.y; A = co.x; B = co.y; Cc = co.z; op = co.w; cr = cd.x; cg = cd.y; cb = cd.z; dep = cd.w;
-  }
-  float s_gx = 0.f, s_gy = 0.f, s_gxx = 0.f, s_gxy = 0.f, s_gyy = 0.f;
-  float a_o = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
-
-#pragma unroll 2
-  for (int it = 0; it < kWave / PP; ++it) {
-    const int p = it * PP + sub;                 // this lane's pixel (same for the whole group)
-    const float4 pa = pixA[p];                   // dCr, dCg, dCb, dD     (LDS, broadcast inside the group)
-    const float4 pb = pixB[p];                   // T carry, S carry, n_contrib bits, -
-    const int nc = __float_as_int(pb.z);
-    if (GW == kWave && __builtin_amdgcn_readfirstlane(nc) <= c * kWave) continue;   // pixel ended before this chunk
-    const float dx = mx - (tx0 + (float)(p & 7)), dy = my - (ty0 + (float)(p >> 3));
-    AlphaEval a = eval_alpha(dx, dy, A, B, Cc, op);
-    const bool ok = valid && (idx < nc) && a.ok;
-    const float om = ok ? 1.f - a.alpha : 1.f;
-    const float P = group_scan_mul<GW>(om);          // prod over this splat and all behind it (in chunk)
-    const float E = group_shr1<GW>(P, 1.f, lane);    // prod over all strictly behind it
-    const float rP = __builtin_amdgcn_rcpf(P);
-    const float Tj = pb.x * rP;                      // transmittance in front of splat j
-    const float inv1ma = E * rP;                     // 1 / (1 - alpha_j)
-    const float w = __fmaf_rn(pa.x, cr, __fmaf_rn(pa.y, cg, __fmaf_rn(pa.z, cb, pa.w * dep)));
-    const float aT = ok ? a.alpha * Tj : 0.f;
-    const float q = w * aT;
-    const float Qi = group_scan_add<GW>(q);          // inclusive: this splat and all behind it
-    const float Sx = (Qi - q) + pb.y;                // strictly behind (+ carried chunks + background term)
-    const float dL_dalpha = __fmaf_rn(Tj, w, -Sx * inv1ma);
-    if (GW == kWave) {
-      // carry to the next (nearer) chunk: the last lane holds the nearest splat of this chunk
-      if (lane == kWave - 1) pixB[p] = make_float4(Tj, Qi + pb.y, pb.z, 0.f);
-    }
-    if (ok) {
-      a_r = __fmaf_rn(aT, pa.x, a_r);
-      a_g = __fmaf_rn(aT, pa.y, a_g);
-      a_b = __fmaf_rn(aT, pa.z, a_b);
-      a_d = __fmaf_rn(aT, pa.w, a_d);
-      const float gd = a.G * dL_dalpha;              // dL/dopacity contribution; alpha clamp is straight-through
-      a_o += gd;
-      const float gg = gd * op;                      // G * dL/dG
-      const float gxv = gg * dx, gyv = gg * dy;
-      s_gx += gxv; s_gy += gyv;
-      s_gxx = __fmaf_rn(gxv, dx, s_gxx);
-      s_gxy = __fmaf_rn(gxv, dy, s_gxy);
-      s_gyy = __fmaf_rn(gyv, dy, s_gyy);
-    }
-  }
-  if (GW < kWave) {
-    // the PP groups saw disjoint pixels: add them up (fixed order), result valid in every group
-#pragma unroll
-    for (int off = GW; off < kWave; off <<= 1) {
-      s_gx += __shfl_xor(s_gx, off); s_gy += __shfl_xor(s_gy, off); s_gxx += __shfl_xor(s_gxx, off);
-      s_gxy += __shfl_xor(s_gxy, off); s_gyy += __shfl_xor(s_gyy, off); a_o += __shfl_xor(a_o, off);
-      a_r += __shfl_xor(a_r, off); a_g += __shfl_xor(a_g, off); a_b += __shfl_xor(a_b, off); a_d += __shfl_xor(a_d, off);
-    }
-  }
-  if (valid && sub == 0) {
-    // slot of this (tile, Gaussian) pair inside the Gaussian's own run of partials
-    ushort4 r = rect[g];
-    uint64_t slot = (uint64_t)abs_offset(saved, L, g) + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
-    if ((int64_t)slot < cap) {
-      float dmx = (-(A * s_gx) - B * s_gy) * halfW;
-      float dmy = (-(Cc * s_gy) - B * s_gx) * halfH;
-      partials[slot * 3 + 0] = make_float4(dmx, dmy, -0.5f * s_gxx, -s_gxy);
-      partials[slot * 3 + 1] = make_float4(-0.5f * s_gyy, a_o, a_r, a_g);
-      partials[slot * 3 + 2] = make_float4(a_b, a_d, 0.f, 0.f);
-    }
-  }
-}
-
 // The hot loop of the backward, TWO pixels per lane.  blend_bwd is bound by VALU issue (one wave64 op = 4 cycles), and
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot), so every lane carries its splat
 // against a horizontally adjacent pixel PAIR in 2-vectors: the quadratic form, the colour dot product, alpha*T and all
@@ -414,8 +324,7 @@ __device__ __forceinline__ int pair_first_pixel(int g) {
 template <int GW>
 __device__ __forceinline__ void bwd_chunk2(
     int lane, int c, int eff, int64_t begin, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/,
-    const uint32_t* __restrict__ point_list, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
-    const float4* __restrict__ rgbd, const ushort4* __restrict__ rect, const char* __restrict__ saved, const LOff& L,
+    const uint32_t* __restrict__ point_list, const GRec* __restrict__ grec, const char* __restrict__ saved, const LOff& L,
     int tx, int ty, float halfW, float halfH, float4* __restrict__ partials, int64_t cap) {
   constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
   const int sub = lane / GW;                     // which of them this lane works on
@@ -428,11 +337,13 @@ __device__ __forceinline__ void bwd_chunk2(
   if (valid) {
     g = point_list[begin + idx];
     // everything that depends on g in ONE round trip (the slot is only needed after the loop, its latency is not)
-    float2 m = xy[g];
-    float4 co = conic_o[g];
-    float4 cd = rgbd[g];
-    ushort4 r = rect[g];
-    uint64_t sl64 = (uint64_t)abs_offset(saved, L, g) + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
+    const float4* rec = (const float4*)(grec + g);
+    float4 m = rec[0];
+    float4 co = rec[1];
+    float4 cd = rec[2];
+    const uint32_t rel = ((const uint32_t*)(rec + 3))[1];
+    const Rect r = unpack_rect(__float_as_uint(m.z), __float_as_uint(m.w));
+    uint64_t sl64 = (uint64_t)abs_offset(saved, L, g, rel) + (uint32_t)((ty - r.y0) * (r.x1 - r.x0) + (tx - r.x0));
     if ((int64_t)sl64 < cap) slot = (uint32_t)sl64;
     mx = m.x; my = m.y; A = co.x; B = co.y; Cc = co.z; op = co.w; cr = cd.x; cg = cd.y; cb = cd.z; dep = cd.w;
   }
@@ -533,10 +444,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   const int64_t cap = L.cap;
   const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
   const uint32_t* __restrict__ point_list = (const uint32_t*)(saved + L.o_point_list);
-  const float2* __restrict__ xy = (const float2*)(saved + L.o_xy);
-  const float4* __restrict__ conic_o = (const float4*)(saved + L.o_conic_o);
-  const float4* __restrict__ rgbd = (const float4*)(saved + L.o_rgbd);
-  const ushort4* __restrict__ rect = (const ushort4*)(saved + L.o_rect);
+  const GRec* __restrict__ grec = grec_of(saved, L);
   const float* __restrict__ final_T = (const float*)(saved + L.o_final_T);
   const uint32_t* __restrict__ n_contrib = (const uint32_t*)(saved + L.o_n_contrib);
   const uint32_t* __restrict__ tile_maxc = (const uint32_t*)(saved + L.o_tile_maxc);
@@ -573,8 +481,9 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   // pairs the forward never reached (behind every pixel's last contributor) still own a slot: define it as zero
   for (int idx = eff + lane; idx < count; idx += kWave) {
     uint32_t g = point_list[begin + idx];
-    ushort4 r = rect[g];
-    uint64_t slot = (uint64_t)abs_offset(saved, L, g) + (uint32_t)((ty - (int)r.y) * ((int)r.z - (int)r.x) + (tx - (int)r.x));
+    const float4 q0 = ((const float4*)(grec + g))[0];
+    const Rect r = unpack_rect(__float_as_uint(q0.z), __float_as_uint(q0.w));
+    uint64_t slot = (uint64_t)abs_offset(saved, L, g, grec[g].offset) + (uint32_t)((ty - r.y0) * (r.x1 - r.x0) + (tx - r.x0));
     if ((int64_t)slot < cap) {
       partials[slot * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
       partials[slot * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -604,17 +513,17 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
 
   if (eff <= 16) {
     stage(std::integral_constant<int, 16>{});
-    bwd_chunk2<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty, halfW,
+    bwd_chunk2<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty, halfW,
                    halfH, partials, cap);
   } else if (eff <= 32) {
     stage(std::integral_constant<int, 32>{});
-    bwd_chunk2<32>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty, halfW,
+    bwd_chunk2<32>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty, halfW,
                    halfH, partials, cap);
   } else {
     stage(std::integral_constant<int, 64>{});
     const int nchunks = (eff + kWave - 1) / kWave;
     for (int c = nchunks - 1; c >= 0; --c) {
-      bwd_chunk2<64>(lane, c, eff, begin, tx0, ty0, pixA, pixB, point_list, xy, conic_o, rgbd, rect, saved, L, tx, ty,
+      bwd_chunk2<64>(lane, c, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty,
                      halfW, halfH, partials, cap);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();

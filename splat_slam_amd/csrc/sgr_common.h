@@ -67,9 +67,9 @@ struct ViewTab {
 struct LOff {
   int N, H, W, gx, gy, sgx, sgy, ntiles, pre_blocks, nseg, dbg;
   int64_t cap;
-  size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
+  size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_vis_pos, o_seg_list, o_entries, o_partials, o_tau_part, o_gradrec, o_taurec;
+      o_seg_list, o_entries, o_partials, o_tau_part, o_gradrec, o_taurec;
 };
 // shared (view independent) scalars of a batch
 struct Common {
@@ -81,6 +81,22 @@ struct Common {
 
 int debug_flags();   // SGR_DEBUG environment variable (timing experiments only; 0 in production)
 
+// Everything later stages gather BY GAUSSIAN for one view, as ONE 64-byte record (= one HBM sector pair, one L2 line
+// half) instead of seven SoA arrays: a gather of 8...16 bytes costs a whole sector, so seven arrays meant up to seven
+// sectors per (tile, Gaussian) pair.
+struct __attribute__((aligned(16))) GRec {
+  float px, py;                 // projected centre (pixels)
+  uint32_t rect01, rect23;      // 8x8-tile rectangle x0 | y0<<16, x1 | y1<<16
+  float A, B, C, opacity;       // conic + activated opacity
+  float r, g, b, depth;         // colour, view-space depth
+  uint32_t touched, offset, vis_pos, clamped;   // pairs, in-segment prefix of pairs, slot in the visible list, SH clamp bits
+};
+static_assert(sizeof(GRec) == 64, "GRec must be one 64-byte record");
+struct Rect { int x0, y0, x1, y1; };
+__device__ __forceinline__ Rect unpack_rect(uint32_t r01, uint32_t r23) {
+  return {(int)(r01 & 0xffffu), (int)(r01 >> 16), (int)(r23 & 0xffffu), (int)(r23 >> 16)};
+}
+
 // Carves the two workspaces. Pure function of (N, H, W, capacity): forward and backward agree by construction.
 struct Layout {
   int N, H, W;
@@ -89,9 +105,9 @@ struct Layout {
   int sgx, sgy;            // 16x16 super-tile grid (one 256-thread workgroup)
   int tile_bits;
   // saved
-  size_t o_hdr, o_tile_count, o_xy, o_conic_o, o_rgbd, o_rect, o_offsets, o_touched, o_clamped, o_point_list, o_ranges,
+  size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_vis_pos, o_seg_list, saved_bytes, zero_bytes;
+      o_seg_list, saved_bytes, zero_bytes;
   // scratch (forward)
   size_t o_entries;
   // scratch (backward) -- aliases the forward scratch
@@ -115,13 +131,7 @@ struct Layout {
     o_hdr = take(sizeof(SavedHeader));
     o_tile_count = take((size_t)ntiles * 4 * kCntStride);     // hdr + tile_count are zeroed by ONE launch per forward
     zero_bytes = o;
-    o_xy = take(n * 8);
-    o_conic_o = take(n * 16);
-    o_rgbd = take(n * 16);
-    o_rect = take(n * 8);
-    o_offsets = take(n * 4);
-    o_touched = take(n * 4);
-    o_clamped = take(n);
+    o_grec = take(n * sizeof(GRec));   // one 64-byte record per Gaussian: what binning / blending / backward gather
     o_point_list = take(c * 4);
     o_ranges = take((size_t)ntiles * 8 * kRngStride);
     o_tile_maxc = take((size_t)ntiles * 4);
@@ -132,7 +142,6 @@ struct Layout {
     o_block_base_t = take(nb * 4);
     o_block_base_v = take(nb * 4);
     o_vis_list = take(n * 4);
-    o_vis_pos = take(n * 4);
     o_seg_list = take(n * 4);        // per-segment visible lists written by K1; K3 turns them into the compact o_vis_list
     saved_bytes = o;
 
@@ -150,12 +159,11 @@ struct Layout {
     LOff d;
     d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags();
     d.cap = cap;
-    d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_xy = o_xy; d.o_conic_o = o_conic_o; d.o_rgbd = o_rgbd;
-    d.o_rect = o_rect; d.o_offsets = o_offsets; d.o_touched = o_touched; d.o_clamped = o_clamped;
+    d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_grec = o_grec;
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;
     d.o_n_contrib = o_n_contrib; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
     d.o_block_base_t = o_block_base_t; d.o_block_base_v = o_block_base_v; d.o_vis_list = o_vis_list;
-    d.o_vis_pos = o_vis_pos; d.o_seg_list = o_seg_list; d.o_entries = o_entries; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
+    d.o_seg_list = o_seg_list; d.o_entries = o_entries; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
     d.o_gradrec = o_gradrec; d.o_taurec = o_taurec;
     return d;
   }
@@ -209,9 +217,10 @@ struct ProfScope {
 };
 
 // absolute partial-slot offset of Gaussian g: in-segment prefix (written by preprocess_fwd) + its segment's base (tile_scan)
-__device__ __forceinline__ uint32_t abs_offset(const char* saved, const LOff& L, uint32_t g) {
-  return ((const uint32_t*)(saved + L.o_offsets))[g] + ((const uint32_t*)(saved + L.o_block_base_t))[g >> kSegShift];
+__device__ __forceinline__ uint32_t abs_offset(const char* saved, const LOff& L, uint32_t g, uint32_t rel_offset) {
+  return rel_offset + ((const uint32_t*)(saved + L.o_block_base_t))[g >> kSegShift];
 }
+__device__ __forceinline__ const GRec* grec_of(const char* saved, const LOff& L) { return (const GRec*)(saved + L.o_grec); }
 
 // 3-float rows as ONE 12-byte access (three dword accesses with a 12-byte lane stride use a third of each cache line)
 struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };

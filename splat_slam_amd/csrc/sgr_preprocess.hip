@@ -391,13 +391,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     const uint32_t vis = o.visible ? 1u : 0u;
     if (o.visible) {
       p_radii[v][i] = (int32_t)o.rad;
-      ((uint32_t*)(saved + L.o_touched))[i] = cnt;
-      ((float2*)(saved + L.o_xy))[i] = make_float2(o.px, o.py);
-      ((float4*)(saved + L.o_conic_o))[i] = make_float4(o.A, o.B, o.C, o.opac);
-      ((float4*)(saved + L.o_rgbd))[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
-      ((ushort4*)(saved + L.o_rect))[i] =
-          make_ushort4((unsigned short)o.x0, (unsigned short)o.y0, (unsigned short)o.x1, (unsigned short)o.y1);
-      ((uint8_t*)(saved + L.o_clamped))[i] = (uint8_t)o.clamped;
+      float4* rec = (float4*)((GRec*)(saved + L.o_grec) + i);          // q3 (prefix, list slot) follows after the scans
+      rec[0] = make_float4(o.px, o.py, __uint_as_float((uint32_t)o.x0 | ((uint32_t)o.y0 << 16)),
+                           __uint_as_float((uint32_t)o.x1 | ((uint32_t)o.y1 << 16)));
+      rec[1] = make_float4(o.A, o.B, o.C, o.opac);
+      rec[2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
       uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
       if (!(L.dbg & 16))
       for (int y = o.y0; y < o.y1; ++y)
@@ -417,9 +415,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
     __syncthreads();
     if (o.visible) {
-      ((uint32_t*)(saved + L.o_offsets))[i] = ex_t - vbase_t[v];      // relative; abs_offset() adds the segment base
       const uint32_t k = ex_v - vbase_v[v];
-      ((uint32_t*)(saved + L.o_vis_pos))[i] = k;                       // relative; scatter_kernel makes it absolute
+      // touched, in-segment prefix (abs_offset() adds the segment base), list slot (relative; scatter_kernel makes it
+      // absolute), SH clamp bits
+      ((uint4*)((GRec*)(saved + L.o_grec) + i))[3] = make_uint4(cnt, ex_t - vbase_t[v], k, o.clamped);
       ((uint32_t*)(saved + L.o_seg_list))[seg0 + k] = (uint32_t)i;
     }
     carry_t += tot_t;
@@ -448,7 +447,7 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
     const float* __restrict__ projmatrix, const float* __restrict__ projraw, const float* __restrict__ campos,
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-    uint32_t slot0, const uint32_t* __restrict__ touched, const uint8_t* __restrict__ clamped_in,
+    uint32_t slot0, uint32_t touched_cnt, unsigned clamped_bits,
     const float4* __restrict__ partials, int64_t cap, float* __restrict__ dshs, int sh_accumulate, GaussGrad& acc,
     float tau[6]) {
   float g_m2[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_rgb[3] = {0.f, 0.f, 0.f}, g_dep = 0.f;
@@ -460,7 +459,7 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
   float* dcolors = nullptr;   // precomputed-colour gradient is returned through acc.rgb_or_sh0
   {
     // fixed-order gather of this Gaussian's per-tile partials: deterministic, no atomics
-    uint32_t off = slot0, cnt = touched[i];
+    uint32_t off = slot0, cnt = touched_cnt;
     for (uint32_t k = 0; k < cnt; ++k) {
       uint64_t e = (uint64_t)off + k;
       if ((int64_t)e >= cap) break;
@@ -568,7 +567,7 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
     if (colors_precomp) {
       sh0[0] = g_rgb[0]; sh0[1] = g_rgb[1]; sh0[2] = g_rgb[2];
     } else {
-      unsigned cl = clamped_in[i];
+      unsigned cl = clamped_bits;
       float dc[3] = {(cl & 1u) ? 0.f : g_rgb[0], (cl & 2u) ? 0.f : g_rgb[1], (cl & 4u) ? 0.f : g_rgb[2]};
       float* out = dshs ? dshs + (size_t)i * M * 3 : nullptr;
       if (deg == 0) {
@@ -681,6 +680,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   if (t >= V) return;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int i = (int)((const uint32_t*)(saved + L.o_vis_list))[t];
+  const uint4 q3 = ((const uint4*)(grec_of(saved, L) + i))[3];
   GaussGrad acc;
 #pragma unroll
   for (int j = 0; j < 3; ++j) { acc.p[j] = 0.f; acc.s[j] = 0.f; acc.rgb_or_sh0[j] = 0.f; }
@@ -691,8 +691,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   acc.op = 0.f; acc.m2[0] = 0.f; acc.m2[1] = 0.f;
   preprocess_bwd_one_view(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, tab.viewmatrix[v], tab.projmatrix[v],
                           cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                          abs_offset(saved, L, (uint32_t)i), (const uint32_t*)(saved + L.o_touched),
-                          (const uint8_t*)(saved + L.o_clamped), (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
+                          abs_offset(saved, L, (uint32_t)i, q3.y), q3.x, q3.w,
+                          (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
                           dshs, accumulate, acc, tau);
   float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)t * 4;
   rec[0] = make_float4(acc.p[0], acc.p[1], acc.p[2], acc.rgb_or_sh0[0]);
@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(256) grad_gather_kernel(
     uint32_t pos = 0;
     if (r > 0) {
       any = true;
-      pos = ((const uint32_t*)(tab.saved[v] + L.o_vis_pos))[i];
+      pos = grec_of(tab.saved[v], L)[i].vis_pos;
       const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)pos * 4;
       float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
       a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
