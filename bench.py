@@ -162,6 +162,10 @@ def main():
     trace("timed fwd ok")
     render_fwd_bwd_ms = timed(fwd_bwd)
     trace("timed fwd_bwd ok")
+    render_fused_ms = None
+    if args.loop == "fused":       # the loop's own forward-only render (persistent buffers, no host sync): keyframe selection
+        loop.render_forward(cam0)
+        render_fused_ms = timed(lambda: loop.render_forward(cam0), reps=50)
 
     # ---- work counters of the views of the last timed step (saved blocks of the fused loop; one sync each)
     stats = (C.c_int64 * 4)()
@@ -238,7 +242,10 @@ def main():
                    "gaussians": N, "width": intr["W"], "height": intr["H"], "views_per_step": views_per_step, "loop": args.loop,
                    "parallelism": "view-parallel x%d, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
         "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4),
-        "render_ms": {"forward": round(render_fwd_ms, 4), "forward_backward_loss": round(render_fwd_bwd_ms, 4)},
+        "render_ms": {"forward": round(render_fwd_ms, 4), "forward_backward_loss": round(render_fwd_bwd_ms, 4),
+                      "forward_fused_loop": None if render_fused_ms is None else round(render_fused_ms, 4),
+                      "note": "forward / forward_backward_loss: one view through the drop-in autograd API (one host sync per "
+                              "forward, like upstream); forward_fused_loop: FusedMappingLoop.render_forward, no sync"},
         "map_iterations_per_s": round(args.steps / elapsed, 2),
         "refine_iterations_per_s": None if refine_its is None else round(refine_its, 1),
         "work_per_view": {"visible_gaussians": V, "tile_pairs_R": R, "tile_pairs_walked_R_eff": R_eff_sum // nv,

@@ -395,6 +395,43 @@ class FusedMappingLoop(MappingLoop):
             stt["step"] += n_it
         pl.frest_state["step"] += n_it
 
+    def _run_span_ranks(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True):
+        """The multi-GPU form of _run_span: per iteration (1) this rank's views, gradients summed into the flat buffer,
+        (2) ONE all-reduce of that buffer over the ranks (RCCL over xGMI), (3) the identical Adam step on every rank.
+        The all-reduce sits between two kernels of the same iteration, so the iterations are enqueued from a lean host
+        loop (two C-ABI calls + one collective each) instead of one sgr_map_run."""
+        n_it = len(lrs)
+        pl = self._plan()
+        self._views_array(list(window_cams) + list(pool_cams), False)      # probes new cameras, settles the capacity
+        nw, per = len(window_cams), (len(picks) // n_it if picks else 0)
+        pool = self._views_array(pool_cams, False, images=False) if pool_cams else None
+        arr = (nat.SgrMapView * max(1, nw + per))()
+        for v, c in enumerate(window_cams):
+            arr[v] = self._map_view(c, False, images=False)
+        st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
+        views_st, adam_st = nat.SgrMapStep(), nat.SgrMapStep()
+        C.memmove(C.byref(views_st), C.byref(st), C.sizeof(st))
+        C.memmove(C.byref(adam_st), C.byref(st), C.sizeof(st))
+        views_st.adam_groups, views_st.exp_rows, views_st.grads_clean = None, 0, -1
+        views_st.num_views, views_st.views = nw + per, arr
+        adam_st.num_views, adam_st.views = 0, None
+        adam_st.scaling, adam_st.rotation, adam_st.opacity = None, None, None      # (activation belongs to the views call)
+        adam_st.adam_groups = pl.groups
+        stream = self._stream()
+        for k in range(n_it):
+            for j in range(per):
+                arr[nw + j] = pool[picks[k * per + j]]
+            nat.check(self.lib.sgr_map_step(C.byref(views_st), stream), "sgr_map_step")
+            self._all_reduce_sum(self._acc["flat"])
+            pl.groups[0].lr = lrs[k]
+            for g in range(5):
+                pl.groups[g].step += 1
+            nat.check(self.lib.sgr_map_step(C.byref(adam_st), stream), "sgr_map_step")
+        for g, stt in pl.states:
+            stt["step"] += n_it
+        pl.frest_state["step"] += n_it
+        self._acc_clean = True
+
     def _step(self, cams, iso_weight=0.0, adam=True, skip=(), initialization=False, stats=True, forward_only=False,
               exposure="none", activate=True):
         """ONE host call: activate -> batched views (forward / loss / backward) -> Adam -> exposure Adam."""
@@ -579,7 +616,7 @@ class FusedMappingLoop(MappingLoop):
             it += 1
             # a span of regular iterations (no densification / opacity reset, no pose optimiser) is ONE host call
             n = 0
-            if not prune and not pose_opt and self.world == 1 and self.span_calls:
+            if not prune and not pose_opt and self.span_calls:
                 while it + n < iters and not self._is_special(self.iteration_count + n + 1):
                     n += 1
             if n > 0:
@@ -589,7 +626,8 @@ class FusedMappingLoop(MappingLoop):
                 for _ in range(n):               # the reference's draws, in its order (mapper.py:470)
                     picks += torch.randperm(len(random_viewpoint_stack))[:2].tolist()
                 lrs = [float(self._xyz_group()["lr"])] + [self.gaussians.lr_at(c0 + k) for k in range(1, n)]
-                self._run_span(viewpoint_stack, random_viewpoint_stack, picks, lrs, 10.0, "window")
+                (self._run_span if self.world == 1 else self._run_span_ranks)(viewpoint_stack, random_viewpoint_stack, picks,
+                                                                              lrs, 10.0, "window")
                 self.iteration_count = c0 + n
                 self.gaussians.update_learning_rate(self.iteration_count)
                 self.last_used = list(viewpoint_stack) + [random_viewpoint_stack[k] for k in picks[len(picks) - per:]]

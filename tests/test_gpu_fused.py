@@ -134,7 +134,7 @@ def test_fused_loop_tracks_autograd_loop():
         assert (a.occ_aware_visibility[kf] != f.occ_aware_visibility[kf]).float().mean().item() < 0.01
 
 
-def _mg_worker(rank, world, port, out):
+def _mg_worker(rank, world, port, out, span=True):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -145,6 +145,7 @@ def _mg_worker(rank, world, port, out):
     mine = cams[rank * 3: rank * 3 + 3]            # each rank maps its own three views of the replicated map
     f = _loop(FusedMappingLoop, syn, params, mine, [c.uid for c in mine])
     f.world = world
+    f.span_calls = span
 
     def staged_all_reduce(t):                      # one 1-GPU box: both ranks share cuda:0, so exchange through gloo/CPU
         c = t.detach().cpu()
@@ -171,6 +172,12 @@ def test_view_parallel_ranks_stay_bitwise_identical_and_match_single_process():
     mp.spawn(_mg_worker, args=(2, port, out), nprocs=2, join=True)
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k          # replicas never drift
+    # the lean per-iteration host loop of a run (_run_span_ranks) is the same computation as one _step per iteration
+    s2 = socket.socket(); s2.bind(("127.0.0.1", 0)); port2 = s2.getsockname()[1]; s2.close()
+    out2 = mp.Manager().dict()
+    mp.spawn(_mg_worker, args=(2, port2, out2, False), nprocs=2, join=True)
+    for k in out[0]:
+        assert torch.equal(out[0][k], out2[0][k]), k
     # single process, all six views in one window: same gradient sum up to fp32 summation order
     syn, params, cams = _scene(n=2000, views=6, seed=21)
     f = _loop(FusedMappingLoop, syn, params, cams, [c.uid for c in cams])
