@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 3
+#define SGR_ABI_VERSION 4
 
 typedef enum SgrStatus {
   SGR_OK = 0,
@@ -95,6 +95,10 @@ typedef struct SgrWorkspace {
   void* scratch;               /* transient inside one call; may be shared by calls on the same stream   */
   size_t scratch_bytes;
   int64_t capacity;            /* max (tile, Gaussian) pairs the workspaces were sized for               */
+  int32_t counters_clean;      /* != 0: the per-tile pair counters inside `saved` are zero -- every completed forward
+                                  (same N, H, W, capacity) leaves them so; 0 for a fresh / foreign block: the library
+                                  then spends one extra launch zeroing them */
+  int32_t reserved;
 } SgrWorkspace;
 
 typedef struct SgrGradOutputs {

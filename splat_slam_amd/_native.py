@@ -32,7 +32,7 @@ class SgrOutputs(C.Structure):
 
 class SgrWorkspace(C.Structure):
     _fields_ = [("saved", _fp), ("saved_bytes", C.c_size_t), ("scratch", _fp), ("scratch_bytes", C.c_size_t),
-                ("capacity", C.c_int64)]
+                ("capacity", C.c_int64), ("counters_clean", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SgrGradOutputs(C.Structure):
@@ -128,7 +128,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.sgr_abi_version() != 3:
+        if h.sgr_abi_version() != 4:
             raise ImportError("libsplat_hip.so ABI version mismatch")
         _lib = h
     return _lib

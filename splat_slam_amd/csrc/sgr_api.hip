@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -138,9 +139,12 @@ static void tab_set_view(ViewTab& t, int v, const SgrSettings* s, const SgrOutpu
 }
 
 // forward of a batch that shares N, H, W, capacity and the view-independent settings
-static int forward_batch(const ViewTab& tab, int nviews, const Layout& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
+static int forward_batch(const ViewTab& tab, int nviews, const Layout& L, const Common& cm, const SgrInputs& in, hipStream_t st,
+                         bool counters_clean = false) {
   LOff d = L.dev();
-  launch_zero_heads(tab, nviews, d, L.zero_bytes, st);   // header + per-tile pair counters
+  // header + per-tile pair counters; tile_scan re-zeroes the counters after reading them, so only blocks that never
+  // went through a forward (or the caller does not vouch for) need this launch
+  if (!counters_clean) launch_zero_heads(tab, nviews, d, L.zero_bytes, st);
   launch_preprocess_fwd(tab, nviews, d, cm, in, st);     // K1: project, footprint, count pairs per tile
   launch_binning(tab, nviews, d, st);                    // K2: tile/block scans   K3: scatter keys
   return SGR_OK;
@@ -216,7 +220,7 @@ int sgr_backward(const SgrSettings* s, const SgrInputs* in, const int32_t* radii
 
 // fused: optimiser tail to run inside the gather pass; *fused_done tells whether it did (uniform single-chunk batches only)
 static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrInputs* in, const SgrGradInputs* grads, float alpha,
-                          float rgb_boundary_threshold, int32_t forward_only, const FusedAdam* fused, bool* fused_done,
+                          float rgb_boundary_threshold, int32_t forward_only, FusedAdam* fused, bool* fused_done,
                           void* stream) {
   if (fused_done) *fused_done = false;
   if (num_views < 0 || (num_views > 0 && (!views || !in)) || (!forward_only && !grads))
@@ -268,8 +272,10 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
     const int nv = num_views - base < kMaxViews ? num_views - base : kMaxViews;
     ViewTab tab = {};
     LossTab lt = {};
+    bool all_clean = true;
     for (int v = 0; v < nv; ++v) {
       const SgrMapView& m = views[base + v];
+      all_clean = all_clean && m.ws.counters_clean != 0;
       if (int rc = check_workspace(&m.ws, L)) return rc;
       const bool no_images = !m.out.color && !m.out.depth && !m.out.opacity && !forward_only;   // loss-only iteration
       if ((!no_images && (!m.out.color || !m.out.depth || !m.out.opacity)) || !m.out.radii)
@@ -288,7 +294,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
         lt.parts[v] = m.loss_scratch;
       }
     }
-    if (int rc = forward_batch(tab, nv, L, cm, *in, st)) return rc;
+    if (int rc = forward_batch(tab, nv, L, cm, *in, st, all_clean)) return rc;
     if (forward_only) {
       launch_blend_fwd(tab, nv, d, f.settings.bg, nullptr, nullptr, st);
       continue;
@@ -297,9 +303,17 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
     // reduction is a separate launch
     LossCoef lc = {alpha / (3.f * (float)HW), (1.f - alpha) / (float)HW, rgb_boundary_threshold};
     launch_blend_fwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
-    launch_mapping_loss_final(lt, nv, HW, L.ntiles, alpha, st);
-    launch_blend_bwd(tab, nv, d, f.settings.bg, st);
     const bool fuse = fused && num_views <= kMaxViews;
+    if (fuse) {        // the loss sums (and the exposure step that consumes them) ride in the optimiser launch
+      fused->tail_views = nv; fused->tail_nparts = L.ntiles;
+      fused->tail_inv_rgb = 1.f / (3.f * (float)HW); fused->tail_inv_dep = 1.f / (float)HW; fused->tail_alpha = alpha;
+      for (int v = 0; v < nv; ++v) {
+        fused->tail_parts[v] = lt.parts[v]; fused->tail_loss[v] = lt.loss[v]; fused->tail_da[v] = lt.da[v]; fused->tail_db[v] = lt.db[v];
+      }
+    } else {
+      launch_mapping_loss_final(lt, nv, HW, L.ntiles, alpha, st);
+    }
+    launch_blend_bwd(tab, nv, d, f.settings.bg, st);
     launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, fuse ? fused : nullptr, st);
     if (fuse && fused_done) *fused_done = true;
   }
@@ -341,6 +355,13 @@ static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_cle
       fa.stat_accum = g.stat_grad_accum;
       fa.stat_denom = g.stat_grad_accum ? g.stat_denom : nullptr;
       fa.stat_maxr = g.stat_grad_accum ? g.stat_max_radii : nullptr;
+      if (p->exp_rows > 0) {
+        if (!p->exp_param || !p->exp_grad || !p->exp_avg || !p->exp_avg_sq || !p->exp_step || !p->exp_active || p->exp_row_width <= 0)
+          return set_error(SGR_ERR_INVALID, "map_step: exposure block incomplete");
+        fa.exp_rows = p->exp_rows; fa.exp_width = p->exp_row_width; fa.exp_param = p->exp_param; fa.exp_grad = p->exp_grad;
+        fa.exp_avg = p->exp_avg; fa.exp_avg_sq = p->exp_avg_sq; fa.exp_step = p->exp_step; fa.exp_active = p->exp_active;
+        fa.exp_lr = p->exp_lr; fa.exp_b1 = p->exp_beta1; fa.exp_b2 = p->exp_beta2; fa.exp_eps = p->exp_eps;
+      }
     }
   }
   bool fused = false;
@@ -350,7 +371,7 @@ static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_cle
       return rc;
   if (p->adam_groups && !fused)
     if (int rc = sgr_gaussian_adam_step(p->num_gaussians, p->adam_groups, p->beta1, p->beta2, p->eps, p->iso_weight, stream)) return rc;
-  if (p->exp_rows > 0)
+  if (p->exp_rows > 0 && !fused)
     if (int rc = sgr_masked_adam(p->exp_rows, p->exp_row_width, p->exp_param, p->exp_grad, p->exp_avg, p->exp_avg_sq, p->exp_step,
                                  p->exp_active, p->exp_lr, p->exp_beta1, p->exp_beta2, p->exp_eps, stream))
       return rc;
@@ -373,6 +394,7 @@ int sgr_map_run(const SgrMapRun* r, void* stream) {
   if (nv > 64) return set_error(SGR_ERR_INVALID, "map_run: more than 64 views per iteration");
   SgrMapView views[64];
   for (int v = 0; v < r->num_window; ++v) views[v] = r->window[v];
+  std::vector<char> pool_used((size_t)(r->pool_size > 0 ? r->pool_size : 0), 0);   // a block is clean after its first forward
   SgrMapStep st = r->step;
   st.views = views;
   st.num_views = nv;
@@ -384,7 +406,11 @@ int sgr_map_run(const SgrMapRun* r, void* stream) {
       const int32_t k = r->picks[(size_t)it * r->picks_per_iter + j];
       if (k < 0 || k >= r->pool_size) return set_error(SGR_ERR_INVALID, "map_run: pick %d outside the pool", k);
       views[r->num_window + j] = r->pool[k];
+      if (pool_used[k]) views[r->num_window + j].ws.counters_clean = 1;
+      pool_used[k] = 1;
     }
+    if (it == 1)
+      for (int v = 0; v < r->num_window; ++v) views[v].ws.counters_clean = 1;
     if (r->n_touched_last_only) {       // the per-Gaussian "touched" counters only matter after the run (mapper.py:494-498)
       const bool last = it == r->num_iters - 1;
       for (int v = 0; v < r->num_window; ++v) views[v].out.n_touched = last ? r->window[v].out.n_touched : nullptr;

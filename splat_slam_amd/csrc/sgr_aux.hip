@@ -60,11 +60,10 @@ __global__ void __launch_bounds__(256) mapping_loss_kernel(LossTab tab, int HW, 
   }
 }
 
-// second stage: one 256-thread block per view adds the partials in a fixed order (thread-strided, then DPP + LDS)
-__global__ void __launch_bounds__(256) mapping_loss_final_kernel(LossTab tab, int nparts, float inv_rgb, float inv_dep, float alpha) {
-  __shared__ LossPart red[4];
-  const int vw = blockIdx.x;
-  const LossPart* __restrict__ parts = (const LossPart*)tab.parts[vw];
+// second stage: one 256-thread block adds a view's partials in a fixed order (thread-strided, then DPP + LDS)
+__device__ __forceinline__ void loss_final_view(const LossPart* __restrict__ parts, int nparts, float inv_rgb, float inv_dep,
+                                                float alpha, float* loss, float* da, float* db, LossPart* red /*LDS[4]*/) {
+#pragma clang fp contract(off)
   LossPart t = {0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < nparts; i += 256) {
     LossPart p = parts[i];
@@ -79,10 +78,17 @@ __global__ void __launch_bounds__(256) mapping_loss_final_kernel(LossTab tab, in
   if (threadIdx.x == 0) {
     LossPart s = red[0];
     for (int w = 1; w < 4; ++w) { s.rgb += red[w].rgb; s.dep += red[w].dep; s.da += red[w].da; s.db += red[w].db; }
-    if (tab.loss[vw]) tab.loss[vw][0] = alpha * (s.rgb * inv_rgb) + (1.f - alpha) * (s.dep * inv_dep);
-    if (tab.da[vw]) tab.da[vw][0] = s.da;
-    if (tab.db[vw]) tab.db[vw][0] = s.db;
+    if (loss) loss[0] = alpha * (s.rgb * inv_rgb) + (1.f - alpha) * (s.dep * inv_dep);
+    if (da) da[0] = s.da;
+    if (db) db[0] = s.db;
   }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) mapping_loss_final_kernel(LossTab tab, int nparts, float inv_rgb, float inv_dep, float alpha) {
+  __shared__ LossPart red[4];
+  const int vw = blockIdx.x;
+  loss_final_view((const LossPart*)tab.parts[vw], nparts, inv_rgb, inv_dep, alpha, tab.loss[vw], tab.da[vw], tab.db[vw], red);
 }
 
 static int loss_blocks(int HW) {
@@ -119,11 +125,10 @@ __global__ void __launch_bounds__(256) adam_kernel(int64_t n, float* __restrict_
   }
 }
 
-__global__ void masked_adam_kernel(int rows, int width, float* __restrict__ p, const float* __restrict__ g,
-                                   float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ step,
-                                   const int32_t* __restrict__ active, float lr, float b1, float b2, float eps) {
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows || !active[r]) return;
+__device__ __forceinline__ void masked_adam_row(int r, int width, float* __restrict__ p, const float* __restrict__ g,
+                                                float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ step,
+                                                float lr, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
   int st = step[r] + 1;
   step[r] = st;
   float bc1 = 1.f - powf(b1, (float)st), bc2 = 1.f - powf(b2, (float)st);
@@ -137,6 +142,15 @@ __global__ void masked_adam_kernel(int rows, int width, float* __restrict__ p, c
     m[i] = mi;
     v[i] = vi;
   }
+}
+
+__global__ void masked_adam_kernel(int rows, int width, float* __restrict__ p, const float* __restrict__ g,
+                                   float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ step,
+                                   const int32_t* __restrict__ active, float lr, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows || !active[r]) return;
+  masked_adam_row(r, width, p, g, m, v, step, lr, b1, b2, eps);
 }
 
 // ------------------------------------------------------------------------------------------------ fused map step
@@ -305,7 +319,26 @@ __global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroup
 // activations the next iteration renders with.
 template <int MODE>
 __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nviews, LOff L, FusedAdam fa) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int)blockIdx.x < fa.tail_views) {      // rider blocks (scheduled first): one per view
+    // fixed-order sum of the view's per-tile loss parts, then the exposure (keyframe) Adam step of the ONE slab row this
+    // view's exposure gradient lives in (every active row belongs to a window keyframe, and those are rendered every
+    // iteration: mapper.py:426-447, 1096-1111) -- no dependency on any other block
+    __shared__ LossPart red[4];
+    const int v = blockIdx.x;
+    loss_final_view((const LossPart*)fa.tail_parts[v], fa.tail_nparts, fa.tail_inv_rgb, fa.tail_inv_dep, fa.tail_alpha,
+                    fa.tail_loss[v], fa.tail_da[v], fa.tail_db[v], red);
+    if (threadIdx.x == 0 && fa.exp_rows > 0 && fa.tail_da[v]) {
+      const ptrdiff_t d = fa.tail_da[v] - fa.exp_grad;
+      if (d >= 0 && d < (ptrdiff_t)fa.exp_rows * fa.exp_width && d % fa.exp_width == 0) {
+        const int r = (int)(d / fa.exp_width);
+        if (fa.exp_active[r])
+          masked_adam_row(r, fa.exp_width, fa.exp_param, fa.exp_grad, fa.exp_avg, fa.exp_avg_sq, fa.exp_step, fa.exp_lr,
+                          fa.exp_b1, fa.exp_b2, fa.exp_eps);
+      }
+    }
+    return;
+  }
+  const int i = ((int)blockIdx.x - fa.tail_views) * blockDim.x + threadIdx.x;
   if (i >= L.N) return;
   float a[14];
 #pragma unroll
@@ -336,10 +369,11 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
 
 void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st) {
   if (L.N <= 0) return;
+  const int grid = L.pre_blocks + fa.tail_views;
   if (fa.grads_clean)
-    hipLaunchKernelGGL(gather_adam_kernel<2>, dim3(L.pre_blocks), dim3(256), 0, st, tab, nviews, L, fa);
+    hipLaunchKernelGGL(gather_adam_kernel<2>, dim3(grid), dim3(256), 0, st, tab, nviews, L, fa);
   else
-    hipLaunchKernelGGL(gather_adam_kernel<1>, dim3(L.pre_blocks), dim3(256), 0, st, tab, nviews, L, fa);
+    hipLaunchKernelGGL(gather_adam_kernel<1>, dim3(grid), dim3(256), 0, st, tab, nviews, L, fa);
 }
 
 // ------------------------------------------------------------------------------------------------ 3-NN

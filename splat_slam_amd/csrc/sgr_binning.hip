@@ -47,9 +47,14 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   if (blockIdx.x == 0) {
     uint32_t* tmp = (uint32_t*)(saved + L.o_tile_maxc);      // free until blend_fwd overwrites it
     uint2* ranges = (uint2*)(saved + L.o_ranges);
-    uint32_t R = block1024_scan((const uint32_t*)(saved + L.o_tile_count), tmp, L.ntiles, red, kCntStride);
+    uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
+    uint32_t R = block1024_scan(tile_count, tmp, L.ntiles, red, kCntStride);
     __syncthreads();
-    for (int t = threadIdx.x; t < L.ntiles; t += 1024) { uint32_t s0 = tmp[t]; ranges[(size_t)t * kRngStride] = make_uint2(s0, s0); }
+    for (int t = threadIdx.x; t < L.ntiles; t += 1024) {
+      uint32_t s0 = tmp[t];
+      ranges[(size_t)t * kRngStride] = make_uint2(s0, s0);
+      tile_count[(size_t)t * kCntStride] = 0u;       // consumed: leave the counters clean for the next forward
+    }
     if (threadIdx.x == 0) {
       hdr->num_rendered = R;
       hdr->overflow = (int64_t)R > L.cap ? 1u : 0u;

@@ -202,6 +202,17 @@ struct FusedAdam {
   int grads_clean;            // gradient sinks are all-zero on entry: neither read nor written
   float *s_out, *r_out, *o_out;
   float *stat_accum, *stat_denom, *stat_maxr;
+  // optional riders of the same launch (one extra block): the fixed-order sum of the per-tile loss parts of every view
+  // (mapping_loss_final) and the exposure (keyframe) Adam step that consumes the exposure gradients it produces
+  int tail_views, tail_nparts;
+  float tail_inv_rgb, tail_inv_dep, tail_alpha;
+  const void* tail_parts[kMaxViews];
+  float* tail_loss[kMaxViews];
+  float* tail_da[kMaxViews];
+  float* tail_db[kMaxViews];
+  int exp_rows, exp_width;
+  float* exp_param; const float* exp_grad; float* exp_avg; float* exp_avg_sq; int32_t* exp_step; const int32_t* exp_active;
+  float exp_lr, exp_b1, exp_b2, exp_eps;
 };
 int make_fused_adam(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight, FusedAdam* out);
 void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st);

@@ -46,6 +46,7 @@ class _ViewBuffers:
         self.loss_scratch = torch.empty(max(1024, ntiles) * 16, dtype=torch.uint8, device=dev)   # one LossPart per 8x8 tile
         self.saved = None
         self.scratch = None
+        self.clean = False         # the saved block went through a forward with its current layout (counters are zero)
         self.pairs = -1            # (tile, Gaussian) pairs seen by the probe render; -1 = not probed at this map size
         self.capacity = 0
         self.gt_depth = None
@@ -201,9 +202,11 @@ class FusedMappingLoop(MappingLoop):
         if vb.saved is None or vb.saved.numel() < sb or vb.capacity != cap:
             vb.saved = torch.empty(sb, dtype=torch.uint8, device=self.device)
             vb.capacity = cap
+            vb.clean = False       # per-tile counters of a fresh block are garbage: the library zeroes them once
         if vb.scratch is None or vb.scratch.numel() < tb:
             vb.scratch = torch.empty(tb, dtype=torch.uint8, device=self.device)
-        return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), cap)
+        return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), cap,
+                                int(vb.clean), 0)
 
     def _probe(self, cam, vb):
         """One synchronous forward to learn this camera's pair count at the current map size."""
@@ -227,6 +230,16 @@ class FusedMappingLoop(MappingLoop):
             nat.check(rc, "sgr_forward")
             break
         vb.pairs = int(R.value)
+        vb.clean = True
+
+    def _mark_clean(self, cams):
+        """A completed forward leaves the per-tile counters of a saved block zero: later calls skip the zeroing launch."""
+        for c in cams:
+            vb = self._views.get(c.uid)
+            if vb is not None and not vb.clean:
+                vb.clean = True
+                for _, mv in (vb.mv or {}).values():
+                    mv.ws.counters_clean = 1
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _inputs(self):
@@ -391,6 +404,7 @@ class FusedMappingLoop(MappingLoop):
         rc = self.lib.sgr_map_run(C.byref(run), self._stream())
         nat.check(rc, "sgr_map_run")
         self._acc_clean = True
+        self._mark_clean(list(window_cams) + [pool_cams[k] for k in set(picks)])
         for g, stt in pl.states:                 # the library advanced pl.groups[k].step; mirror it in torch's state
             stt["step"] += n_it
         pl.frest_state["step"] += n_it
@@ -431,6 +445,7 @@ class FusedMappingLoop(MappingLoop):
             stt["step"] += n_it
         pl.frest_state["step"] += n_it
         self._acc_clean = True
+        self._mark_clean(list(window_cams) + [pool_cams[k] for k in set(picks)])
 
     def _step(self, cams, iso_weight=0.0, adam=True, skip=(), initialization=False, stats=True, forward_only=False,
               exposure="none", activate=True):
@@ -462,6 +477,7 @@ class FusedMappingLoop(MappingLoop):
         if not activate:
             st.scaling, st.rotation, st.opacity = sc, ro, op
         nat.check(rc, "sgr_map_step")
+        self._mark_clean(cams)
         if not forward_only:
             if adam:
                 self._acc_clean = True

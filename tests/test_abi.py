@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
         assert name in nat.SIGNATURES, f"{name} has no ctypes signature in splat_slam_amd/_native.py"
     assert sorted(nat.SIGNATURES) == declared
     lib = nat.lib()
-    assert lib.sgr_abi_version() == 3
+    assert lib.sgr_abi_version() == 4
     assert isinstance(nat.last_error(), str)
 
 
@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(nat.SgrSettings) == 40 + 5 * 8
     assert ctypes.sizeof(nat.SgrInputs) == 7 * 8
     assert ctypes.sizeof(nat.SgrOutputs) == 5 * 8
-    assert ctypes.sizeof(nat.SgrWorkspace) == 5 * 8
+    assert ctypes.sizeof(nat.SgrWorkspace) == 6 * 8
     assert ctypes.sizeof(nat.SgrGradOutputs) == 2 * 8
     assert ctypes.sizeof(nat.SgrGradInputs) == 9 * 8 + 8 + 3 * 8
     assert ctypes.sizeof(nat.SgrAdamGroup) == 4 * 8 + 8 + 8
