@@ -123,6 +123,10 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). splat_slam_amd has no CPU fallback by design.")
+        # The caller's device memory and streams are torch's: load torch FIRST so that this process ends up with ONE HIP
+        # runtime (torch's bundled libamdhip64). Loading /opt/rocm's copy first gives a second runtime that cannot see
+        # the device ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
