@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 4
+#define SGR_ABI_VERSION 5
 
 typedef enum SgrStatus {
   SGR_OK = 0,
@@ -295,6 +295,40 @@ int sgr_map_run(const SgrMapRun* run, void* stream);
  * (src/mapper.py:1096-1111: lr 0.01, default eps 1e-8) live in such a slab. */
 int sgr_masked_adam(int32_t rows, int32_t row_width, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     int32_t* step, const int32_t* active, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* Mapper.update_mapping_points (src/mapper.py:154-255) as ONE pass: the Gaussians anchored to keyframe `frame_idx`
+ * (unique_kfIDs == frame_idx) are depth-rescaled along the old camera's ray (unless rigid), moved by `transform`
+ * (= inv(inv(w2c_old) @ w2c_new), host, row-major) and rotated by its quaternion; every rotation leaves normalised (the
+ * reference writes the activated rotations back).  In place on the raw parameter tensors; resetting the Adam moments of
+ * the three tensors (replace_tensor_to_optimizer, gaussian_model.py:603-617) stays with the caller. */
+typedef struct SgrDeformFrame {
+  int32_t frame_idx;
+  int32_t rigid;               /* != 0: pose change only (no depth rescale, depth maps unused) */
+  float w2c_old[16];           /* host, row-major 4x4 */
+  float c2w_old[16];           /* inverse of w2c_old */
+  float transform[16];
+  float quat_wxyz[4];          /* rotation part of `transform` */
+  float intrinsics[9];         /* row-major K */
+  int32_t height, width;
+  const float* depth_new;      /* device [H,W] */
+  const float* depth_old;      /* device [H,W] */
+} SgrDeformFrame;
+int sgr_deform_points(int64_t n, const int32_t* unique_kfIDs, const SgrDeformFrame* frame, float* xyz, float* rotation,
+                      float* scaling, void* stream);
+
+/* Densify / prune compaction (gaussian_model.py:519-600: prune_points, _prune_optimizer and the index selects of
+ * densify_and_clone / densify_and_split): sgr_keep_list turns a byte mask into the ascending list of kept row indices
+ * (count written to a device int64, no host sync); sgr_gather_rows copies rows src_rows[k] -> k for up to any number of
+ * tensors (parameters, Adam moments, statistics, keyframe ids ...) in one launch per 32 tensors. */
+typedef struct SgrRowTensor {
+  const void* in;              /* [n_in, row_bytes] */
+  void* out;                   /* [m, row_bytes], must not alias `in` */
+  int32_t row_bytes;           /* multiple of 4 */
+} SgrRowTensor;
+size_t sgr_compact_scratch_bytes(int64_t n);
+int sgr_keep_list(int64_t n, const uint8_t* keep, int32_t* src_rows, int64_t* count_device, void* scratch, size_t scratch_bytes,
+                  void* stream);
+int sgr_gather_rows(int64_t m, const int32_t* src_rows, int32_t num_tensors, const SgrRowTensor* tensors, void* stream);
 
 /* simple_knn distCUDA2: mean squared distance to the 3 nearest neighbours (self excluded). */
 size_t sknn_scratch_bytes(int32_t n);

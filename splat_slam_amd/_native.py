@@ -75,6 +75,16 @@ class SgrMapRun(C.Structure):
                 ("pool_exp_row", C.POINTER(C.c_int32)), ("n_touched_last_only", C.c_int32)]
 
 
+class SgrDeformFrame(C.Structure):
+    _fields_ = [("frame_idx", C.c_int32), ("rigid", C.c_int32), ("w2c_old", C.c_float * 16), ("c2w_old", C.c_float * 16),
+                ("transform", C.c_float * 16), ("quat_wxyz", C.c_float * 4), ("intrinsics", C.c_float * 9),
+                ("height", C.c_int32), ("width", C.c_int32), ("depth_new", _fp), ("depth_old", _fp)]
+
+
+class SgrRowTensor(C.Structure):
+    _fields_ = [("in_", _fp), ("out", _fp), ("row_bytes", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/splat_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "sgr_abi_version": (C.c_int, []),
@@ -101,6 +111,10 @@ SIGNATURES = {
     "sgr_map_run": (C.c_int, [C.POINTER(SgrMapRun), _fp]),
     "sgr_masked_adam": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _fp]),
+    "sgr_deform_points": (C.c_int, [C.c_int64, _fp, C.POINTER(SgrDeformFrame), _fp, _fp, _fp, _fp]),
+    "sgr_compact_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "sgr_keep_list": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "sgr_gather_rows": (C.c_int, [C.c_int64, _fp, C.c_int32, C.POINTER(SgrRowTensor), _fp]),
     "sknn_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "sknn_dist2": (C.c_int, [_fp, C.c_int32, _fp, _fp, C.c_size_t, _fp]),
     "se3_exp": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
@@ -132,7 +146,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.sgr_abi_version() != 4:
+        if h.sgr_abi_version() != 5:
             raise ImportError("libsplat_hip.so ABI version mismatch")
         _lib = h
     return _lib

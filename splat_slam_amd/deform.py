@@ -1,6 +1,8 @@
 """Map deformation after the tracker moved a keyframe -- mirror of Mapper.update_mapping_points,
 /root/reference/src/mapper.py:154-255, and the quaternion helpers it uses
-(/root/reference/thirdparty/gaussian_splatting/utils/general_utils.py:138-175).  Pure torch (device agnostic)."""
+(/root/reference/thirdparty/gaussian_splatting/utils/general_utils.py:138-175).  Torch formulation (device agnostic,
+used on CPU and as the checker); a model that lives on the GPU goes through ONE pass of sgr_deform_points instead of
+the ~25 torch kernels below."""
 import torch
 
 
@@ -35,6 +37,8 @@ def update_mapping_points(gaussians, frame_idx, w2c, w2c_old, depth, depth_old, 
     if frame_mask.sum() == 0:
         return
     dev = gaussians.get_xyz.device
+    if dev.type == "cuda" and USE_HIP:
+        return _update_mapping_points_hip(gaussians, frame_idx, w2c, w2c_old, depth, depth_old, intrinsics, method)
     frame_mask = frame_mask.to(dev)
     transformation = torch.linalg.inv(torch.linalg.inv(w2c_old) @ w2c)
     if method == "rigid":
@@ -81,3 +85,43 @@ def update_mapping_points(gaussians, frame_idx, w2c, w2c_old, depth, depth_old, 
     scales = gaussians._scaling.detach()
     scales[frame_mask] = scales[frame_mask] + torch.log(rescale)
     gaussians._scaling = gaussians.replace_tensor_to_optimizer(scales, "scaling")["scaling"]
+
+
+USE_HIP = True
+
+
+def _update_mapping_points_hip(gaussians, frame_idx, w2c, w2c_old, depth, depth_old, intrinsics, method=None):
+    """Same update through the C ABI: the 4x4 algebra stays on the host side (three tiny matrices), the per-Gaussian work
+    is one kernel in place on the parameter storage; the Parameter / Adam-state replacement is the reference's."""
+    import ctypes as C
+    from splat_slam_amd import _native as nat
+    dev = gaussians.get_xyz.device
+    w2c_old = w2c_old.to(dev).float()
+    w2c = w2c.to(dev).float()
+    c2w_old = torch.linalg.inv(w2c_old)
+    transformation = torch.linalg.inv(c2w_old @ w2c)
+    tq = rotation_matrix_to_quaternion(transformation[:3, :3].unsqueeze(0))[0]
+    f = nat.SgrDeformFrame()
+    f.frame_idx, f.rigid = int(frame_idx), int(method == "rigid")
+    for name, t in (("w2c_old", w2c_old), ("c2w_old", c2w_old), ("transform", transformation)):
+        getattr(f, name)[:] = t.detach().cpu().reshape(-1).tolist()
+    f.quat_wxyz[:] = tq.detach().cpu().tolist()
+    f.intrinsics[:] = intrinsics.detach().float().cpu().reshape(-1).tolist()
+    keep = []
+    if not f.rigid:
+        dn = depth.to(device=dev, dtype=torch.float32).contiguous()
+        do = depth_old.to(device=dev, dtype=torch.float32).contiguous()
+        keep += [dn, do]
+        f.height, f.width = int(dn.shape[0]), int(dn.shape[1])
+        f.depth_new, f.depth_old = dn.data_ptr(), do.data_ptr()
+    ids = gaussians.unique_kfIDs.to(device=dev, dtype=torch.int32).contiguous()
+    xyz = gaussians._xyz.detach().contiguous()
+    rot = gaussians._rotation.detach().contiguous()
+    sc = gaussians._scaling.detach().contiguous()
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().sgr_deform_points(xyz.shape[0], ids.data_ptr(), C.byref(f), xyz.data_ptr(), rot.data_ptr(),
+                                              sc.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "sgr_deform_points")
+    gaussians._xyz = gaussians.replace_tensor_to_optimizer(xyz, "xyz")["xyz"]
+    gaussians._rotation = gaussians.replace_tensor_to_optimizer(rot, "rotation")["rotation"]
+    if not f.rigid:
+        gaussians._scaling = gaussians.replace_tensor_to_optimizer(sc, "scaling")["scaling"]

@@ -94,6 +94,7 @@ class GaussianModel:
         self.isotropic = False
         self.spatial_lr_scale = 1.0
         self._knn_fn = knn_fn
+        self.use_hip_compaction = True   # CUDA models prune through sgr_keep_list / sgr_gather_rows (bit-identical to torch)
 
     # ---- activations (gaussian_model.py:53-61,76-101)
     @property
@@ -325,8 +326,56 @@ class GaussianModel:
         self._xyz, self._features_dc, self._features_rest = t["xyz"], t["f_dc"], t["f_rest"]
         self._opacity, self._scaling, self._rotation = t["opacity"], t["scaling"], t["rotation"]
 
+    def _prune_hip(self, valid):
+        """prune_points on the device: ONE keep-list scan + ONE gather launch over every per-Gaussian tensor (parameters,
+        both Adam moments, densification statistics, keyframe ids) instead of ~25 boolean-index kernels."""
+        import ctypes as C
+        from splat_slam_amd import _native as nat
+        lib, dev, n = nat.lib(), self._xyz.device, int(valid.shape[0])
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        keep = valid.to(device=dev, dtype=torch.uint8).contiguous()
+        src = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        scratch = torch.empty(lib.sgr_compact_scratch_bytes(n), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.sgr_keep_list(n, keep.data_ptr(), src.data_ptr(), cnt.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                        stream), "sgr_keep_list")
+        m = int(cnt.item())                       # (the reference's boolean indexing synchronises here as well)
+        table, hold = [], []
+
+        def compact(t):
+            t = t.contiguous()
+            out = torch.empty((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            rb = (t.numel() // max(n, 1)) * t.element_size()
+            if rb and m:
+                table.append(nat.SgrRowTensor(t.data_ptr(), out.data_ptr(), rb))
+                hold.append(t)
+            return out
+
+        new_params = {}
+        for group in self.optimizer.param_groups:
+            p = group["params"][0]
+            st = self.optimizer.state.get(p, None)
+            np_ = compact(p.detach())
+            if st is not None:
+                st["exp_avg"], st["exp_avg_sq"] = compact(st["exp_avg"]), compact(st["exp_avg_sq"])
+                del self.optimizer.state[p]
+            group["params"][0] = nn.Parameter(np_.requires_grad_(True))
+            if st is not None:
+                self.optimizer.state[group["params"][0]] = st
+            new_params[group["name"]] = group["params"][0]
+        aux = [compact(getattr(self, a).to(dev)) for a in ("xyz_gradient_accum", "denom", "max_radii2D", "unique_kfIDs", "n_obs")]
+        if table:
+            arr = (nat.SgrRowTensor * len(table))(*table)
+            with torch.cuda.device(dev):
+                nat.check(lib.sgr_gather_rows(m, src.data_ptr(), len(table), arr, stream), "sgr_gather_rows")
+        self._adopt(new_params)
+        self.xyz_gradient_accum, self.denom, self.max_radii2D, self.unique_kfIDs, self.n_obs = aux
+
     def prune_points(self, mask):
         valid = ~mask
+        if self._xyz.is_cuda and self.optimizer is not None and self.use_hip_compaction:
+            return self._prune_hip(valid)
         self._adopt(self._prune_optimizer(valid))
         self.xyz_gradient_accum = self.xyz_gradient_accum[valid]
         self.denom = self.denom[valid]
