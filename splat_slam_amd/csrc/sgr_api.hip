@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) stats_kernel(int N, int ntiles, const int
   unsigned long long v = 0, r = 0, re = 0, ne = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) v += radii[i] > 0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
-    uint32_t c = ranges[(size_t)t * kRngStride].y - ranges[(size_t)t * kRngStride].x;
+    uint32_t c = ranges[(size_t)t * kRngStride].y - (ranges[(size_t)t * kRngStride].x & ~kOverfull);
     r += c; re += min(c, tile_maxc[t]); ne += c > 0;
   }
   atomicAdd(&out[0], v); atomicAdd(&out[1], r); atomicAdd(&out[2], re); atomicAdd(&out[3], ne);

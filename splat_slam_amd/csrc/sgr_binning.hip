@@ -38,8 +38,8 @@ __device__ uint32_t block1024_scan(const uint32_t* __restrict__ in, uint32_t* __
 }
 
 // K2: three independent scans per view, one 1024-thread block each (grid = (3, views)): (0) tile starts, (1) segment
-// bases of the partial-slot offsets, (2) segment bases of the compact visible list.  ranges[t] = (start, start): scatter uses .y
-// as the fill cursor, so after K3 it is the end of the tile's run.
+// bases of the partial-slot offsets, (2) segment bases of the compact visible list.  ranges[t] = (start, end) of the tile's
+// run; for tiles with more than kBucket pairs .x carries kOverfull and .y starts as scatter's fill cursor (= end after K3).
 __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   __shared__ uint32_t red[16];
   char* saved = tab.saved[blockIdx.y];
@@ -50,12 +50,23 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
     uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
     uint32_t R = block1024_scan(tile_count, tmp, L.ntiles, red, kCntStride);
     __syncthreads();
+    uint32_t over = 0;
     for (int t = threadIdx.x; t < L.ntiles; t += 1024) {
-      uint32_t s0 = tmp[t];
-      ranges[(size_t)t * kRngStride] = make_uint2(s0, s0);
+      const uint32_t s0 = tmp[t], c = tile_count[(size_t)t * kCntStride];
+      // <= kBucket pairs: K1 already binned them in the tile's bucket, the run [s0, s0+c) only addresses point_list.
+      // more: scatter_kernel fills the run; .y is its fill cursor and ends at s0 + c as well.
+      ranges[(size_t)t * kRngStride] = c <= (uint32_t)kBucket ? make_uint2(s0, s0 + c) : make_uint2(s0 | kOverfull, s0);
+      over += c > (uint32_t)kBucket ? 1u : 0u;
       tile_count[(size_t)t * kCntStride] = 0u;       // consumed: leave the counters clean for the next forward
     }
+    over = wave_scan_add_u32(over);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = over;
+    __syncthreads();
     if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int wv = 0; wv < 16; ++wv) tot += red[wv];
+      hdr->num_overfull = tot;
       hdr->num_rendered = R;
       hdr->overflow = (int64_t)R > L.cap ? 1u : 0u;
       hdr->sorted_count = (uint32_t)((int64_t)R > L.cap ? L.cap : (int64_t)R);
@@ -69,10 +80,10 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
 }
 
 // K3: grid = (ceil(N/1024), views); the block concatenates the visible lists of its four 256-Gaussian segments (K1)
-// into the view's compact visible list (absolute position = segment base from K2 + position in the segment list) and
-// scatters one (depth bits | Gaussian) key per (tile, Gaussian) pair into the tile's run.  Order inside a run is
-// arbitrary; K4 sorts it.  Waves beyond the lists leave at once (a SLAM view sees a few % of the map: typically one
-// live wave per block, all lanes busy).
+// into the view's compact visible list (absolute position = segment base from K2 + position in the segment list).
+// Binning is normally finished by then (K1's buckets); only if the view has tiles with more than kBucket pairs, the pairs
+// of THOSE tiles are scattered into their exactly sized runs (returning atomic on the tile cursor).  Order inside a run /
+// bucket is arbitrary; K4 sorts it.
 __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
   const int v = blockIdx.y;
   char* saved = tab.saved[v];
@@ -89,7 +100,7 @@ __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
   const uint32_t e1 = c[0], e2 = e1 + c[1], e3 = e2 + c[2], nvis = e3 + c[3];
   uint2* ranges = (uint2*)(saved + L.o_ranges);
   uint64_t* entries = (uint64_t*)(tab.scratch[v] + L.o_entries);
-  if (L.dbg & 4) return;
+  const bool any_overfull = ((const SavedHeader*)(saved + L.o_hdr))->num_overfull != 0;
 #pragma unroll 1
   for (uint32_t t = threadIdx.x; t < nvis; t += 256) {
     const int j = (t >= e1) + (t >= e2) + (t >= e3);
@@ -97,27 +108,23 @@ __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
     const uint32_t i = ((const uint32_t*)(saved + L.o_seg_list))[(s0 + j) * kSeg + k];
     const uint32_t vp = (j == 0 ? b[0] : (j == 1 ? b[1] : (j == 2 ? b[2] : b[3]))) + k;
     GRec* rec = (GRec*)(saved + L.o_grec) + i;
-    const float4 q0 = ((const float4*)rec)[0];
-    const uint32_t dbits = __float_as_uint(rec->depth);
-    const int cnt = (int)rec->touched;
     rec->vis_pos = vp;
     ((uint32_t*)(saved + L.o_vis_list))[vp] = i;
+    if (!any_overfull) continue;
+    const int cnt = (int)rec->touched;
     if (cnt == 0) continue;
+    const float4 q0 = ((const float4*)rec)[0];
+    const uint32_t dbits = __float_as_uint(rec->depth);
     const Rect r = unpack_rect(__float_as_uint(q0.z), __float_as_uint(q0.w));
     uint64_t key = ((uint64_t)dbits << 32) | i;
     const int w = r.x1 - r.x0;
-    // returning atomics are latency-bound: keep 4 in flight (most splats cover <= 4 bins)
-    for (int k0 = 0; k0 < cnt; k0 += 4) {
-      uint32_t pos[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        int kk = k0 + jj;
-        if (kk < cnt) pos[jj] = (L.dbg & 8) ? ranges[(size_t)((r.y0 + kk / w) * L.gx + r.x0 + kk % w) * kRngStride].x + (i & 7u)
-                                            : atomicAdd(&ranges[(size_t)((r.y0 + kk / w) * L.gx + r.x0 + kk % w) * kRngStride].y, 1u);
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-        if (k0 + jj < cnt && (int64_t)pos[jj] < L.cap) entries[pos[jj]] = key;
+    // pairs of over-full tiles (> kBucket pairs; K1 could bin only the first kBucket) go into the exactly sized run
+    for (int kk = 0; kk < cnt; ++kk) {
+      const size_t tl = (size_t)((r.y0 + kk / w) * L.gx + r.x0 + kk % w);
+      const uint32_t x = ranges[tl * kRngStride].x;
+      if (!(x & kOverfull)) continue;
+      const uint32_t pos = atomicAdd(&ranges[tl * kRngStride].y, 1u);
+      if ((int64_t)pos < L.cap) entries[pos] = key;
     }
   }
 }

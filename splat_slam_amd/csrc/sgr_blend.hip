@@ -127,21 +127,24 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   }
 
   const uint2 rng = ranges[(size_t)tile * kRngStride];
-  const int64_t begin = rng.x;
+  const int64_t begin = rng.x & ~kOverfull;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
   const int count = endc > begin ? (int)(endc - begin) : 0;
+  // unsorted keys: the tile's bucket (filled by K1) unless the tile had more than kBucket pairs (then its exact run)
+  const uint64_t* __restrict__ keys_in = (rng.x & kOverfull) ? entries + begin
+                                                              : (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
 
   // ---- sort this tile's run by (depth bits, Gaussian index) and publish the index list for the backward
   uint32_t g_first = 0;                       // sorted Gaussian index of list position `lane` (count <= 64 path)
   int mode = 0;                               // 0: registers, 1: LDS, 2: global
   if (count <= kWave) {
-    uint64_t key = lane < count ? entries[begin + lane] : ~0ull;
+    uint64_t key = lane < count ? keys_in[lane] : ~0ull;
     key = wave_sort64(key, count, lane);
     g_first = (uint32_t)key;
     if (lane < count) point_list[begin + lane] = g_first;
   } else if (count <= kLdsSortMax) {
     mode = 1;
-    for (int i = lane; i < count; i += kWave) keys[i] = entries[begin + i];
+    for (int i = lane; i < count; i += kWave) keys[i] = keys_in[i];
     __builtin_amdgcn_wave_barrier();
     wave_sort_any(count, lane, [&](int i) { return keys[i]; }, [&](int i, uint64_t v) { keys[i] = v; },
                   [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); });
@@ -472,7 +475,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
     }
   }
   const uint2 rng = ranges[(size_t)tile * kRngStride];
-  const int64_t begin = rng.x;
+  const int64_t begin = rng.x & ~kOverfull;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
   const int count = endc > begin ? (int)(endc - begin) : 0;
   if (count == 0) return;

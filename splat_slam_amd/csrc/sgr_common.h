@@ -23,6 +23,11 @@ constexpr int kWave = 64;
 // binning kernels, one counter per line does not
 constexpr int kCntStride = 4;          // uint32 units between two tiles' pair counters
 constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
+// Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the
+// key goes straight into the tile's fixed bucket -- no second pass.  Only tiles with more than kBucket pairs are re-scattered
+// by scatter_kernel into the exactly sized runs (ranges[t].x carries kOverfull for them).
+constexpr int kBucket = 64;
+constexpr uint32_t kOverfull = 0x80000000u;
 constexpr int kSeg = 256;              // Gaussians per preprocess segment (one 256-thread block), see preprocess_fwd_kernel
 constexpr int kSegShift = 8;
 
@@ -40,7 +45,8 @@ struct SavedHeader {
   uint32_t overflow;       // != 0 when R > capacity (pairs were dropped)
   uint32_t sorted_count;   // number of pairs actually binned = min(R, capacity)
   uint32_t num_visible;    // V: Gaussians with radii > 0
-  uint32_t pad[12];
+  uint32_t num_overfull;   // tiles with more than kBucket pairs (scatter_kernel re-bins only those)
+  uint32_t pad[11];
 };
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -69,7 +75,7 @@ struct LOff {
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_seg_list, o_entries, o_partials, o_tau_part, o_gradrec, o_taurec;
+      o_seg_list, o_entries, o_bucket, o_partials, o_tau_part, o_gradrec, o_taurec;
 };
 // shared (view independent) scalars of a batch
 struct Common {
@@ -109,7 +115,7 @@ struct Layout {
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
       o_seg_list, saved_bytes, zero_bytes;
   // scratch (forward)
-  size_t o_entries;
+  size_t o_entries, o_bucket;
   // scratch (backward) -- aliases the forward scratch
   size_t o_partials, o_tau_part, o_gradrec, o_taurec, scratch_bytes;
   int pre_blocks, nseg;
@@ -147,6 +153,7 @@ struct Layout {
 
     o = 0;
     o_entries = take(c * 8);
+    o_bucket = take((size_t)ntiles * kBucket * 8);
     size_t fwd = o;
     o = 0;
     o_partials = take(c * 48);
@@ -163,7 +170,7 @@ struct Layout {
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;
     d.o_n_contrib = o_n_contrib; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
     d.o_block_base_t = o_block_base_t; d.o_block_base_v = o_block_base_v; d.o_vis_list = o_vis_list;
-    d.o_seg_list = o_seg_list; d.o_entries = o_entries; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
+    d.o_seg_list = o_seg_list; d.o_entries = o_entries; d.o_bucket = o_bucket; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
     d.o_gradrec = o_gradrec; d.o_taurec = o_taurec;
     return d;
   }

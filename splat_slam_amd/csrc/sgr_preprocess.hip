@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ int32_t* p_radii[kMaxViews];
   __shared__ int32_t* p_ntouched[kMaxViews];
   __shared__ const float* p_campos[kMaxViews];
+  __shared__ char* p_scratch[kMaxViews];
   __shared__ uint8_t cand[kMaxViews][kSeg];
   __shared__ uint32_t wtot[kMaxViews][4];
   __shared__ uint32_t vstart[kMaxViews + 1];
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     if (u < nviews) {
       if (tid < 16) mats[u][tid] = tab.viewmatrix[u][tid];
       else if (tid < 32) mats[u][tid] = tab.projmatrix[u][tid - 16];
-      if (tid == 32) { p_saved[u] = tab.saved[u]; p_radii[u] = tab.radii[u]; p_ntouched[u] = tab.n_touched[u]; p_campos[u] = tab.campos[u]; }
+      if (tid == 32) { p_saved[u] = tab.saved[u]; p_radii[u] = tab.radii[u]; p_ntouched[u] = tab.n_touched[u]; p_campos[u] = tab.campos[u]; p_scratch[u] = tab.scratch[u]; }
     }
   }
   if (tid <= kMaxViews) { vbase_t[tid] = 0u; vbase_v[tid] = 0u; }
@@ -396,14 +397,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
                            __uint_as_float((uint32_t)o.x1 | ((uint32_t)o.y1 << 16)));
       rec[1] = make_float4(o.A, o.B, o.C, o.opac);
       rec[2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
-      uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
-      if (!(L.dbg & 16))
-      for (int y = o.y0; y < o.y1; ++y)
-        for (int x = o.x0; x < o.x1; ++x) {
-          if (L.dbg & 64) __hip_atomic_fetch_add(&tile_count[(size_t)(y * L.gx + x) * kCntStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          else atomicAdd(&tile_count[(size_t)(y * L.gx + x) * kCntStride], 1u);
-        }
     }
+    // count the pairs per tile; the returning atomic is the pair's rank in its tile: while the tile's bucket has room the
+    // key is binned right here.  The first 4 atomics (most splats cover <= 4 bins) are issued now and consumed after the
+    // block scans below, which hide their round trip.
+    uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
+    uint64_t* bucket = (uint64_t*)(p_scratch[v] + L.o_bucket);
+    const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
+    const int w = o.x1 - o.x0;
+    uint32_t rank[4] = {0u, 0u, 0u, 0u}, tl[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      if (jj < (int)cnt) {
+        tl[jj] = (uint32_t)((o.y0 + jj / w) * L.gx + o.x0 + jj % w);
+        rank[jj] = atomicAdd(&tile_count[(size_t)tl[jj] * kCntStride], 1u);
+      }
     uint32_t tot_t, tot_v;
     const uint32_t ex_t = carry_t + block256_exclusive_scan(cnt, red, tot_t);
     const uint32_t ex_v = carry_v + block256_exclusive_scan(vis, red, tot_v);
@@ -415,6 +423,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
     __syncthreads();
     if (o.visible) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        if (jj < (int)cnt && rank[jj] < (uint32_t)kBucket) bucket[(size_t)tl[jj] * kBucket + rank[jj]] = key;
+      for (int k0 = 4; k0 < (int)cnt; k0 += 4) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int kk = k0 + jj;
+          if (kk < (int)cnt) {
+            tl[jj] = (uint32_t)((o.y0 + kk / w) * L.gx + o.x0 + kk % w);
+            rank[jj] = atomicAdd(&tile_count[(size_t)tl[jj] * kCntStride], 1u);
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (k0 + jj < (int)cnt && rank[jj] < (uint32_t)kBucket) bucket[(size_t)tl[jj] * kBucket + rank[jj]] = key;
+      }
       const uint32_t k = ex_v - vbase_v[v];
       // touched, in-segment prefix (abs_offset() adds the segment base), list slot (relative; scatter_kernel makes it
       // absolute), SH clamp bits
