@@ -179,7 +179,12 @@ def main():
             nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], vb.radii.data_ptr(), stats,
                                           torch.cuda.current_stream(dev).cuda_stream), "sgr_query_stats")
             per_view.append([int(x) for x in stats])
+        hist = (C.c_int64 * 8)()
+        nat.check(lib.sgr_query_list_histogram(C.byref(ws), N, intr["H"], intr["W"], hist, torch.cuda.current_stream(dev).cuda_stream),
+                  "sgr_query_list_histogram")
+        list_hist = dict(zip(["0", "1-4", "5-8", "9-16", "17-32", "33-64", "65-256", ">256"], [int(x) for x in hist]))
     else:
+        list_hist = None
         pkg = render(cam0, loop.gaussians, PipelineParams(), bg)
         fn = pkg["render"].grad_fn
         saved = fn.saved_tensors[-1]
@@ -249,7 +254,7 @@ def main():
         "map_iterations_per_s": round(args.steps / elapsed, 2),
         "refine_iterations_per_s": None if refine_its is None else round(refine_its, 1),
         "work_per_view": {"visible_gaussians": V, "tile_pairs_R": R, "tile_pairs_walked_R_eff": R_eff_sum // nv,
-                          "nonempty_tiles": tiles_nonempty},
+                          "nonempty_tiles": tiles_nonempty, "tiles_by_walked_list_length_last_view": list_hist},
         "roofline": roofline,
     }
     if args.profile_all:

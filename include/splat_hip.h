@@ -157,6 +157,10 @@ int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_h
  *   stats[3] = number of non-empty 8x8 tiles */
 int sgr_query_stats(const SgrWorkspace* ws, int32_t num_gaussians, int32_t image_height, int32_t image_width,
                     const int32_t* radii, int64_t stats_host[4], void* stream);
+/* Histogram of the per-tile list lengths the blend kernels walk (same synchronous, accounting-only use):
+ * bins 0, 1-4, 5-8, 9-16, 17-32, 33-64, 65-256, >256 splats. */
+int sgr_query_list_histogram(const SgrWorkspace* ws, int32_t num_gaussians, int32_t image_height, int32_t image_width,
+                             int64_t hist_host[8], void* stream);
 
 /* Per-kernel HIP-event timing.  kind: 0 preprocess_fwd (+ per-tile pair counting), 1 tile_scan, 2 scatter,
  * 3/4/6 unused, 5 blend_fwd (+ in-wave tile sort), 7 blend_bwd, 8 preprocess_bwd (+ pose reduce).  sgr_profile_enable(mask) arms event pairs around the kinds whose

@@ -97,6 +97,7 @@ SIGNATURES = {
                                C.POINTER(SgrGradInputs), C.POINTER(SgrWorkspace), _fp]),
     "sgr_query": (C.c_int, [_fp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _fp]),
     "sgr_query_stats": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(C.c_int64), _fp]),
+    "sgr_query_list_histogram": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _fp]),
     "sgr_profile_enable": (C.c_int, [C.c_uint32]),
     "sgr_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "sgr_mapping_loss": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float,

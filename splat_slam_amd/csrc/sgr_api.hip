@@ -92,6 +92,17 @@ __global__ void __launch_bounds__(256) stats_kernel(int N, int ntiles, const int
   atomicAdd(&out[0], v); atomicAdd(&out[1], r); atomicAdd(&out[2], re); atomicAdd(&out[3], ne);
 }
 
+// walked list length (min(pairs, last contributor)) of every tile into 8 bins: 0, 1-4, 5-8, 9-16, 17-32, 33-64, 65-256, >256
+__global__ void __launch_bounds__(256) hist_kernel(int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_maxc,
+                                                    unsigned long long* __restrict__ out) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+    uint32_t c = ranges[(size_t)t * kRngStride].y - (ranges[(size_t)t * kRngStride].x & ~kOverfull);
+    c = min(c, tile_maxc[t]);
+    int b = c == 0 ? 0 : c <= 4 ? 1 : c <= 8 ? 2 : c <= 16 ? 3 : c <= 32 ? 4 : c <= 64 ? 5 : c <= 256 ? 6 : 7;
+    atomicAdd(&out[b], 1ull);
+  }
+}
+
 
 static int check_settings(const SgrSettings* s, const SgrInputs* in) {
   const int N = s->num_gaussians, H = s->image_height, W = s->image_width;
@@ -453,6 +464,21 @@ int sgr_query_stats(const SgrWorkspace* ws, int32_t N, int32_t H, int32_t W, con
   HIP_TRY(hipMemcpyAsync(h, d, 32, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   for (int i = 0; i < 4; ++i) stats_host[i] = (int64_t)h[i];
+  return SGR_OK;
+}
+
+int sgr_query_list_histogram(const SgrWorkspace* ws, int32_t N, int32_t H, int32_t W, int64_t hist_host[8], void* stream) {
+  if (!ws || !ws->saved || !ws->scratch || !hist_host) return set_error(SGR_ERR_INVALID, "null argument");
+  Layout L = make_layout(N, H, W, ws->capacity);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* d = (unsigned long long*)ws->scratch;
+  HIP_TRY(hipMemsetAsync(d, 0, 64, st));
+  hipLaunchKernelGGL(hist_kernel, dim3(32), dim3(256), 0, st, L.ntiles, (const uint2*)((char*)ws->saved + L.o_ranges),
+                     (const uint32_t*)((char*)ws->saved + L.o_tile_maxc), d);
+  unsigned long long h[8];
+  HIP_TRY(hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < 8; ++i) hist_host[i] = (int64_t)h[i];
   return SGR_OK;
 }
 
