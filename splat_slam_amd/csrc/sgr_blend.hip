@@ -301,6 +301,35 @@ __device__ __forceinline__ float group_shr1(float v, float fill, int lane) {
   if (GW == 32) r = (lane == 32) ? fill : r;
   return r;
 }
+// 8-lane groups (two per DPP row): row_shr:1 / :2 leak the upper neighbour group's tail into lanes 8 / 8,9 of the row, so
+// those lanes keep their value (one select per step); row_shr:4 is confined by its bank mask (banks 1 and 3 only).
+template <>
+__device__ __forceinline__ float group_scan_mul<8>(float v) {
+  const int l8 = (int)(threadIdx.x & 7);
+  float t = v;
+  asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") : "+v"(t));
+  v = l8 == 0 ? v : t;
+  t = v;
+  asm(SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf") : "+v"(t));
+  v = l8 < 2 ? v : t;
+  asm(SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xa") : "+v"(v));
+  return v;
+}
+template <>
+__device__ __forceinline__ float group_scan_add<8>(float v) {
+  const int l8 = (int)(threadIdx.x & 7);
+  float d = dpp_f<DPP_ROW_SHR1>(0.f, v);
+  v += l8 == 0 ? 0.f : d;
+  d = dpp_f<DPP_ROW_SHR2>(0.f, v);
+  v += l8 < 2 ? 0.f : d;
+  v += dpp_f<DPP_ROW_SHR4, 0xf, 0xa>(0.f, v);
+  return v;
+}
+template <>
+__device__ __forceinline__ float group_shr1<8>(float v, float fill, int lane) {
+  float r = dpp_f<DPP_ROW_SHR1>(fill, v);
+  return (lane & 7) == 0 ? fill : r;
+}
 
 // The hot loop of the backward, TWO pixels per lane.  blend_bwd is bound by VALU issue (one wave64 op = 4 cycles), and
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot), so every lane carries its splat
@@ -361,15 +390,14 @@ __device__ __forceinline__ void bwd_chunk2(
     const float2 b1 = *(const float2*)&pixB2[gp * 2 + 1];
     const int nc0 = __float_as_int(b1.x), nc1 = __float_as_int(b1.y);
     if (GW == kWave && __builtin_amdgcn_readfirstlane(max(nc0, nc1)) <= c * kWave) continue;   // both ended before this chunk
-    const int p0 = pair_first_pixel<GW>(gp);
-    const float pxf = tx0 + (float)(p0 & 7);
-    const v2f dx = splat2(mx) - (v2f){pxf, pxf + (float)PP};
-    const float dy = my - (ty0 + (float)(p0 >> 3));
+    const int p0 = pair_first_pixel<GW>(gp), p1 = p0 + PP;     // horizontally adjacent, or (GW = 8) vertically adjacent
+    const v2f dx = splat2(mx) - (v2f){tx0 + (float)(p0 & 7), tx0 + (float)(p1 & 7)};
+    const v2f dy = splat2(my) - (v2f){ty0 + (float)(p0 >> 3), ty0 + (float)(p1 >> 3)};
     // eval_alpha() on the pair, same operation order
     const v2f adx = splat2(A) * dx;
-    const float cdy2 = (Cc * dy) * dy;
-    const v2f qf = __builtin_elementwise_fma(adx, dx, splat2(cdy2));
-    const v2f bdxdy = (splat2(B) * dx) * splat2(dy);
+    const v2f cdy2 = (splat2(Cc) * dy) * dy;
+    const v2f qf = __builtin_elementwise_fma(adx, dx, cdy2);
+    const v2f bdxdy = (splat2(B) * dx) * dy;
     const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
     const v2f G = {__expf(power.x), __expf(power.y)};
     const v2f og = splat2(op) * G;
@@ -410,12 +438,12 @@ __device__ __forceinline__ void bwd_chunk2(
     gd.y = ok1 ? gd.y : 0.f;
     a_o += gd;
     const v2f gg = gd * splat2(op);                      // G * dL/dG
-    const v2f gxv = gg * dx, gyv = gg * splat2(dy);
+    const v2f gxv = gg * dx, gyv = gg * dy;
     s_gx += gxv;
     s_gy += gyv;
     s_gxx = __builtin_elementwise_fma(gxv, dx, s_gxx);
-    s_gxy = __builtin_elementwise_fma(gxv, splat2(dy), s_gxy);
-    s_gyy = __builtin_elementwise_fma(gyv, splat2(dy), s_gyy);
+    s_gxy = __builtin_elementwise_fma(gxv, dy, s_gxy);
+    s_gyy = __builtin_elementwise_fma(gyv, dy, s_gyy);
   }
   float t_gx = s_gx.x + s_gx.y, t_gy = s_gy.x + s_gy.y, t_gxx = s_gxx.x + s_gxx.y, t_gxy = s_gxy.x + s_gxy.y,
         t_gyy = s_gyy.x + s_gyy.y, t_o = a_o.x + a_o.y, t_r = a_r.x + a_r.y, t_g = a_g.x + a_g.y, t_b = a_b.x + a_b.y,
@@ -514,7 +542,11 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
   const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
 
-  if (eff <= 16) {
+  if (eff <= 8) {          // half of the iterations of the 16-lane form: 16 pixels per iteration
+    stage(std::integral_constant<int, 8>{});
+    bwd_chunk2<8>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty, halfW,
+                  halfH, partials, cap);
+  } else if (eff <= 16) {
     stage(std::integral_constant<int, 16>{});
     bwd_chunk2<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty, halfW,
                    halfH, partials, cap);
