@@ -85,7 +85,9 @@ struct Common {
   const float* projraw;
 };
 
-int debug_flags();   // SGR_DEBUG environment variable (timing experiments only; 0 in production)
+// SGR_DEBUG environment variable -- stage-cost experiments only (scripts/stage_times.py), results are wrong when set:
+//   bit 0: preprocess_fwd stops after the cull / compact phase     bit 1: ... and skips the visibility test's arithmetic
+int debug_flags();
 
 // Everything later stages gather BY GAUSSIAN for one view, as ONE 64-byte record (= one HBM sector pair, one L2 line
 // half) instead of seven SoA arrays: a gather of 8...16 bytes costs a whole sector, so seven arrays meant up to seven
