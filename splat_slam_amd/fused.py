@@ -372,16 +372,16 @@ class FusedMappingLoop(MappingLoop):
                 st.exp_lr, st.exp_beta1, st.exp_beta2, st.exp_eps = 0.01, 0.9, 0.999, 1e-8
         return st
 
-    def _run_span(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True):
+    def _run_span(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True, initialization=False):
         """len(lrs) regular iterations with ONE host call (sgr_map_run): iteration k renders window_cams plus
         pool_cams[picks[k]] and steps Adam with the xyz learning rate lrs[k]."""
         n_it = len(lrs)
         if self.world > 1 or n_it == 0:
             raise RuntimeError("_run_span is the single-GPU fast path")
         pl = self._plan()
-        self._views_array(list(window_cams) + list(pool_cams), False)      # probes new cameras, settles the capacity
-        win = self._views_array(window_cams, False, images=False) if window_cams else None
-        pool = self._views_array(pool_cams, False, images=False) if pool_cams else None
+        self._views_array(list(window_cams) + list(pool_cams), initialization)   # probes new cameras, settles the capacity
+        win = self._views_array(window_cams, initialization, images=False) if window_cams else None
+        pool = self._views_array(pool_cams, initialization, images=False) if pool_cams else None
         st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
         per = len(picks) // n_it if picks else 0
         run = nat.SgrMapRun()
@@ -587,12 +587,36 @@ class FusedMappingLoop(MappingLoop):
     # ------------------------------------------------------------------------------------------------ loops
     def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
         vb, nt = None, None
-        for mapping_iteration in range(self.init_itr_num if iters is None else iters):
+        total = self.init_itr_num if iters is None else iters
+        mapping_iteration = 0
+        while mapping_iteration < total:
+            # regular iterations up to the next densify / reset point: ONE host call (the learning rate is not scheduled
+            # during initialisation, mapper.py:303-353)
+            n = 0
+            # (the last iteration goes through _step: its rendered images are the return value, mapper.py:355-398)
+            while (self.world == 1 and self.span_calls and mapping_iteration + n < total - 1
+                   and (mapping_iteration + n) % self.init_gaussian_update != 0
+                   and self.iteration_count + n + 1 != self.init_gaussian_reset
+                   and self.iteration_count + n + 1 != self.opt_params.densify_from_iter):
+                n += 1
+            if n > 0:
+                self._ensure_state()
+                lr = float(self._xyz_group()["lr"])
+                self._run_span([viewpoint], [], [], [lr] * n, 0.0, "none", initialization=True)
+                self.iteration_count += n
+                mapping_iteration += n
+                vb = self._views[viewpoint.uid]
+                nt = vb.n_touched
+                self._since_check += n
+                if self._since_check >= self.check_every:
+                    self.check_overflow()
+                continue
             self.iteration_count += 1
             self._ensure_state()
             densify = mapping_iteration % self.init_gaussian_update == 0
             reset = self.iteration_count == self.init_gaussian_reset or (
                 self.iteration_count == self.opt_params.densify_from_iter)
+            mapping_iteration += 1
             if densify or reset:
                 # the reference densifies / resets between backward and optimizer.step (mapper.py:339-352): tensors
                 # re-created there have grad None and are skipped by Adam

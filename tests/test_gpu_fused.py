@@ -359,3 +359,32 @@ def test_empty_map_and_invisible_map_are_handled():
         assert torch.equal(f.gaussians._xyz.detach(), before)
         assert torch.isfinite(vb.loss).all()
     assert torch.isfinite(f.gaussians._scaling).all() and torch.isfinite(f.gaussians._opacity).all()
+
+
+def test_initialize_map_with_run_calls_equals_iteration_by_iteration():
+    """initialize_map (mapper.py:303-398): the regular iterations between densification points as sgr_map_run calls ==
+    one sgr_map_step per iteration, bit for bit, including the Gaussian counts after every densify / prune."""
+    import copy
+    from splat_slam_amd.fused import FusedMappingLoop
+    syn, params, cams = _scene(n=1800, views=1, seed=31)
+    cfg = copy.deepcopy(syn.DEFAULT_CONFIG)
+    tr = cfg["mapping"]["Training"]
+    tr["init_itr_num"], tr["init_gaussian_update"], tr["init_gaussian_reset"] = 47, 20, 33
+    cfg["mapping"]["opt_params"]["densify_from_iter"] = 10 ** 9
+    out = []
+    for span in (True, False):
+        loop = FusedMappingLoop(cfg, device=DEV, span_calls=span)
+        loop.gaussians = syn.model_from_parameters(params, device=DEV)
+        cam = _fresh_cams(syn, cams)[0]
+        loop.viewpoints = {0: cam}
+        loop.current_window = [0]
+        torch.manual_seed(11)
+        pkg = loop.initialize_map(0, cam)
+        torch.cuda.synchronize()
+        gm = loop.gaussians
+        out.append([gm._xyz.detach().clone(), gm._features_dc.detach().clone(), gm._opacity.detach().clone(),
+                    gm._scaling.detach().clone(), gm._rotation.detach().clone(), pkg["render"].clone(), pkg["n_touched"].clone(),
+                    gm.xyz_gradient_accum.clone(), torch.tensor([loop.iteration_count])])
+    assert out[0][0].shape == out[1][0].shape and out[0][0].shape[0] != 1800          # densification did change N
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
