@@ -214,3 +214,26 @@ def test_map_deformation_kernel_matches_the_torch_formulation():
             p = {"xyz": a._xyz, "rotation": a._rotation, "scaling": a._scaling}[name]
             assert float(a.optimizer.state[p]["exp_avg"].abs().max()) == 0.0
         assert not torch.equal(a._xyz.detach()[moved], _random_model(900, seed=4)._xyz.detach()[moved])
+
+
+def test_densify_and_prune_with_hip_row_selection_equals_torch():
+    """densify_and_clone's row selection through sgr_keep_list / sgr_gather_rows: the whole densify_and_prune (clone, split with
+    the same torch.normal draws, prune) ends in bit-identical models."""
+    res = []
+    for hip in (True, False):
+        gm = _random_model(1500, seed=21)
+        gm.use_hip_compaction = hip
+        with torch.no_grad():
+            gm._scaling.data = gm._scaling.data * 0.2 - 2.5          # some above, some below the 1 % extent split threshold
+        gm.xyz_gradient_accum = torch.rand(1500, 1, generator=torch.Generator().manual_seed(1)).to(DEV) * 1e-3
+        gm.denom = torch.ones(1500, 1, device=DEV)
+        torch.manual_seed(77)
+        with torch.no_grad():
+            gm.densify_and_prune(0.0002, 0.3, 6.0, 20)
+        res.append(gm)
+    a, b = res
+    assert a.get_xyz.shape[0] == b.get_xyz.shape[0] and a.get_xyz.shape[0] != 1500
+    for name in ["_xyz", "_features_dc", "_opacity", "_scaling", "_rotation", "unique_kfIDs", "n_obs", "max_radii2D", "denom"]:
+        assert torch.equal(getattr(a, name).detach(), getattr(b, name).detach()), name
+    for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
+        assert torch.equal(a.optimizer.state[ga["params"][0]]["exp_avg"], b.optimizer.state[gb["params"][0]]["exp_avg"])
