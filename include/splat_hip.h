@@ -17,6 +17,18 @@
  *   sgr_adam_step          -> torch.optim.Adam(eps=1e-15) over the GaussianModel groups,
  *                             thirdparty/gaussian_splatting/scene/gaussian_model.py:264-313, stepped at
  *                             src/mapper.py:352,557,703
+ *   sgr_activate,
+ *   sgr_gaussian_adam_step -> the activation getters (exp / normalize / sigmoid, gaussian_model.py:76-101) and the Adam step of
+ *                             the five per-Gaussian groups incl. the isotropy regulariser of src/mapper.py:487-488
+ *   sgr_masked_adam        -> the keyframe (exposure) optimiser of src/mapper.py:1096-1111, stepped at :561
+ *   sgr_map_views          -> the per-view body of Mapper.map (src/mapper.py:426-490): render, loss, backward for <= 16 views
+ *   sgr_map_step           -> one iteration of Mapper.map / initialize_map / final_refine (src/mapper.py:303-353, 414-568, 656-708)
+ *   sgr_map_run            -> a run of such iterations between two densify / reset points (the `for` loops at :304, :414, :668)
+ *   sgr_deform_points      -> Mapper.update_mapping_points, src/mapper.py:154-255
+ *   sgr_keep_list,
+ *   sgr_gather_rows        -> prune_points / _prune_optimizer and the row selects of densify_and_clone,
+ *                             thirdparty/gaussian_splatting/scene/gaussian_model.py:519-600, 700-713
+ *   sgr_query*, sgr_profile_* -> (no reference counterpart) capacity protocol, work counters, per-kernel HIP-event timing
  *   sknn_dist2             -> simple_knn._C.distCUDA2, thirdparty/gaussian_splatting/scene/gaussian_model.py:18,194-200
  *   se3_*                  -> lietorch SE3 ops used on the mapping path, thirdparty/glorie_slam/depth_video.py:327-330
  *                             (SE3(pose).inv().matrix()), and the tau convention of
