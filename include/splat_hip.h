@@ -19,15 +19,15 @@
  *                             src/mapper.py:352,557,703
  *   sgr_activate,
  *   sgr_gaussian_adam_step -> the activation getters (exp / normalize / sigmoid, gaussian_model.py:76-101) and the Adam step of
- *                             the five per-Gaussian groups incl. the isotropy regulariser of src/mapper.py:487-488
+ *                             the five per-Gaussian groups incl. the isotropy regulariser of src/mapper.py:487-489
  *   sgr_masked_adam        -> the keyframe (exposure) optimiser of src/mapper.py:1096-1111, stepped at :561
  *   sgr_map_views          -> the per-view body of Mapper.map (src/mapper.py:426-490): render, loss, backward for <= 16 views
  *   sgr_map_step           -> one iteration of Mapper.map / initialize_map / final_refine (src/mapper.py:303-353, 414-568, 656-708)
- *   sgr_map_run            -> a run of such iterations between two densify / reset points (the `for` loops at :304, :414, :668)
+ *   sgr_map_run            -> a run of such iterations between two densify / reset points (the `for` loops at :304, :414, :656)
  *   sgr_deform_points      -> Mapper.update_mapping_points, src/mapper.py:154-255
  *   sgr_keep_list,
  *   sgr_gather_rows        -> prune_points / _prune_optimizer and the row selects of densify_and_clone,
- *                             thirdparty/gaussian_splatting/scene/gaussian_model.py:519-600, 700-713
+ *                             thirdparty/gaussian_splatting/scene/gaussian_model.py:519-557, 690-719
  *   sgr_query*, sgr_profile_* -> (no reference counterpart) capacity protocol, work counters, per-kernel HIP-event timing
  *   sknn_dist2             -> simple_knn._C.distCUDA2, thirdparty/gaussian_splatting/scene/gaussian_model.py:18,194-200
  *   se3_*                  -> lietorch SE3 ops used on the mapping path, thirdparty/glorie_slam/depth_video.py:327-330
@@ -316,7 +316,7 @@ int sgr_masked_adam(int32_t rows, int32_t row_width, float* param, const float* 
  * (unique_kfIDs == frame_idx) are depth-rescaled along the old camera's ray (unless rigid), moved by `transform`
  * (= inv(inv(w2c_old) @ w2c_new), host, row-major) and rotated by its quaternion; every rotation leaves normalised (the
  * reference writes the activated rotations back).  In place on the raw parameter tensors; resetting the Adam moments of
- * the three tensors (replace_tensor_to_optimizer, gaussian_model.py:603-617) stays with the caller. */
+ * the three tensors (replace_tensor_to_optimizer, gaussian_model.py:488-501) stays with the caller. */
 typedef struct SgrDeformFrame {
   int32_t frame_idx;
   int32_t rigid;               /* != 0: pose change only (no depth rescale, depth maps unused) */
@@ -332,7 +332,7 @@ typedef struct SgrDeformFrame {
 int sgr_deform_points(int64_t n, const int32_t* unique_kfIDs, const SgrDeformFrame* frame, float* xyz, float* rotation,
                       float* scaling, void* stream);
 
-/* Densify / prune compaction (gaussian_model.py:519-600: prune_points, _prune_optimizer and the index selects of
+/* Densify / prune compaction (gaussian_model.py:519-557 prune_points, _prune_optimizer; :690-719 the row selects of
  * densify_and_clone / densify_and_split): sgr_keep_list turns a byte mask into the ascending list of kept row indices
  * (count written to a device int64, no host sync); sgr_gather_rows copies rows src_rows[k] -> k for up to any number of
  * tensors (parameters, Adam moments, statistics, keyframe ids ...) in one launch per 32 tensors. */

@@ -3,7 +3,7 @@
 //
 // Replaces the torch-op chains of Mapper.update_mapping_points (/root/reference/src/mapper.py:154-255) and of
 // GaussianModel.prune_points / _prune_optimizer / cat_tensors_to_optimizer
-// (/root/reference/thirdparty/gaussian_splatting/scene/gaussian_model.py:519-600): ~20 elementwise / index kernels per
+// (/root/reference/thirdparty/gaussian_splatting/scene/gaussian_model.py:519-597): ~20 elementwise / index kernels per
 // call become one pass over the Gaussians, respectively one scan plus one gather pass over ALL per-Gaussian tensors.
 #include <cstring>
 

@@ -158,7 +158,7 @@ def _random_model(n, seed=0):
 
 
 def test_prune_points_hip_compaction_equals_torch_indexing():
-    """gaussian_model.py:519-560: one keep-list scan + one gather launch over all per-Gaussian tensors is bit-identical to
+    """gaussian_model.py:519-557: one keep-list scan + one gather launch over all per-Gaussian tensors is bit-identical to
     the reference's chain of boolean-index selects (parameters, Adam moments, statistics, keyframe ids)."""
     for n, frac in ((1, 0.0), (777, 0.3), (5000, 0.95), (300, 1.0)):
         mask = (torch.rand(n, generator=torch.Generator().manual_seed(n)) < frac).to(DEV)
