@@ -349,8 +349,7 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
     const int r = tab.radii[v][i];
     if (r > 0) {
       any = true;
-      const uint32_t pos = grec_of(tab.saved[v], L)[i].vis_pos;
-      const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)pos * 4;
+      const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)i * 4;
       float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
       a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
       a[8] += r2.x; a[9] += r2.y; a[10] += r2.z; a[11] += r2.w; a[12] += r3.x; a[13] += r3.y;

@@ -718,7 +718,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                           abs_offset(saved, L, (uint32_t)i, q3.y), q3.x, q3.w,
                           (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
                           dshs, accumulate, acc, tau);
-  float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)t * 4;
+  // the record sits at the GAUSSIAN's index (one full 64-byte sector): the gather pass then needs no list-slot lookup
+  float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)i * 4;
   rec[0] = make_float4(acc.p[0], acc.p[1], acc.p[2], acc.rgb_or_sh0[0]);
   rec[1] = make_float4(acc.rgb_or_sh0[1], acc.rgb_or_sh0[2], acc.op, acc.s[0]);
   rec[2] = make_float4(acc.s[1], acc.s[2], acc.q[0], acc.q[1]);
@@ -754,8 +755,8 @@ __global__ void __launch_bounds__(256) grad_gather_kernel(
     uint32_t pos = 0;
     if (r > 0) {
       any = true;
-      pos = grec_of(tab.saved[v], L)[i].vis_pos;
-      const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)pos * 4;
+      if (tab.dL_dtau[v]) pos = grec_of(tab.saved[v], L)[i].vis_pos;       // (only the pose terms are stored by list slot)
+      const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)i * 4;
       float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
       a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
       a[8] += r2.x; a[9] += r2.y; a[10] += r2.z; a[11] += r2.w; a[12] += r3.x; a[13] += r3.y;
