@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   const int nblocks = sgx * sgy;
   const int st = super_tile_of_block(blockIdx.x, nblocks);
   if (st >= nblocks) return;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave-uniform: tile state in SGPRs
   constexpr int kLdsSortMax = SORT_MAX;
   char* slice = smem + (size_t)wv * (SORT_MAX * 8 + kWave * 48);
   const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   const int nblocks = sgx * sgy;
   const int st = super_tile_of_block(blockIdx.x, nblocks);
   if (st >= nblocks) return;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave-uniform: tile state in SGPRs
   const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
   if (tx >= gx || ty >= gy) return;
   const int tile = ty * gx + tx;
