@@ -47,11 +47,11 @@ __device__ __forceinline__ uint64_t wave_sort64(uint64_t key, int n, int lane) {
   for (int k = 2; k <= kWave; k <<= 1) {
     if ((k >> 1) >= n) break;                       // everything above n is +inf already in place (uniform)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      uint64_t other = shfl_xor_u64(key, j);
-      bool up = (lane & k) == 0;
-      bool lower = (lane & j) == 0;
-      uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
-      key = (lower == up) ? mn : mx;
+      const uint64_t other = shfl_xor_u64(key, j);
+      const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);     // ascending block and lower partner (or both not)
+      // one compare: take the partner's key iff it is the one this lane has to keep (keys are unique; equal keys only
+      // occur among the ~0 padding, where either choice is the same value)
+      key = ((other < key) == keep_min) ? other : key;
     }
   }
   return key;
