@@ -1,0 +1,45 @@
+"""The JSON line bench.py printed on the MI355X (committed under profiles/) carries every key of the driver's contract."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    assert files, "no committed bench line under profiles/"
+    return json.loads(open(files[-1]).read().strip().splitlines()[-1])
+
+
+def test_bench_line_has_the_contract_keys():
+    d = _latest_line()
+    for k in ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"]:
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "f32" and d["n_gpus"] == 1 and "workload" in d["config"] and "model" not in d["config"]
+    assert "640x480" in d["metric"] and d["config"]["gaussians"] == 300000 and d["config"]["width"] == 640 and d["config"]["height"] == 480
+    r = d["roofline"]
+    for k in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    for k in ["value", "unit", "cores", "kind", "sample"]:
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    # value is whole-job keyframes/s: consistent with the step time it was derived from (61 iterations per keyframe)
+    assert abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"] / 61.0) / d["value"] < 0.01
+
+
+def test_committed_profiles_agree_with_the_bench_line():
+    d = _latest_line()
+    tag = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))[-1].split(os.sep)[-1].split("_")[0]
+    k = json.load(open(os.path.join(ROOT, "profiles", tag + "_kernel_batched_avg.json")))["kernels"]
+    trace_us = k["sgr::blend_bwd_kernel"]["avg_us"]
+    event_us = 1e3 * d["roofline"]["avg_launch_ms"]
+    assert abs(trace_us - event_us) / event_us < 0.10, (trace_us, event_us)      # rocprofv3 trace vs live HIP events
+    h = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm_bytes.json")))["kernels"]["sgr::blend_bwd_kernel"]
+    assert d["roofline"]["traffic"] in (None, h["hbm_bytes_per_launch_corrected"]) or \
+        abs(d["roofline"]["traffic"] - h["hbm_bytes_per_launch_corrected"]) / h["hbm_bytes_per_launch_corrected"] < 0.05
