@@ -1,17 +1,21 @@
 """Autograd-free mapping loops for MI355X: the same three loops as splat_slam_amd.mapper.MappingLoop
-(/root/reference/src/mapper.py:303-353, 400-568, 656-708) executed as a flat sequence of C-ABI calls per iteration
+(/root/reference/src/mapper.py:303-353, 400-568, 656-708) executed through the C ABI:
 
-    sgr_activate                                    (exp / normalize / sigmoid of the GaussianModel getters, once)
-    per view:  sgr_forward (async) -> sgr_mapping_loss -> sgr_backward(accumulate + densification stats)
-    sgr_gaussian_adam_step                          (activation chain rule + isotropy term + Adam, all groups, one pass)
+    sgr_map_run    a run of regular iterations between two densify / reset points = ONE host call
+                   (map(iters=60), final_refine in chunks, initialize_map between its densification points)
+    sgr_map_step   one iteration = activate -> batched views {forward, loss in the compositing epilogue, backward into the
+                   gradient sinks + densification statistics} -> Adam of the five groups -> exposure Adam
+                   (used around map surgery, with pose optimisation, and -- twice per iteration with one all-reduce in
+                   between -- on several GPUs)
 
 instead of ~60 eager torch kernels and an autograd graph per view.  Nothing on this path synchronises with the host:
-outputs, saved blocks and gradient accumulators are persistent device buffers sized once per map size (HBM is 288 GB;
-re-allocation only happens when densify/prune changes N), the pair capacity of every camera is learned by one
-synchronous forward and re-checked every `check_every` iterations.
+outputs, saved blocks and gradient sinks are persistent device buffers sized once per map size (HBM is 288 GB;
+re-allocation only happens when densify / prune changes N), the pair capacity of every camera is learned by one
+synchronous probe forward and re-checked every `check_every` iterations.
 
-Numerically this is the same computation as the autograd loop (tests/test_gpu_fused.py compares parameter
-trajectories); the order of fp32 additions differs (views are accumulated in place instead of by autograd).
+Numerically this is the same computation as the autograd loop (tests/test_gpu_fused.py compares gradients and parameter
+trajectories; the run / step / fused-tail / multi-rank variants are bitwise identical among themselves); only the order
+of fp32 additions differs from autograd (views are accumulated in place).
 
 Deliberate deviation: the reference's `map(prune=True)` pass runs a full backward whose only
 lasting effect is a stale `.grad` on the exposure parameters; here the prune pass is forward-only.
