@@ -12,15 +12,15 @@
 namespace sgr {
 
 // exclusive scan of in[0..n) by ONE 1024-thread block, 4 items per thread per pass; returns the total
-__device__ uint32_t block1024_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, uint32_t* red,
-                                   int in_stride = 1) {
+template <typename LOAD>
+__device__ uint32_t block1024_scan(LOAD in, uint32_t* __restrict__ out, int n, uint32_t* red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;   // 16 waves
   uint32_t carry = 0;
   for (int base = 0; base < n; base += 4096) {
     int i0 = base + threadIdx.x * 4;
     uint32_t v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (i0 + k) < n ? in[(size_t)(i0 + k) * in_stride] : 0u;
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k) < n ? in(i0 + k) : 0u;
     uint32_t s4 = v[0] + v[1] + v[2] + v[3];
     uint32_t inc = wave_scan_add_u32(s4);
     if (lane == 63) red[wv] = inc;
@@ -48,16 +48,17 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
     uint32_t* tmp = (uint32_t*)(saved + L.o_tile_maxc);      // free until blend_fwd overwrites it
     uint2* ranges = (uint2*)(saved + L.o_ranges);
     uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
-    uint32_t R = block1024_scan(tile_count, tmp, L.ntiles, red, kCntStride);
+    auto cidx = [&](int t) { return tile_counter_index(t % L.gx, t / L.gx, L.gxp); };
+    uint32_t R = block1024_scan([&](int t) { return tile_count[cidx(t)]; }, tmp, L.ntiles, red);
     __syncthreads();
     uint32_t over = 0;
     for (int t = threadIdx.x; t < L.ntiles; t += 1024) {
-      const uint32_t s0 = tmp[t], c = tile_count[(size_t)t * kCntStride];
+      const uint32_t s0 = tmp[t], c = tile_count[cidx(t)];
       // <= kBucket pairs: K1 already binned them in the tile's bucket, the run [s0, s0+c) only addresses point_list.
       // more: scatter_kernel fills the run; .y is its fill cursor and ends at s0 + c as well.
       ranges[(size_t)t * kRngStride] = c <= (uint32_t)kBucket ? make_uint2(s0, s0 + c) : make_uint2(s0 | kOverfull, s0);
       over += c > (uint32_t)kBucket ? 1u : 0u;
-      tile_count[(size_t)t * kCntStride] = 0u;       // consumed: leave the counters clean for the next forward
+      tile_count[cidx(t)] = 0u;       // consumed: leave the counters clean for the next forward
     }
     over = wave_scan_add_u32(over);
     __syncthreads();
@@ -72,9 +73,11 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
       hdr->sorted_count = (uint32_t)((int64_t)R > L.cap ? L.cap : (int64_t)R);
     }
   } else if (blockIdx.x == 1) {
-    (void)block1024_scan((const uint32_t*)(saved + L.o_block_touched), (uint32_t*)(saved + L.o_block_base_t), L.nseg, red);
+    const uint32_t* bt = (const uint32_t*)(saved + L.o_block_touched);
+    (void)block1024_scan([&](int i) { return bt[i]; }, (uint32_t*)(saved + L.o_block_base_t), L.nseg, red);
   } else {
-    uint32_t V = block1024_scan((const uint32_t*)(saved + L.o_block_vis), (uint32_t*)(saved + L.o_block_base_v), L.nseg, red);
+    const uint32_t* bv = (const uint32_t*)(saved + L.o_block_vis);
+    uint32_t V = block1024_scan([&](int i) { return bv[i]; }, (uint32_t*)(saved + L.o_block_base_v), L.nseg, red);
     if (threadIdx.x == 0) hdr->num_visible = V;
   }
 }

@@ -21,7 +21,11 @@ constexpr int kTile = 8;               // our binning tile = one wave64 = 8x8 pi
 constexpr int kWave = 64;
 // per-tile atomic counters live on their own 64-byte line: ~200 atomics per line (16 counters x 12 hits) serialised the
 // binning kernels, one counter per line does not
-constexpr int kCntStride = 4;          // uint32 units between two tiles' pair counters
+// per-tile pair counters: the counters of two horizontally adjacent tiles (x even, x+1) are the halves of ONE 64-bit word,
+// so a splat that covers both takes one atomic for the two ranks (binning is bound by the number of atomics); one such
+// word per 32 bytes keeps the per-line contention where the padded layout had it
+constexpr int kCntSlotWords = 8;       // uint32 units per tile-pair slot
+__host__ __device__ inline size_t tile_counter_index(int x, int y, int gxp) { return ((size_t)y * gxp + (x >> 1)) * kCntSlotWords + (x & 1); }
 constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
 // Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the
 // key goes straight into the tile's fixed bucket -- no second pass.  Only tiles with more than kBucket pairs are re-scattered
@@ -71,7 +75,7 @@ struct ViewTab {
 };
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {
-  int N, H, W, gx, gy, sgx, sgy, ntiles, pre_blocks, nseg, dbg;
+  int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg;
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
@@ -137,7 +141,7 @@ struct Layout {
     nseg = (N + kSeg - 1) / kSeg;
     size_t nb = (size_t)(pre_blocks > 0 ? pre_blocks : 1);
     o_hdr = take(sizeof(SavedHeader));
-    o_tile_count = take((size_t)ntiles * 4 * kCntStride);     // hdr + tile_count are zeroed by ONE launch per forward
+    o_tile_count = take((size_t)gy * ((gx + 1) / 2) * 4 * kCntSlotWords);     // hdr + tile_count are zeroed by ONE launch (fresh blocks)
     zero_bytes = o;
     o_grec = take(n * sizeof(GRec));   // one 64-byte record per Gaussian: what binning / blending / backward gather
     o_point_list = take(c * 4);
@@ -166,7 +170,7 @@ struct Layout {
   }
   __host__ LOff dev() const {
     LOff d;
-    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags();
+    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags();
     d.cap = cap;
     d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_grec = o_grec;
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;

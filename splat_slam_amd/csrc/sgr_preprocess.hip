@@ -398,20 +398,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       rec[1] = make_float4(o.A, o.B, o.C, o.opac);
       rec[2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     }
-    // count the pairs per tile; the returning atomic is the pair's rank in its tile: while the tile's bucket has room the
-    // key is binned right here.  The first 4 atomics (most splats cover <= 4 bins) are issued now and consumed after the
-    // block scans below, which hide their round trip.
+    // Count the pairs per tile; the returning atomic is the pair's rank in its tile: while the tile's bucket has room the
+    // key is binned right here.  The kernel's time follows the NUMBER of atomics, so a splat that covers the two tiles of
+    // a counter word (x even, x+1) takes both ranks with ONE 64-bit atomic; a row of the rectangle is a leading single
+    // tile (odd x0), pairs, and a trailing single tile.  The first 4 operations (most splats need <= 4) are issued now
+    // and consumed after the block scans below, which hide their round trip.
     uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
     uint64_t* bucket = (uint64_t*)(p_scratch[v] + L.o_bucket);
     const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
-    const int w = o.x1 - o.x0;
-    uint32_t rank[4] = {0u, 0u, 0u, 0u}, tl[4] = {0u, 0u, 0u, 0u};
+    const int lead = o.x0 & 1, wrect = o.x1 - o.x0;
+    const int opr = lead + ((wrect - lead + 1) >> 1);                  // operations per row
+    const int nops = cnt > 0u ? opr * (o.y1 - o.y0) : 0;
+    auto issue = [&](int k, int& tx, int& ty, bool& pair) -> unsigned long long {
+      const int row = k / opr, j = k % opr;
+      ty = o.y0 + row;
+      tx = (lead && j == 0) ? o.x0 : o.x0 + lead + 2 * (j - lead);
+      pair = !(tx & 1) && (tx + 1 < o.x1);
+      uint32_t* c = &tile_count[tile_counter_index(tx, ty, L.gxp)];
+      if (pair) return atomicAdd((unsigned long long*)c, 0x100000001ull);
+      return (unsigned long long)atomicAdd(c, 1u);
+    };
+    auto consume = [&](unsigned long long old, int tx, int ty, bool pair) {
+      const uint32_t t0 = (uint32_t)(ty * L.gx + tx);
+      const uint32_t r0 = (uint32_t)old, r1 = (uint32_t)(old >> 32);
+      if (r0 < (uint32_t)kBucket) bucket[(size_t)t0 * kBucket + r0] = key;
+      if (pair && r1 < (uint32_t)kBucket) bucket[(size_t)(t0 + 1) * kBucket + r1] = key;
+    };
+    unsigned long long old4[4] = {0ull, 0ull, 0ull, 0ull};
+    int tx4[4] = {0, 0, 0, 0}, ty4[4] = {0, 0, 0, 0};
+    bool pr4[4] = {false, false, false, false};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (jj < (int)cnt) {
-        tl[jj] = (uint32_t)((o.y0 + jj / w) * L.gx + o.x0 + jj % w);
-        rank[jj] = atomicAdd(&tile_count[(size_t)tl[jj] * kCntStride], 1u);
-      }
+      if (jj < nops) old4[jj] = issue(jj, tx4[jj], ty4[jj], pr4[jj]);
     uint32_t tot_t, tot_v;
     const uint32_t ex_t = carry_t + block256_exclusive_scan(cnt, red, tot_t);
     const uint32_t ex_v = carry_v + block256_exclusive_scan(vis, red, tot_v);
@@ -425,19 +443,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     if (o.visible) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
-        if (jj < (int)cnt && rank[jj] < (uint32_t)kBucket) bucket[(size_t)tl[jj] * kBucket + rank[jj]] = key;
-      for (int k0 = 4; k0 < (int)cnt; k0 += 4) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int kk = k0 + jj;
-          if (kk < (int)cnt) {
-            tl[jj] = (uint32_t)((o.y0 + kk / w) * L.gx + o.x0 + kk % w);
-            rank[jj] = atomicAdd(&tile_count[(size_t)tl[jj] * kCntStride], 1u);
-          }
-        }
+        if (jj < nops) consume(old4[jj], tx4[jj], ty4[jj], pr4[jj]);
+      for (int k0 = 4; k0 < nops; k0 += 4) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-          if (k0 + jj < (int)cnt && rank[jj] < (uint32_t)kBucket) bucket[(size_t)tl[jj] * kBucket + rank[jj]] = key;
+          if (k0 + jj < nops) old4[jj] = issue(k0 + jj, tx4[jj], ty4[jj], pr4[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (k0 + jj < nops) consume(old4[jj], tx4[jj], ty4[jj], pr4[jj]);
       }
       const uint32_t k = ex_v - vbase_v[v];
       // touched, in-segment prefix (abs_offset() adds the segment base), list slot (relative; scatter_kernel makes it
