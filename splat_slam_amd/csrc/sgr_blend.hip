@@ -10,8 +10,8 @@
 //     16x16 reference tile.  Waves never synchronise with each other: no __syncthreads in either kernel.
 //   * FORWARD first sorts its tile's (depth bits | Gaussian) keys: <= 64 keys in registers (bitonic network over
 //     lanes), <= 1024 keys in the wave's LDS slice, longer lists in place in HBM (slow path).  Then it is pixel-parallel
-//     (lane = pixel): 64 sorted splats at a time are staged into LDS (coalesced gather -> ds_write_b128) and walked with
-//     broadcast ds_read_b128; per-pixel accumulators stay in VGPRs.  n_touched is one ballot+popcount+atomic per
+//     (lane = pixel): 64 sorted splats at a time are staged into LDS pair-interleaved and walked TWO splats per trip with
+//     broadcast ds_read_b128 + packed fp32 (v_pk_*_f32); per-pixel accumulators stay in VGPRs.  n_touched is one ballot+popcount+atomic per
 //     (wave, splat), not per pixel.
 //   * BACKWARD is splat-parallel (lane = splat).  For one pixel the transmittance in front of every splat is a
 //     multiplicative DPP scan over lanes and the colour behind it an additive DPP scan of ONE scalar
@@ -79,6 +79,10 @@ __device__ __forceinline__ void wave_sort_any(int n, int lane, LD load, ST store
     }
   }
 }
+
+// gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot); both blend kernels use 2-vectors
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int SORT_MAX>
@@ -160,56 +164,89 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
       point_list[begin + i] = (uint32_t)__hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
-  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+  float T = 1.f;
+  v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, Dd = {0.f, 0.f};   // (even, odd) list positions, added at the end
   uint32_t last = 0;
   bool done = !inside;
+  const v2f px2 = splat2(pxf), py2 = splat2(pyf);
 
   for (int base = 0; base < count; base += kWave) {
     const int n = min(kWave, count - base);
-    // gather this chunk: lane j fetches splat j (40 B of geometry from the Gaussian SoA)
-    if (lane < n) {
-      uint32_t g;
-      if (mode == 0) g = g_first;
-      else if (mode == 1) g = (uint32_t)keys[base + lane];
-      else g = (uint32_t)__hip_atomic_load(entries + begin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float4* rec = (const float4*)(grec + g);       // one 64-byte record: centre | conic, opacity | colour, depth
-      float4 m = rec[0];
-      float4 co = rec[1];
-      float4 cd = rec[2];
-      lds[lane * 3 + 0] = make_float4(m.x, m.y, co.x, co.y);
-      lds[lane * 3 + 1] = make_float4(co.z, co.w, cd.w, __uint_as_float(g));
-      lds[lane * 3 + 2] = make_float4(cd.x, cd.y, cd.z, 0.f);
+    // gather this chunk: lane j fetches splat j (one 64-byte record: centre | conic, opacity | colour, depth) and stores
+    // it PAIR-INTERLEAVED (splats 2p, 2p+1 side by side, 6 float4 per pair) so that the walk reads 2-vectors;
+    // an odd chunk is padded with a splat of opacity 0 (never contributes)
+    if (lane <= n) {
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
+      uint32_t g = 0;
+      if (lane < n) {
+        if (mode == 0) g = g_first;
+        else if (mode == 1) g = (uint32_t)keys[base + lane];
+        else g = (uint32_t)__hip_atomic_load(entries + begin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float4* rec = (const float4*)(grec + g);
+        m = rec[0];
+        co = rec[1];
+        cd = rec[2];
+      }
+      float* f = (float*)lds + (lane >> 1) * 24 + (lane & 1);
+      f[0] = m.x; f[2] = m.y; f[4] = co.x; f[6] = co.y;
+      f[8] = co.z; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
+      f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // branch-free body (selects, no divergent control flow); the "every pixel finished" exit is polled every 4 splats
+    // Two splats per trip, branch free.  blend_fwd is VALU-issue bound like the backward, so the footprint (eval_alpha's
+    // operation sequence, packed), alpha * T and the four accumulate FMAs issue once per PAIR (v_pk_*_f32); exp, the
+    // tests and the transmittance chain stay per splat.  The "every pixel finished" exit is polled every 4 splats.
     auto walk = [&](auto count_touched) {
-      for (int j = 0; j < n; ++j) {
+#pragma clang fp contract(off)      // the two instantiations must round alike (T * (1 - alpha) is not to become an fma in one)
+      for (int j = 0; j < n; j += 2) {
         if ((j & 3) == 0 && __builtin_amdgcn_ballot_w64(!done) == 0) break;
-        float4 e0 = lds[j * 3 + 0], e1 = lds[j * 3 + 1], e2 = lds[j * 3 + 2];
-        AlphaEval a = eval_alpha(e0.x - pxf, e0.y - pyf, e0.z, e0.w, e1.x, e1.y);
-        const float testT = T * (1.f - a.alpha);
-        const bool live = !done && a.ok;
-        const bool term = live && (testT < kTEps);
-        const bool comp = live && !term;
-        done = done || term;
-        const float w = comp ? a.alpha * T : 0.f;
-        C0 = __fmaf_rn(e2.x, w, C0);
-        C1 = __fmaf_rn(e2.y, w, C1);
-        C2 = __fmaf_rn(e2.z, w, C2);
-        D = __fmaf_rn(e1.z, w, D);
+        const float4* e = lds + (j >> 1) * 6;
+        const float4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4];
+        const float2 q5 = *(const float2*)&e[5];
+        const v2f dx = (v2f){q0.x, q0.y} - px2, dy = (v2f){q0.z, q0.w} - py2;
+        const v2f qf = __builtin_elementwise_fma((v2f){q1.x, q1.y} * dx, dx, ((v2f){q2.x, q2.y} * dy) * dy);
+        const v2f bdxdy = ((v2f){q1.z, q1.w} * dx) * dy;
+        const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
+        const v2f G = {__expf(power.x), __expf(power.y)};
+        const v2f og = (v2f){q2.z, q2.w} * G;
+        const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
+        const bool ok0 = (power.x <= 0.0f) && (alpha.x >= kAlphaMin);
+        const bool ok1 = (power.y <= 0.0f) && (alpha.y >= kAlphaMin);
+        const v2f one_m = splat2(1.f) - alpha;
+        const float test0 = T * one_m.x;
+        const bool live0 = !done && ok0;
+        const bool term0 = live0 && (test0 < kTEps);
+        const bool comp0 = live0 && !term0;
+        done = done || term0;
+        const float T1 = comp0 ? test0 : T;
+        const float test1 = T1 * one_m.y;
+        const bool live1 = !done && ok1;
+        const bool term1 = live1 && (test1 < kTEps);
+        const bool comp1 = live1 && !term1;
+        done = done || term1;
+        v2f w = alpha * (v2f){T, T1};
+        w.x = comp0 ? w.x : 0.f;
+        w.y = comp1 ? w.y : 0.f;
+        Cr = __builtin_elementwise_fma((v2f){q4.x, q4.y}, w, Cr);
+        Cg = __builtin_elementwise_fma((v2f){q4.z, q4.w}, w, Cg);
+        Cb = __builtin_elementwise_fma((v2f){q5.x, q5.y}, w, Cb);
+        Dd = __builtin_elementwise_fma((v2f){q3.x, q3.y}, w, Dd);
         if (decltype(count_touched)::value) {
-          unsigned long long tm = __builtin_amdgcn_ballot_w64(comp && testT > kTouchedT);
-          if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(e1.w)], (int)__popcll(tm));
+          unsigned long long tm = __builtin_amdgcn_ballot_w64(comp0 && test0 > kTouchedT);
+          if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.z)], (int)__popcll(tm));
+          tm = __builtin_amdgcn_ballot_w64(comp1 && test1 > kTouchedT);
+          if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.w)], (int)__popcll(tm));
         }
-        T = comp ? testT : T;
-        last = comp ? (uint32_t)(base + j + 1) : last;
+        T = comp1 ? test1 : T1;
+        last = comp1 ? (uint32_t)(base + j + 2) : (comp0 ? (uint32_t)(base + j + 1) : last);
       }
     };
     if (n_touched) walk(std::true_type{}); else walk(std::false_type{});
     __builtin_amdgcn_wave_barrier();
     if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
   }
+  const float C0 = Cr.x + Cr.y, C1 = Cg.x + Cg.y, C2 = Cb.x + Cb.y, D = Dd.x + Dd.y;
 
   // per-tile bound for the backward: it never has to look past the last contributor of any pixel
   uint32_t mx = last;
@@ -340,8 +377,6 @@ __device__ __forceinline__ float group_shr1<8>(float v, float fill, int lane) {
 // (A matrix-core variant -- the 16-lane-group layout is exactly the A/B operand layout of v_mfma_f32_16x16x4_f32, the
 // ten sums being two small GEMMs over the pixels -- cut the instruction count by 20 % but ran 8 % slower: fp32 MFMA
 // passes contend with the VALU work of the other waves of the SIMD.)
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
 
 // pixel pair g (0..31) of a tile for group width GW:  p0 = 2*PP*(g/PP) + g%PP,  p1 = p0 + PP   (PP = 64/GW)
 template <int GW>
