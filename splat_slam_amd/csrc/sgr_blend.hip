@@ -302,34 +302,24 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
 // (the builtin path costs a v_mov_dpp with old = 1.0 plus a v_mul).  s_nop 1 = the 2 wait states a DPP read of a
 // freshly written VGPR requires.
 #define SGR_MUL_DPP(CTRL) "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 " CTRL "\n\t"
+#define SGR_ADD_DPP(CTRL) "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTRL "\n\t"
+// The backward scans TWO values per lane (its pixel pair): interleaved, each scan's step is the other's wait state, so a
+// step of both costs two VALU ops + s_nop 0.
+#define SGR_DPP2(OP, CTRL) "v_" OP "_f32_dpp %0, %0, %0 " CTRL "\n\tv_" OP "_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+#define SGR_SCAN2_ROW(OP)                                                                                     \
+  "s_nop 1\n\t" SGR_DPP2(OP, "row_shr:1 row_mask:0xf bank_mask:0xf") SGR_DPP2(OP, "row_shr:2 row_mask:0xf bank_mask:0xf") \
+      SGR_DPP2(OP, "row_shr:4 row_mask:0xf bank_mask:0xf") SGR_DPP2(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")
+#define SGR_SCAN2(OP, a, b)                                                                                                \
+  do {                                                                                                                     \
+    if (GW == 16) asm(SGR_SCAN2_ROW(OP) "s_nop 0" : "+v"(a), "+v"(b));                                                      \
+    else if (GW == 32) asm(SGR_SCAN2_ROW(OP) SGR_DPP2(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0" : "+v"(a), "+v"(b)); \
+    else asm(SGR_SCAN2_ROW(OP) SGR_DPP2(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                     \
+             SGR_DPP2(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0" : "+v"(a), "+v"(b));                          \
+  } while (0)
 template <int GW>
-__device__ __forceinline__ float group_scan_mul(float v) {
-  if (GW == 16)
-    asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf")
-        SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:8 row_mask:0xf bank_mask:0xf")
-        : "+v"(v));
-  else if (GW == 32)
-    asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf")
-        SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:8 row_mask:0xf bank_mask:0xf")
-        SGR_MUL_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-        : "+v"(v));
-  else
-    asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf")
-        SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xf") SGR_MUL_DPP("row_shr:8 row_mask:0xf bank_mask:0xf")
-        SGR_MUL_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf") SGR_MUL_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-        : "+v"(v));
-  return v;
-}
+__device__ __forceinline__ void group_scan_mul2(float& a, float& b) { SGR_SCAN2("mul", a, b); }
 template <int GW>
-__device__ __forceinline__ float group_scan_add(float v) {
-  v += dpp_f<DPP_ROW_SHR1>(0.f, v);
-  v += dpp_f<DPP_ROW_SHR2>(0.f, v);
-  v += dpp_f<DPP_ROW_SHR4>(0.f, v);
-  v += dpp_f<DPP_ROW_SHR8>(0.f, v);
-  if (GW >= 32) v += dpp_f<DPP_ROW_BCAST15, 0xa>(0.f, v);
-  if (GW >= 64) v += dpp_f<DPP_ROW_BCAST31, 0xc>(0.f, v);
-  return v;
-}
+__device__ __forceinline__ void group_scan_add2(float& a, float& b) { SGR_SCAN2("add", a, b); }
 // value of the previous lane inside the group (first lane of a group receives `fill`)
 template <int GW>
 __device__ __forceinline__ float group_shr1(float v, float fill, int lane) {
@@ -340,8 +330,7 @@ __device__ __forceinline__ float group_shr1(float v, float fill, int lane) {
 }
 // 8-lane groups (two per DPP row): row_shr:1 / :2 leak the upper neighbour group's tail into lanes 8 / 8,9 of the row, so
 // those lanes keep their value (one select per step); row_shr:4 is confined by its bank mask (banks 1 and 3 only).
-template <>
-__device__ __forceinline__ float group_scan_mul<8>(float v) {
+__device__ __forceinline__ float group8_scan_mul(float v) {
   const int l8 = (int)(threadIdx.x & 7);
   float t = v;
   asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") : "+v"(t));
@@ -352,16 +341,21 @@ __device__ __forceinline__ float group_scan_mul<8>(float v) {
   asm(SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xa") : "+v"(v));
   return v;
 }
-template <>
-__device__ __forceinline__ float group_scan_add<8>(float v) {
+__device__ __forceinline__ float group8_scan_add(float v) {
   const int l8 = (int)(threadIdx.x & 7);
-  float d = dpp_f<DPP_ROW_SHR1>(0.f, v);
-  v += l8 == 0 ? 0.f : d;
-  d = dpp_f<DPP_ROW_SHR2>(0.f, v);
-  v += l8 < 2 ? 0.f : d;
-  v += dpp_f<DPP_ROW_SHR4, 0xf, 0xa>(0.f, v);
+  float t = v;
+  asm(SGR_ADD_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") : "+v"(t));
+  v = l8 == 0 ? v : t;
+  t = v;
+  asm(SGR_ADD_DPP("row_shr:2 row_mask:0xf bank_mask:0xf") : "+v"(t));
+  v = l8 < 2 ? v : t;
+  asm(SGR_ADD_DPP("row_shr:4 row_mask:0xf bank_mask:0xa") : "+v"(v));
   return v;
 }
+template <>
+__device__ __forceinline__ void group_scan_mul2<8>(float& a, float& b) { a = group8_scan_mul(a); b = group8_scan_mul(b); }
+template <>
+__device__ __forceinline__ void group_scan_add2<8>(float& a, float& b) { a = group8_scan_add(a); b = group8_scan_add(b); }
 template <>
 __device__ __forceinline__ float group_shr1<8>(float v, float fill, int lane) {
   float r = dpp_f<DPP_ROW_SHR1>(fill, v);
@@ -436,12 +430,15 @@ __device__ __forceinline__ void bwd_chunk2(
     const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
     const v2f G = {__expf(power.x), __expf(power.y)};
     const v2f og = splat2(op) * G;
-    const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
+    v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
     const bool ok0 = valid && (idx < nc0) && (power.x <= 0.0f) && (alpha.x >= kAlphaMin);
     const bool ok1 = valid && (idx < nc1) && (power.y <= 0.0f) && (alpha.y >= kAlphaMin);
+    // a pair that does not contribute takes part with alpha = 0: factor 1 in the product, weight 0 in the sums
+    alpha.x = ok0 ? alpha.x : 0.f;
+    alpha.y = ok1 ? alpha.y : 0.f;
     const v2f one_m = splat2(1.f) - alpha;
-    const float P0 = group_scan_mul<GW>(ok0 ? one_m.x : 1.f);      // prod over this splat and all behind it (in chunk)
-    const float P1 = group_scan_mul<GW>(ok1 ? one_m.y : 1.f);
+    float P0 = one_m.x, P1 = one_m.y;
+    group_scan_mul2<GW>(P0, P1);                         // prod over this splat and all behind it (in chunk)
     const v2f E = {group_shr1<GW>(P0, 1.f, lane), group_shr1<GW>(P1, 1.f, lane)};   // prod over all strictly behind it
     const v2f rP = {__builtin_amdgcn_rcpf(P0), __builtin_amdgcn_rcpf(P1)};
     const v2f Tj = (v2f){b0.x, b0.y} * rP;               // transmittance in front of splat j
@@ -449,11 +446,11 @@ __device__ __forceinline__ void bwd_chunk2(
     const v2f dCr = {a0.x, a0.y}, dCg = {a0.z, a0.w}, dCb = {a1.x, a1.y}, dD = {a1.z, a1.w};
     const v2f w = __builtin_elementwise_fma(dCr, splat2(cr), __builtin_elementwise_fma(dCg, splat2(cg),
                   __builtin_elementwise_fma(dCb, splat2(cb), dD * splat2(dep))));
-    v2f aT = alpha * Tj;
-    aT.x = ok0 ? aT.x : 0.f;
-    aT.y = ok1 ? aT.y : 0.f;
+    const v2f aT = alpha * Tj;                           // (Tj is finite: the product only spans contributing splats)
     const v2f q = w * aT;
-    const v2f Qi = {group_scan_add<GW>(q.x), group_scan_add<GW>(q.y)};   // inclusive: this splat and all behind it
+    float Q0 = q.x, Q1 = q.y;
+    group_scan_add2<GW>(Q0, Q1);                         // inclusive: this splat and all behind it
+    const v2f Qi = {Q0, Q1};
     const v2f Sc = {b0.z, b0.w};
     const v2f Sx = (Qi - q) + Sc;                        // strictly behind (+ carried chunks + background term)
     const v2f dL_dalpha = __builtin_elementwise_fma(Tj, w, -(Sx * inv1ma));
