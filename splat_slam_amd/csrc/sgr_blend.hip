@@ -37,26 +37,6 @@ __device__ __forceinline__ int super_tile_of_block(int b, int nblocks) {
   return (b & 7) * per + (b >> 3);   // may be >= nblocks for the tail: caller checks
 }
 
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
-  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-// ascending bitonic network over the 64 lanes (one key per lane; idle lanes hold ~0)
-__device__ __forceinline__ uint64_t wave_sort64(uint64_t key, int n, int lane) {
-  for (int k = 2; k <= kWave; k <<= 1) {
-    if ((k >> 1) >= n) break;                       // everything above n is +inf already in place (uniform)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint64_t other = shfl_xor_u64(key, j);
-      const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);     // ascending block and lower partner (or both not)
-      // one compare: take the partner's key iff it is the one this lane has to keep (keys are unique; equal keys only
-      // occur among the ~0 padding, where either choice is the same value)
-      key = ((other < key) == keep_min) ? other : key;
-    }
-  }
-  return key;
-}
-
 // Bitonic sort of a[0..n) for ANY n with one wave ("mirror" formulation: every compare-exchange is ascending, so
 // virtual +inf padding behind n never moves).  LOAD/STORE abstract LDS vs. device-coherent global memory.
 template <typename LD, typename ST, typename SYNC>
@@ -130,22 +110,51 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
     eb = lt.exp_b[vw] ? lt.exp_b[vw][0] : 0.f;
   }
 
+  // unsorted keys: the tile's bucket (filled by K1) unless the tile had more than kBucket pairs (then its exact run).
+  // The bucket's address does not depend on the tile's range: lane j fetches bucket entry j (kBucket = one wave) in the
+  // same round trip as the range -- the first half of the bucket, which covers 98 % of the tiles of a SLAM view; the
+  // rest follows once the count is known (entries behind the tile's count are ignored).
+  const uint64_t* __restrict__ bucket = (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
+  static_assert(kBucket == kWave, "one bucket entry per lane");
+  uint64_t key_spec = lane < 32 ? bucket[lane] : ~0ull;
   const uint2 rng = ranges[(size_t)tile * kRngStride];
   const int64_t begin = rng.x & ~kOverfull;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
   const int count = endc > begin ? (int)(endc - begin) : 0;
-  // unsorted keys: the tile's bucket (filled by K1) unless the tile had more than kBucket pairs (then its exact run)
-  const uint64_t* __restrict__ keys_in = (rng.x & kOverfull) ? entries + begin
-                                                              : (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
+  const bool overfull = (rng.x & kOverfull) != 0;
+  const uint64_t* __restrict__ keys_in = overfull ? entries + begin : bucket;
 
   // ---- sort this tile's run by (depth bits, Gaussian index) and publish the index list for the backward
-  uint32_t g_first = 0;                       // sorted Gaussian index of list position `lane` (count <= 64 path)
   int mode = 0;                               // 0: registers, 1: LDS, 2: global
   if (count <= kWave) {
-    uint64_t key = lane < count ? keys_in[lane] : ~0ull;
-    key = wave_sort64(key, count, lane);
-    g_first = (uint32_t)key;
-    if (lane < count) point_list[begin + lane] = g_first;
+    // One chunk.  Every lane keeps ITS (unsorted) key and finds the key's position in the sorted list by counting
+    // smaller keys (keys are unique; broadcast through SGPRs: count short steps and no LDS round trips instead of a
+    // 21-step shuffle network), fetches the key's record and files it under that position.
+    if (count > 32 && lane >= 32 && lane < count) key_spec = keys_in[lane];
+    const uint64_t key = overfull ? (lane < count ? keys_in[lane] : ~0ull) : (lane < count ? key_spec : ~0ull);
+    const uint32_t g = (uint32_t)key;
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    uint32_t rank = 0;
+    for (int j = 0; j < count; ++j) {
+      const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, j) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
+      rank += kj < key ? 1u : 0u;
+    }
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
+    if (lane < count) {
+      const float4* rec = (const float4*)(grec + g);
+      m = rec[0];
+      co = rec[1];
+      cd = rec[2];
+    }
+    if (lane >= count) rank = (uint32_t)lane;        // lane == count files the zero splat that pads an odd list
+    if (lane < count) point_list[begin + rank] = g;
+    if (lane <= count) {
+      float* f = (float*)lds + (rank >> 1) * 24 + (rank & 1);
+      f[0] = m.x; f[2] = m.y; f[4] = co.x; f[6] = co.y;
+      f[8] = co.z; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
+      f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
+    }
   } else if (count <= kLdsSortMax) {
     mode = 1;
     for (int i = lane; i < count; i += kWave) keys[i] = keys_in[i];
@@ -175,12 +184,11 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
     // gather this chunk: lane j fetches splat j (one 64-byte record: centre | conic, opacity | colour, depth) and stores
     // it PAIR-INTERLEAVED (splats 2p, 2p+1 side by side, 6 float4 per pair) so that the walk reads 2-vectors;
     // an odd chunk is padded with a splat of opacity 0 (never contributes)
-    if (lane <= n) {
+    if (mode != 0 && lane <= n) {
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
       uint32_t g = 0;
       if (lane < n) {
-        if (mode == 0) g = g_first;
-        else if (mode == 1) g = (uint32_t)keys[base + lane];
+        if (mode == 1) g = (uint32_t)keys[base + lane];
         else g = (uint32_t)__hip_atomic_load(entries + begin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float4* rec = (const float4*)(grec + g);
         m = rec[0];
