@@ -248,7 +248,10 @@ int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* i
 
 /* One whole mapping iteration (src/mapper.py:414-568 without densification) in ONE host call:
  *   sgr_activate -> sgr_map_views -> sgr_gaussian_adam_step -> sgr_masked_adam (exposures).
- * Any stage is skipped when its pointer block is NULL / its count is 0. */
+ * Any stage is skipped when its pointer block is NULL / its count is 0.
+ * An optimiser-only step (num_views == 0 with adam_groups: the second half of a multi-GPU iteration, after the gradient
+ * all-reduce) does not activate first: its Adam pass writes scales_out / rot_out / opac_out of the UPDATED parameters
+ * (for the non-NULL ones of scaling / rotation / opacity), so the next views step can skip sgr_activate. */
 typedef struct SgrMapStep {
   int64_t num_gaussians;
   const float* scaling;        /* raw parameters for sgr_activate (NULL = skip activation) */

@@ -346,7 +346,10 @@ int sgr_map_views(int32_t num_views, const SgrMapView* views, const SgrInputs* i
 static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_clean, bool allow_fuse, bool* fused_out, void* stream) {
   if (fused_out) *fused_out = false;
   if (!p) return set_error(SGR_ERR_INVALID, "map_step: null argument");
-  if (!skip_activate && (p->scaling || p->rotation || p->opacity))
+  // an optimiser-only step (no views: the second half of a multi-GPU iteration, after the all-reduce) writes the
+  // activations of the UPDATED parameters in the Adam pass itself instead of activating the old ones first
+  const bool adam_only = p->num_views == 0 && p->adam_groups;
+  if (!skip_activate && !adam_only && (p->scaling || p->rotation || p->opacity))
     if (int rc = sgr_activate(p->num_gaussians, p->scaling, p->rotation, p->opacity, p->scales_out, p->rot_out, p->opac_out, stream)) return rc;
   FusedAdam fa;
   bool try_fuse = false;
@@ -381,7 +384,11 @@ static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_cle
                                 try_fuse ? &fa : nullptr, &fused, stream))
       return rc;
   if (p->adam_groups && !fused)
-    if (int rc = sgr_gaussian_adam_step(p->num_gaussians, p->adam_groups, p->beta1, p->beta2, p->eps, p->iso_weight, stream)) return rc;
+    if (int rc = gaussian_adam_step_act(p->num_gaussians, p->adam_groups, p->beta1, p->beta2, p->eps, p->iso_weight,
+                                        adam_only && p->scaling ? p->scales_out : nullptr,
+                                        adam_only && p->rotation ? p->rot_out : nullptr,
+                                        adam_only && p->opacity ? p->opac_out : nullptr, stream))
+      return rc;
   if (p->exp_rows > 0 && !fused)
     if (int rc = sgr_masked_adam(p->exp_rows, p->exp_row_width, p->exp_param, p->exp_grad, p->exp_avg, p->exp_avg_sq, p->exp_step,
                                  p->exp_active, p->exp_lr, p->exp_beta1, p->exp_beta2, p->exp_eps, stream))

@@ -232,7 +232,7 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
       adam_update(p, g, m, v, 2, c);
       A.param[i] = p; A.exp_avg[i] = m; A.exp_avg_sq[i] = v;
     }
-    if (MODE != 0 && o_out) o_out[i] = 1.f / (1.f + expf(-p));
+    if (o_out) o_out[i] = 1.f / (1.f + expf(-p));
   }
   {   // scaling: exp, plus d/ds of iso_weight * mean_{N,3} |s - mean_3(s)|
     const SgrAdamGroup& A = G.g[3];
@@ -266,7 +266,7 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
       st3(A.exp_avg + 3 * i, F3{m[0], m[1], m[2]});
       st3(A.exp_avg_sq + 3 * i, F3{v[0], v[1], v[2]});
     }
-    if (MODE != 0 && s_out) st3(s_out + 3 * i, F3{expf(p[0]), expf(p[1]), expf(p[2])});
+    if (s_out) st3(s_out + 3 * i, F3{expf(p[0]), expf(p[1]), expf(p[2])});
   }
   {   // rotation: x / max(|x|, 1e-12)
     const SgrAdamGroup& A = G.g[4];
@@ -300,18 +300,20 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
       *(float4*)(A.exp_avg + 4 * i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
       *(float4*)(A.exp_avg_sq + 4 * i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
-    if (MODE != 0 && r_out) {      // same expression as activate_kernel
+    if (r_out) {      // same expression as activate_kernel
       float nn = fmaxf(sqrtf(pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2] + pp[3] * pp[3]), 1e-12f);
       *(float4*)(r_out + 4 * i) = make_float4(pp[0] / nn, pp[1] / nn, pp[2] / nn, pp[3] / nn);
     }
   }
 }
 
-__global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroups G, AdamConst c, float iso_coef) {
+__global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroups G, AdamConst c, float iso_coef,
+                                                            float* __restrict__ s_out, float* __restrict__ r_out,
+                                                            float* __restrict__ o_out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float zero[14] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  gaussian_adam_one<0>(i, G, c, iso_coef, zero, nullptr, nullptr, nullptr);
+  gaussian_adam_one<0>(i, G, c, iso_coef, zero, s_out, r_out, o_out);
 }
 
 // The single-GPU tail of a mapping iteration in one pass: thread = Gaussian; adds up its gradient records over the
@@ -364,6 +366,19 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
     fa.stat_maxr[i] = fmaxf(fa.stat_maxr[i], st_maxr);
   }
   gaussian_adam_one<MODE>(i, fa.G, fa.c, fa.iso_coef, a, fa.s_out, fa.r_out, fa.o_out);
+}
+
+// the Adam step of all five groups; with output pointers also the activations the next forward renders with (the
+// multi-GPU iteration: all-reduce, then this ONE pass instead of Adam + activate)
+int gaussian_adam_step_act(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight,
+                           float* s_out, float* r_out, float* o_out, void* stream) {
+  if (n < 0 || !groups) return set_error(SGR_ERR_INVALID, "gaussian_adam: bad argument");
+  if (n == 0) return SGR_OK;
+  FusedAdam fa;
+  if (int rc = make_fused_adam(n, groups, beta1, beta2, eps, iso_weight, &fa)) return rc;
+  hipLaunchKernelGGL(gaussian_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, fa.G, fa.c,
+                     fa.iso_coef, s_out, r_out, o_out);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "gaussian_adam launch failed");
 }
 
 void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st) {
@@ -625,13 +640,7 @@ int sgr_activate(int64_t n, const float* scaling, const float* rotation, const f
 
 int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight,
                            void* stream) {
-  if (n < 0 || !groups) return set_error(SGR_ERR_INVALID, "gaussian_adam: bad argument");
-  if (n == 0) return SGR_OK;
-  FusedAdam fa;
-  if (int rc = make_fused_adam(n, groups, beta1, beta2, eps, iso_weight, &fa)) return rc;
-  hipLaunchKernelGGL(gaussian_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, fa.G, fa.c,
-                     fa.iso_coef);
-  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "gaussian_adam launch failed");
+  return gaussian_adam_step_act(n, groups, beta1, beta2, eps, iso_weight, nullptr, nullptr, nullptr, stream);
 }
 
 int sgr_masked_adam(int32_t rows, int32_t row_width, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

@@ -228,6 +228,8 @@ struct FusedAdam {
   float exp_lr, exp_b1, exp_b2, exp_eps;
 };
 int make_fused_adam(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight, FusedAdam* out);
+int gaussian_adam_step_act(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight,
+                           float* s_out, float* r_out, float* o_out, void* stream);
 void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st);
 
 // ---- optional per-kernel event timing (sgr_profile_enable / sgr_profile_read)

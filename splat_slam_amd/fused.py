@@ -432,14 +432,14 @@ class FusedMappingLoop(MappingLoop):
         C.memmove(C.byref(adam_st), C.byref(st), C.sizeof(st))
         views_st.adam_groups, views_st.exp_rows, views_st.grads_clean = None, 0, -1
         views_st.num_views, views_st.views = nw + per, arr
-        adam_st.num_views, adam_st.views = 0, None
-        adam_st.scaling, adam_st.rotation, adam_st.opacity = None, None, None      # (activation belongs to the views call)
-        adam_st.adam_groups = pl.groups
+        adam_st.num_views, adam_st.views = 0, None      # optimiser-only step: its Adam pass also writes the activations of
+        adam_st.adam_groups = pl.groups                 # the updated parameters, so only the first views call activates
         stream = self._stream()
         for k in range(n_it):
             for j in range(per):
                 arr[nw + j] = pool[picks[k * per + j]]
             nat.check(self.lib.sgr_map_step(C.byref(views_st), stream), "sgr_map_step")
+            views_st.scaling, views_st.rotation, views_st.opacity = None, None, None
             self._all_reduce_sum(self._acc["flat"])
             pl.groups[0].lr = lrs[k]
             for g in range(5):
