@@ -8,11 +8,11 @@
 // MI355X design (not the CUDA 16x16-block/atomicAdd scheme):
 //   * a bin is 8x8 pixels = exactly one wave64; a 256-thread workgroup is four independent waves covering one
 //     16x16 reference tile.  Waves never synchronise with each other: no __syncthreads in either kernel.
-//   * FORWARD first sorts its tile's (depth bits | Gaussian) keys: <= 64 keys in registers (bitonic network over
-//     lanes), <= 1024 keys in the wave's LDS slice, longer lists in place in HBM (slow path).  Then it is pixel-parallel
-//     (lane = pixel): 64 sorted splats at a time are staged into LDS pair-interleaved and walked TWO splats per trip with
-//     broadcast ds_read_b128 + packed fp32 (v_pk_*_f32); per-pixel accumulators stay in VGPRs.  n_touched is one ballot+popcount+atomic per
-//     (wave, splat), not per pixel.
+//   * FORWARD first sorts its tile's (depth bits | Gaussian) keys: <= 64 keys in registers (every lane ranks its key
+//     against the others, broadcast through SGPRs), <= 256 / 4096 keys bitonic in the wave's LDS slice, longer lists in
+//     place in HBM (slow path).  Then it is pixel-parallel (lane = pixel): 64 sorted splats at a time are staged into LDS
+//     pair-interleaved and walked TWO splats per trip with broadcast ds_read_b128 + packed fp32 (v_pk_*_f32); per-pixel
+//     accumulators stay in VGPRs.  n_touched is one ballot+popcount+atomic per (wave, splat), not per pixel.
 //   * BACKWARD is splat-parallel (lane = splat).  For one pixel the transmittance in front of every splat is a
 //     multiplicative DPP scan over lanes and the colour behind it an additive DPP scan of ONE scalar
 //     (w_j = dL/dC . rgb_j + dL/dD * depth_j): 2 scans per (pixel, list) instead of the 10 cross-lane reductions of a
