@@ -31,7 +31,7 @@ switch so it can be flipped if the real CUDA build is ever available:
 from __future__ import annotations
 
 import math
-from typing import NamedTuple, Optional
+from typing import NamedTuple
 
 import torch
 

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from splat_slam_amd import _native as nat
-from splat_slam_amd.mapper import MappingLoop, PipelineParams
+from splat_slam_amd.mapper import MappingLoop
 from splat_slam_amd.pose import update_pose
 
 _GROUPS = ["xyz", "f_dc", "opacity", "scaling", "rotation"]     # order expected by sgr_gaussian_adam_step

@@ -12,7 +12,6 @@ What differs, on purpose (MI355X-first, documented in DESIGN.md):
   * `unique_kfIDs` / `n_obs` live on the same device as the parameters (the reference keeps them on the CPU and pays
     a D2H mask copy per densify, :556-557,666-667).
 """
-import math
 
 import numpy as np
 import torch

@@ -1,6 +1,5 @@
 """Mapping loss -- mirror of /root/reference/thirdparty/monogs/utils/slam_utils.py:71-119 (SSIM branch off by default,
 /root/reference/configs/splat_slam.yaml:36) plus a fused HIP variant (`sgr_mapping_loss`) with identical values."""
-import ctypes as C
 
 import torch
 

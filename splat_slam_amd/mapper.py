@@ -9,7 +9,7 @@ keyframe selection -- is outside this file; `splat_slam_amd.synthetic` feeds the
 import numpy as np
 import torch
 
-from splat_slam_amd.camera import Camera, getProjectionMatrix2
+from splat_slam_amd.camera import getProjectionMatrix2
 from splat_slam_amd.gaussian_model import GaussianModel, OptParams
 from splat_slam_amd.losses import get_loss_mapping, get_loss_mapping_fused
 from splat_slam_amd.pose import update_pose

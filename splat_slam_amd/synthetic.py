@@ -1,6 +1,5 @@
 """Synthetic mapping-only feed: the "room" scene, its cameras and the keyframe stream that stands
 in for tracker + DepthVideo + dataset, none of which exist on the GPU box (no datasets, no network)."""
-import copy
 import math
 
 import numpy as np
