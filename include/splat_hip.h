@@ -280,7 +280,11 @@ typedef struct SgrMapStep {
   float exp_lr, exp_beta1, exp_beta2, exp_eps;
   int32_t grads_clean;         /* > 0: the gradient sinks are known to be all-zero on entry (as every Adam step leaves
                                   them); the fused gather+Adam pass then never touches them.  0: unknown.
-                                  < 0: keep gather and Adam as separate passes (verification) */
+                                  -1: keep gather and Adam as separate passes (verification)
+                                  -2 (with adam_groups == NULL): no optimiser step, but the gather pass of the fused form
+                                  ADDS the views' gradient sums to the sinks and carries the loss sums and the exposure
+                                  step -- the first half of a multi-GPU iteration (an all-reduce of the sinks and an
+                                  optimiser-only step follow) */
 } SgrMapStep;
 int sgr_map_step(const SgrMapStep* step, void* stream);
 

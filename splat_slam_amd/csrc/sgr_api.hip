@@ -378,6 +378,33 @@ static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_cle
       }
     }
   }
+  // grads_clean == -2: no optimiser step in this call, but the gather pass of the fused form (with its riders: loss sums
+  // and the exposure step) adds the views' gradients to the sinks -- the first half of a multi-GPU iteration
+  if (p->grads_clean == -2 && !p->adam_groups && p->num_views > 0 && p->num_views <= kMaxViews && !p->forward_only && p->grads &&
+      p->in && p->views) {
+    const SgrGradInputs& g = *p->grads;
+    try_fuse = g.accumulate && g.dL_dmeans3D && g.dL_dshs && g.dL_dopacities && g.dL_dscales && g.dL_drotations &&
+               !g.dL_dmeans2D && !g.dL_dcolors_precomp && !g.dL_dcov3D_precomp && p->in->shs && !p->in->colors_precomp &&
+               p->in->scales && p->in->rotations && p->num_gaussians == p->views[0].settings.num_gaussians;
+    for (int v = 0; v < p->num_views && try_fuse; ++v)
+      try_fuse = !p->views[v].dL_dtau && p->views[v].settings.sh_degree == 0 && p->views[v].settings.sh_coeffs == 1;
+    if (try_fuse) {
+      fa = FusedAdam{};
+      fa.gather_only = 1;
+      fa.G.g[0].grad = g.dL_dmeans3D; fa.G.g[1].grad = g.dL_dshs; fa.G.g[2].grad = g.dL_dopacities;
+      fa.G.g[3].grad = g.dL_dscales; fa.G.g[4].grad = g.dL_drotations;
+      fa.stat_accum = g.stat_grad_accum;
+      fa.stat_denom = g.stat_grad_accum ? g.stat_denom : nullptr;
+      fa.stat_maxr = g.stat_grad_accum ? g.stat_max_radii : nullptr;
+      if (p->exp_rows > 0) {
+        if (!p->exp_param || !p->exp_grad || !p->exp_avg || !p->exp_avg_sq || !p->exp_step || !p->exp_active || p->exp_row_width <= 0)
+          return set_error(SGR_ERR_INVALID, "map_step: exposure block incomplete");
+        fa.exp_rows = p->exp_rows; fa.exp_width = p->exp_row_width; fa.exp_param = p->exp_param; fa.exp_grad = p->exp_grad;
+        fa.exp_avg = p->exp_avg; fa.exp_avg_sq = p->exp_avg_sq; fa.exp_step = p->exp_step; fa.exp_active = p->exp_active;
+        fa.exp_lr = p->exp_lr; fa.exp_b1 = p->exp_beta1; fa.exp_b2 = p->exp_beta2; fa.exp_eps = p->exp_eps;
+      }
+    }
+  }
   bool fused = false;
   if (p->num_views > 0)
     if (int rc = map_views_impl(p->num_views, p->views, p->in, p->grads, p->alpha, p->rgb_boundary_threshold, p->forward_only,

@@ -318,7 +318,8 @@ __global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroup
 
 // The single-GPU tail of a mapping iteration in one pass: thread = Gaussian; adds up its gradient records over the
 // views of the batch in view order (exactly grad_gather_kernel's sum), then the Adam step of all five groups, then the
-// activations the next iteration renders with.
+// activations the next iteration renders with.  MODE 3 (multi-GPU) stops after the sum: it is added to the gradient
+// buffers (what grad_gather_kernel does with accumulate = 1), the riders still do the loss sums + exposure step.
 template <int MODE>
 __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nviews, LOff L, FusedAdam fa) {
   if ((int)blockIdx.x < fa.tail_views) {      // rider blocks (scheduled first): one per view
@@ -365,7 +366,18 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
     fa.stat_denom[i] += st_cnt;
     fa.stat_maxr[i] = fmaxf(fa.stat_maxr[i], st_maxr);
   }
-  gaussian_adam_one<MODE>(i, fa.G, fa.c, fa.iso_coef, a, fa.s_out, fa.r_out, fa.o_out);
+  if (MODE == 3) {          // multi-GPU iteration: the sums go into the flat gradient buffer the ranks all-reduce
+    if (!any) return;
+    float* g0 = fa.G.g[0].grad + 3 * (size_t)i; float* g1 = fa.G.g[1].grad + 3 * (size_t)i; float* g3 = fa.G.g[3].grad + 3 * (size_t)i;
+    float* g4 = fa.G.g[4].grad + 4 * (size_t)i;
+    g0[0] += a[0]; g0[1] += a[1]; g0[2] += a[2];
+    g1[0] += a[3]; g1[1] += a[4]; g1[2] += a[5];
+    fa.G.g[2].grad[i] += a[6];
+    g3[0] += a[7]; g3[1] += a[8]; g3[2] += a[9];
+    g4[0] += a[10]; g4[1] += a[11]; g4[2] += a[12]; g4[3] += a[13];
+    return;
+  }
+  gaussian_adam_one<MODE == 3 ? 1 : MODE>(i, fa.G, fa.c, fa.iso_coef, a, fa.s_out, fa.r_out, fa.o_out);
 }
 
 // the Adam step of all five groups; with output pointers also the activations the next forward renders with (the
@@ -384,7 +396,9 @@ int gaussian_adam_step_act(int64_t n, const SgrAdamGroup groups[5], float beta1,
 void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st) {
   if (L.N <= 0) return;
   const int grid = L.pre_blocks + fa.tail_views;
-  if (fa.grads_clean)
+  if (fa.gather_only)
+    hipLaunchKernelGGL(gather_adam_kernel<3>, dim3(grid), dim3(256), 0, st, tab, nviews, L, fa);
+  else if (fa.grads_clean)
     hipLaunchKernelGGL(gather_adam_kernel<2>, dim3(grid), dim3(256), 0, st, tab, nviews, L, fa);
   else
     hipLaunchKernelGGL(gather_adam_kernel<1>, dim3(grid), dim3(256), 0, st, tab, nviews, L, fa);

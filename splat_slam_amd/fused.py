@@ -430,7 +430,10 @@ class FusedMappingLoop(MappingLoop):
         views_st, adam_st = nat.SgrMapStep(), nat.SgrMapStep()
         C.memmove(C.byref(views_st), C.byref(st), C.sizeof(st))
         C.memmove(C.byref(adam_st), C.byref(st), C.sizeof(st))
-        views_st.adam_groups, views_st.exp_rows, views_st.grads_clean = None, 0, -1
+        # views half: gather pass of the fused form without the optimiser (sums added to the flat buffer; the loss sums and
+        # the exposure step -- per view, no collective -- ride in that launch); optimiser half: Gaussian groups only
+        views_st.adam_groups, views_st.grads_clean = None, -2
+        adam_st.exp_rows = 0
         views_st.num_views, views_st.views = nw + per, arr
         adam_st.num_views, adam_st.views = 0, None      # optimiser-only step: its Adam pass also writes the activations of
         adam_st.adam_groups = pl.groups                 # the updated parameters, so only the first views call activates
