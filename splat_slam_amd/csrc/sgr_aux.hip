@@ -341,25 +341,35 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
     }
     return;
   }
+  // per-view pointers into LDS: the gather below indexes them per LANE (a by-value kernarg table cannot be)
+  __shared__ const char* s_scratch[kMaxViews];
+  __shared__ const int32_t* s_radii[kMaxViews];
+#pragma unroll
+  for (int u = 0; u < kMaxViews; ++u)
+    if ((int)threadIdx.x == u && u < nviews) { s_scratch[u] = tab.scratch[u]; s_radii[u] = tab.radii[u]; }
+  __syncthreads();
   const int i = ((int)blockIdx.x - fa.tail_views) * blockDim.x + threadIdx.x;
   if (i >= L.N) return;
   float a[14];
 #pragma unroll
   for (int k = 0; k < 14; ++k) a[k] = 0.f;
   float st_norm = 0.f, st_cnt = 0.f, st_maxr = 0.f;
-  bool any = false;
-  for (int v = 0; v < nviews; ++v) {
-    const int r = tab.radii[v][i];
-    if (r > 0) {
-      any = true;
-      const float4* rec = (const float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)i * 4;
-      float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-      a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
-      a[8] += r2.x; a[9] += r2.y; a[10] += r2.z; a[11] += r2.w; a[12] += r3.x; a[13] += r3.y;
-      st_norm += sqrtf(r3.z * r3.z + r3.w * r3.w);
-      st_cnt += 1.f;
-      st_maxr = fmaxf(st_maxr, (float)r);
-    }
+  // K1 left one word per Gaussian with the views of the batch that see it.  Every lane walks ITS OWN set bits in
+  // ascending view order (the fixed summation order of grad_gather_kernel): a wave makes max-over-lanes(popcount) record
+  // round trips -- about 3 for a SLAM batch -- instead of one per view of the batch.
+  uint32_t seen = ((const uint32_t*)(tab.saved[0] + L.o_vismask))[i];
+  const bool any = seen != 0u;
+  while (seen) {
+    const int v = __builtin_ctz(seen);
+    seen &= seen - 1u;
+    const float4* rec = (const float4*)(s_scratch[v] + L.o_gradrec) + (size_t)i * 4;
+    const int r = s_radii[v][i];
+    float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
+    a[8] += r2.x; a[9] += r2.y; a[10] += r2.z; a[11] += r2.w; a[12] += r3.x; a[13] += r3.y;
+    st_norm += sqrtf(r3.z * r3.z + r3.w * r3.w);
+    st_cnt += 1.f;
+    st_maxr = fmaxf(st_maxr, (float)r);
   }
   if (any && fa.stat_accum) {
     fa.stat_accum[i] += st_norm;

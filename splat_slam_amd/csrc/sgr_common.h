@@ -79,7 +79,7 @@ struct LOff {
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_seg_list, o_entries, o_bucket, o_partials, o_tau_part, o_gradrec, o_taurec;
+      o_seg_list, o_vismask, o_entries, o_bucket, o_partials, o_tau_part, o_gradrec, o_taurec;
 };
 // shared (view independent) scalars of a batch
 struct Common {
@@ -119,7 +119,7 @@ struct Layout {
   // saved
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_seg_list, saved_bytes, zero_bytes;
+      o_seg_list, o_vismask, saved_bytes, zero_bytes;
   // scratch (forward)
   size_t o_entries, o_bucket;
   // scratch (backward) -- aliases the forward scratch
@@ -155,6 +155,7 @@ struct Layout {
     o_block_base_v = take(nb * 4);
     o_vis_list = take(n * 4);
     o_seg_list = take(n * 4);        // per-segment visible lists written by K1; K3 turns them into the compact o_vis_list
+    o_vismask = take(n * 4);         // per Gaussian: the views of the BATCH that see it (bit v; kept in the batch's first saved block)
     saved_bytes = o;
 
     o = 0;
@@ -176,7 +177,7 @@ struct Layout {
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;
     d.o_n_contrib = o_n_contrib; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
     d.o_block_base_t = o_block_base_t; d.o_block_base_v = o_block_base_v; d.o_vis_list = o_vis_list;
-    d.o_seg_list = o_seg_list; d.o_entries = o_entries; d.o_bucket = o_bucket; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
+    d.o_seg_list = o_seg_list; d.o_vismask = o_vismask; d.o_entries = o_entries; d.o_bucket = o_bucket; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
     d.o_gradrec = o_gradrec; d.o_taurec = o_taurec;
     return d;
   }

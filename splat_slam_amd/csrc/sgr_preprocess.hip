@@ -274,6 +274,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint32_t vstart[kMaxViews + 1];
   __shared__ uint32_t vbase_t[kMaxViews + 1], vbase_v[kMaxViews + 1];
   __shared__ uint32_t red[4];
+  __shared__ uint32_t vis_bits[kSeg];            // per Gaussian of the segment: bit v = view v of the batch sees it
   const int N = L.N;
   const int seg = blockIdx.x, seg0 = seg * kSeg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
   }
   if (tid <= kMaxViews) { vbase_t[tid] = 0u; vbase_v[tid] = 0u; }
+  vis_bits[tid] = 0u;
   __syncthreads();
 
   // ---- phase A
@@ -391,6 +393,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     const uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
     const uint32_t vis = o.visible ? 1u : 0u;
     if (o.visible) {
+      atomicOr(&vis_bits[i - seg0], 1u << v);
       p_radii[v][i] = (int32_t)o.rad;
       float4* rec = (float4*)((GRec*)(saved + L.o_grec) + i);          // q3 (prefix, list slot) follows after the scans
       rec[0] = make_float4(o.px, o.py, __uint_as_float((uint32_t)o.x0 | ((uint32_t)o.y0 << 16)),
@@ -462,6 +465,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     carry_v += tot_v;
   }
   __syncthreads();
+  // which views of the batch see Gaussian ia (one word instead of one radii word per view for the optimiser pass)
+  if (ia < N) ((uint32_t*)(p_saved[0] + L.o_vismask))[ia] = vis_bits[tid];
   if (tid < nviews) {
     char* saved = p_saved[tid];
     ((uint32_t*)(saved + L.o_block_touched))[seg] = vbase_t[tid + 1] - vbase_t[tid];
