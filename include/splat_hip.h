@@ -236,8 +236,11 @@ typedef struct SgrMapView {
   const float* exposure_a;     /* [1] or NULL */
   const float* exposure_b;     /* [1] or NULL */
   float* loss;                 /* [1] */
-  float* dL_dimage;            /* [3,H,W] scratch for this view */
-  float* dL_ddepth;            /* [1,H,W] */
+  float* dL_dimage;            /* [3,H,W] scratch for this view.  Uniform batches (the normal case) pass the pixel
+                                  gradients of the L1 loss from the compositing epilogue to the backward as ONE code
+                                  byte per pixel in its first H*W bytes (2 bits per value: 0, +, -); only the
+                                  one-view-at-a-time path of heterogeneous batches leaves float gradients here */
+  float* dL_ddepth;            /* [1,H,W] scratch (same remark) */
   float* dL_dexposure;         /* [2] = (d/da, d/db) or NULL */
   float* dL_dtau;              /* [6] or NULL */
   void* loss_scratch;

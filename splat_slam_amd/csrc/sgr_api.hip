@@ -19,7 +19,7 @@ void launch_preprocess_bwd(const ViewTab&, int, const LOff&, const Common&, cons
 void launch_binning(const ViewTab&, int, const LOff&, hipStream_t);
 void launch_zero_heads(const ViewTab&, int, const LOff&, size_t, hipStream_t);
 void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
-void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, hipStream_t);
+void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
 
 static thread_local char g_err[512] = "";
 int set_error(int code, const char* fmt, ...) {
@@ -221,7 +221,7 @@ int sgr_backward(const SgrSettings* s, const SgrInputs* in, const int32_t* radii
   tab.dL_dcolor[0] = go->dL_dcolor; tab.dL_ddepth[0] = go->dL_ddepth; tab.dL_dtau[0] = gi->dL_dtau;
   LOff d = L.dev();
   Common cm = make_common(s);
-  launch_blend_bwd(tab, 1, d, s->bg, st);
+  launch_blend_bwd(tab, 1, d, s->bg, nullptr, nullptr, st);
   launch_preprocess_bwd(tab, 1, d, cm, *in, *gi, nullptr, st);
   HIP_TRY(hipGetLastError());
   return SGR_OK;
@@ -324,7 +324,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
     } else {
       launch_mapping_loss_final(lt, nv, HW, L.ntiles, alpha, st);
     }
-    launch_blend_bwd(tab, nv, d, f.settings.bg, st);
+    launch_blend_bwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
     launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, fuse ? fused : nullptr, st);
     if (fuse && fused_done) *fused_done = true;
   }

@@ -278,23 +278,27 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
     if (gt_image) {
       // fused mapping loss (slam_utils.py:71-105): this pixel's residuals, the gradients the backward consumes, and
       // its share of the four sums (|rgb|, |depth|, d/da, d/db)
+      // The L1 gradients are +-constant or 0 per value: dL/dC_c = sign * (w_rgb * e^a), dL/dD = sign * w_dep.  The backward
+      // gets ONE code byte per pixel (2 bits per value: 0, 1 = +, 2 = -) in the first H*W bytes of the view's dL_dimage
+      // scratch and rebuilds the same floats (16 -> 1 byte per pixel written here and read there).
       const float g[3] = {gt0, gt1, gt2};
       const bool m = (g[0] + g[1] + g[2]) > lc.thr;
-      float* __restrict__ dimage = lt.dimage[vw];
+      uint32_t code = 0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float r = m ? (ea * I[c] + eb) - g[c] : 0.f;
         l_rgb += fabsf(r);
         float sgn = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+        code |= ((r > 0.f) ? 1u : ((r < 0.f) ? 2u : 0u)) << (2 * c);
         float dab = lc.w_rgb * sgn;
-        dimage[c * hw + pix] = dab * ea;
         l_da += dab * ea * I[c];
         l_db += dab;
       }
       const float gd = gtd;
       const float rd = (gd > 0.01f) ? D - gd : 0.f;
       l_dep = fabsf(rd);
-      lt.ddepth[vw][pix] = lc.w_dep * ((rd > 0.f) ? 1.f : ((rd < 0.f) ? -1.f : 0.f));
+      code |= ((rd > 0.f) ? 1u : ((rd < 0.f) ? 2u : 0u)) << 6;
+      ((uint8_t*)lt.dimage[vw])[pix] = (uint8_t)code;
     }
   }
   if (gt_image) {      // uniform per view
@@ -508,7 +512,12 @@ __device__ __forceinline__ void bwd_chunk2(
   }
 }
 
-__global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg) {
+// PACKED: the pixel gradients come as the forward's loss epilogue left them (one code byte per pixel, see blend_fwd)
+struct SignGrad { const float* exp_a[kMaxViews]; float w_rgb, w_dep; };
+__device__ __forceinline__ float sign_code(uint32_t c, float k) { return (c & 1u) ? k : ((c & 2u) ? -k : 0.f); }
+
+template <bool PACKED>
+__global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
   const int vw = blockIdx.y;
   const char* saved = tab.saved[vw];
   const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
@@ -536,8 +545,15 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
     const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
-      pxA[0] = dL_dcolor[pix]; pxA[1] = dL_dcolor[hw + pix]; pxA[2] = dL_dcolor[2 * hw + pix];
-      pxA[3] = dL_ddepth ? dL_ddepth[pix] : 0.f;
+      if (PACKED) {
+        const uint32_t code = ((const uint8_t*)dL_dcolor)[pix];
+        const float k_rgb = sg.w_rgb * (sg.exp_a[vw] ? __expf(sg.exp_a[vw][0]) : 1.f);
+        pxA[0] = sign_code(code, k_rgb); pxA[1] = sign_code(code >> 2, k_rgb); pxA[2] = sign_code(code >> 4, k_rgb);
+        pxA[3] = sign_code(code >> 6, sg.w_dep);
+      } else {
+        pxA[0] = dL_dcolor[pix]; pxA[1] = dL_dcolor[hw + pix]; pxA[2] = dL_dcolor[2 * hw + pix];
+        pxA[3] = dL_ddepth ? dL_ddepth[pix] : 0.f;
+      }
       pxB[0] = final_T[pix];
       pxB[2] = __int_as_float((int)n_contrib[pix]);
     }
@@ -635,11 +651,20 @@ void launch_blend_fwd(const ViewTab& tab, int nviews, const LOff& L, const float
   else launch_blend_fwd_t<kSortLight>(tab, nviews, L, bg, t, c, st);
 }
 
-void launch_blend_bwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, hipStream_t st) {
+// lt / lc given: the pixel gradients are the code bytes blend_fwd's loss epilogue wrote for these views
+void launch_blend_bwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab* lt, const LossCoef* lc,
+                      hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
   ProfScope prof(PK_BLEND_BWD, st);
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid, nviews), dim3(256), 0, st, tab, L, bg);
+  SignGrad sg = {};
+  if (lt && lc) {
+    for (int v = 0; v < nviews; ++v) sg.exp_a[v] = lt->exp_a[v];
+    sg.w_rgb = lc->w_rgb; sg.w_dep = lc->w_dep;
+    hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid, nviews), dim3(256), 0, st, tab, L, bg, sg);
+  } else {
+    hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid, nviews), dim3(256), 0, st, tab, L, bg, sg);
+  }
 }
 
 }  // namespace sgr
