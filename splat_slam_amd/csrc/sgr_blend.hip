@@ -64,6 +64,25 @@ __device__ __forceinline__ void wave_sort_any(int n, int lane, LD load, ST store
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
 
+// Wave-wide reductions of the forward's epilogue as single-instruction DPP steps (a lane whose DPP source is out of range
+// keeps its value).  Same step sequence -- hence the same association of the sum -- as wave_scan_add().
+#define SGR_ROW_STEPS(X)                                                                                            \
+  X("row_shr:1 row_mask:0xf bank_mask:0xf") X("row_shr:2 row_mask:0xf bank_mask:0xf") X("row_shr:4 row_mask:0xf bank_mask:0xf") \
+  X("row_shr:8 row_mask:0xf bank_mask:0xf") X("row_bcast:15 row_mask:0xa bank_mask:0xf") X("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#define SGR_MAX1(CTRL) "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 " CTRL "\n\t"
+#define SGR_ADD4(CTRL)                                                                                       \
+  "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL \
+  "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // maximum over the wave, in every lane
+  asm(SGR_ROW_STEPS(SGR_MAX1) "s_nop 1" : "+v"(v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ void wave_sum4(float& a, float& b, float& c, float& d) {   // four totals, in every lane
+  // (interleaved: three independent instructions separate dependent DPP steps, no wait states needed)
+  asm("s_nop 1\n\t" SGR_ROW_STEPS(SGR_ADD4) "s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  a = readlane_f(a, 63); b = readlane_f(b, 63); c = readlane_f(c, 63); d = readlane_f(d, 63);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int SORT_MAX>
 __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
@@ -103,7 +122,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   const float* __restrict__ gt_image = lt.gt_image[vw];
   float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, gtd = 0.f, ea = 1.f, eb = 0.f;
   if (gt_image && inside) {
-    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
     gt0 = gt_image[pix]; gt1 = gt_image[hw + pix]; gt2 = gt_image[2 * hw + pix];
     gtd = lt.gt_depth[vw][pix];
     ea = lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f;
@@ -257,14 +276,12 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   const float C0 = Cr.x + Cr.y, C1 = Cg.x + Cg.y, C2 = Cb.x + Cb.y, D = Dd.x + Dd.y;
 
   // per-tile bound for the backward: it never has to look past the last contributor of any pixel
-  uint32_t mx = last;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+  const uint32_t mx = wave_max_u32(last);
   if (lane == 0) tile_maxc[tile] = mx;
 
   float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;
   if (inside) {
-    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
     final_T[pix] = T;
     n_contrib[pix] = last;
     const float I[3] = {C0 + T * bg[0], C1 + T * bg[1], C2 + T * bg[2]};
@@ -302,7 +319,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
     }
   }
   if (gt_image) {      // uniform per view
-    l_rgb = wave_sum(l_rgb); l_dep = wave_sum(l_dep); l_da = wave_sum(l_da); l_db = wave_sum(l_db);
+    wave_sum4(l_rgb, l_dep, l_da, l_db);
     if (lane == 0) ((LossPart*)lt.parts[vw])[tile] = {l_rgb, l_dep, l_da, l_db};
   }
 }
@@ -544,7 +561,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   {
     const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
     if (px < W && py < H) {
-      const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+      const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
       if (PACKED) {
         const uint32_t code = ((const uint8_t*)dL_dcolor)[pix];
         const float k_rgb = sg.w_rgb * (sg.exp_a[vw] ? __expf(sg.exp_a[vw][0]) : 1.f);
