@@ -221,7 +221,9 @@ def main():
     views_in_launch = nv if args.loop == "fused" else 1
     r_eff_launch = R_eff_sum if args.loop == "fused" else per_view[0][2]
     alg_bytes = 84 * r_eff_launch + (24 * HW + 40 * N) * views_in_launch          # SURVEY.md 8d figure
-    own_bytes = 92 * r_eff_launch + 24 * HW * views_in_launch                      # what this design moves
+    # what this design moves: 92 B per pair; per pixel 9 B in the fused loop (final_T, n_contrib, one code byte of
+    # loss-gradient signs) or 24 B through the autograd API (float gradients)
+    own_bytes = 92 * r_eff_launch + (9 if args.loop == "fused" else 24) * HW * views_in_launch
     achieved = alg_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
     pair_evals = r_eff_launch * 64               # (pixel, splat) pairs the kernel evaluates
     valu_tflops = pair_evals * 60 / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
@@ -229,7 +231,8 @@ def main():
     try:                                         # PMC pass of this same command, committed under profiles/
         pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_hbm_bytes.json")))
         if pm.get("workload") == [N, intr["W"], intr["H"], views_in_launch]:
-            traffic = pm["kernels"]["sgr::blend_bwd_kernel"]["hbm_bytes_per_launch_corrected"]
+            name = "sgr::blend_bwd_kernel<true>" if args.loop == "fused" else "sgr::blend_bwd_kernel<false>"
+            traffic = pm["kernels"][name]["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
     roofline = {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

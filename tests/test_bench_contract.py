@@ -37,9 +37,9 @@ def test_committed_profiles_agree_with_the_bench_line():
     d = _latest_line()
     tag = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))[-1].split(os.sep)[-1].split("_")[0]
     k = json.load(open(os.path.join(ROOT, "profiles", tag + "_kernel_batched_avg.json")))["kernels"]
-    trace_us = k["sgr::blend_bwd_kernel"]["avg_us"]
+    trace_us = k["sgr::blend_bwd_kernel<true>"]["avg_us"]
     event_us = 1e3 * d["roofline"]["avg_launch_ms"]
     assert abs(trace_us - event_us) / event_us < 0.10, (trace_us, event_us)      # rocprofv3 trace vs live HIP events
-    h = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm_bytes.json")))["kernels"]["sgr::blend_bwd_kernel"]
+    h = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm_bytes.json")))["kernels"]["sgr::blend_bwd_kernel<true>"]
     assert d["roofline"]["traffic"] in (None, h["hbm_bytes_per_launch_corrected"]) or \
         abs(d["roofline"]["traffic"] - h["hbm_bytes_per_launch_corrected"]) / h["hbm_bytes_per_launch_corrected"] < 0.05
