@@ -83,6 +83,14 @@ __device__ __forceinline__ void wave_sum4(float& a, float& b, float& c, float& d
   a = readlane_f(a, 63); b = readlane_f(b, 63); c = readlane_f(c, 63); d = readlane_f(d, 63);
 }
 
+// Per-pixel state that only the two blend kernels exchange is stored TILE-major (index tile * 64 + lane): a wave then
+// reads / writes one contiguous run instead of eight row pieces of its 8x8 tile.  The loss-gradient code bytes live in
+// the caller's [3,H,W] float scratch: tile-major as well whenever that holds 64 bytes per tile (any image but a
+// few-pixel one).
+__device__ __forceinline__ bool code_bytes_tiled(const LOff& L) {
+  return (uint64_t)L.ntiles * 64ull <= 12ull * (uint64_t)L.H * (uint64_t)L.W;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int SORT_MAX>
 __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
@@ -98,8 +106,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   float* __restrict__ out_color = tab.color[vw];
   float* __restrict__ out_depth = tab.depth[vw];
   float* __restrict__ out_opacity = tab.opacity[vw];
-  float* __restrict__ final_T = (float*)(saved + L.o_final_T);
-  uint32_t* __restrict__ n_contrib = (uint32_t*)(saved + L.o_n_contrib);
+  float2* __restrict__ pix_state = (float2*)(saved + L.o_final_T);
   uint32_t* __restrict__ tile_maxc = (uint32_t*)(saved + L.o_tile_maxc);
   int32_t* __restrict__ n_touched = tab.n_touched[vw];
   extern __shared__ __attribute__((aligned(16))) char smem[];   // per wave: SORT_MAX keys (8 B) + 64 splats x 48 B
@@ -280,10 +287,11 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   if (lane == 0) tile_maxc[tile] = mx;
 
   float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;
+  const uint32_t tpix = (uint32_t)tile * 64u + (uint32_t)lane;
+  pix_state[tpix] = make_float2(T, __uint_as_float(last));       // (lanes outside the image: T = 1, no contributor)
+  uint32_t code = 0;
   if (inside) {
     const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
-    final_T[pix] = T;
-    n_contrib[pix] = last;
     const float I[3] = {C0 + T * bg[0], C1 + T * bg[1], C2 + T * bg[2]};
     if (out_color) {            // (a training iteration that only needs the loss passes no image buffers)
       out_color[pix] = I[0];
@@ -300,7 +308,6 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
       // scratch and rebuilds the same floats (16 -> 1 byte per pixel written here and read there).
       const float g[3] = {gt0, gt1, gt2};
       const bool m = (g[0] + g[1] + g[2]) > lc.thr;
-      uint32_t code = 0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float r = m ? (ea * I[c] + eb) - g[c] : 0.f;
@@ -315,9 +322,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
       const float rd = (gd > 0.01f) ? D - gd : 0.f;
       l_dep = fabsf(rd);
       code |= ((rd > 0.f) ? 1u : ((rd < 0.f) ? 2u : 0u)) << 6;
-      ((uint8_t*)lt.dimage[vw])[pix] = (uint8_t)code;
+      if (!code_bytes_tiled(L)) ((uint8_t*)lt.dimage[vw])[pix] = (uint8_t)code;
     }
   }
+  if (gt_image && code_bytes_tiled(L)) ((uint8_t*)lt.dimage[vw])[tpix] = (uint8_t)code;
   if (gt_image) {      // uniform per view
     wave_sum4(l_rgb, l_dep, l_da, l_db);
     if (lane == 0) ((LossPart*)lt.parts[vw])[tile] = {l_rgb, l_dep, l_da, l_db};
@@ -542,8 +550,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
   const uint32_t* __restrict__ point_list = (const uint32_t*)(saved + L.o_point_list);
   const GRec* __restrict__ grec = grec_of(saved, L);
-  const float* __restrict__ final_T = (const float*)(saved + L.o_final_T);
-  const uint32_t* __restrict__ n_contrib = (const uint32_t*)(saved + L.o_n_contrib);
+  const float2* __restrict__ pix_state = (const float2*)(saved + L.o_final_T);
   const uint32_t* __restrict__ tile_maxc = (const uint32_t*)(saved + L.o_tile_maxc);
   const float* __restrict__ dL_dcolor = tab.dL_dcolor[vw];
   const float* __restrict__ dL_ddepth = tab.dL_ddepth[vw];
@@ -560,20 +567,23 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   float pxA[4] = {0.f, 0.f, 0.f, 0.f}, pxB[3] = {1.f, 0.f, 0.f};
   {
     const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
-    if (px < W && py < H) {
-      const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
-      if (PACKED) {
-        const uint32_t code = ((const uint8_t*)dL_dcolor)[pix];
-        const float k_rgb = sg.w_rgb * (sg.exp_a[vw] ? __expf(sg.exp_a[vw][0]) : 1.f);
-        pxA[0] = sign_code(code, k_rgb); pxA[1] = sign_code(code >> 2, k_rgb); pxA[2] = sign_code(code >> 4, k_rgb);
-        pxA[3] = sign_code(code >> 6, sg.w_dep);
-      } else {
-        pxA[0] = dL_dcolor[pix]; pxA[1] = dL_dcolor[hw + pix]; pxA[2] = dL_dcolor[2 * hw + pix];
-        pxA[3] = dL_ddepth ? dL_ddepth[pix] : 0.f;
-      }
-      pxB[0] = final_T[pix];
-      pxB[2] = __int_as_float((int)n_contrib[pix]);
+    const bool inside = px < W && py < H;
+    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
+    const uint32_t tpix = (uint32_t)tile * 64u + (uint32_t)lane;
+    if (PACKED) {
+      uint32_t code = 0;
+      if (code_bytes_tiled(L)) code = ((const uint8_t*)dL_dcolor)[tpix];       // (outside the image: 0)
+      else if (inside) code = ((const uint8_t*)dL_dcolor)[pix];
+      const float k_rgb = sg.w_rgb * (sg.exp_a[vw] ? __expf(sg.exp_a[vw][0]) : 1.f);
+      pxA[0] = sign_code(code, k_rgb); pxA[1] = sign_code(code >> 2, k_rgb); pxA[2] = sign_code(code >> 4, k_rgb);
+      pxA[3] = sign_code(code >> 6, sg.w_dep);
+    } else if (inside) {
+      pxA[0] = dL_dcolor[pix]; pxA[1] = dL_dcolor[hw + pix]; pxA[2] = dL_dcolor[2 * hw + pix];
+      pxA[3] = dL_ddepth ? dL_ddepth[pix] : 0.f;
     }
+    const float2 ps = pix_state[tpix];                 // (outside the image the forward left T = 1, no contributor)
+    pxB[0] = ps.x;
+    pxB[2] = ps.y;
   }
   const uint2 rng = ranges[(size_t)tile * kRngStride];
   const int64_t begin = rng.x & ~kOverfull;

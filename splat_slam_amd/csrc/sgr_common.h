@@ -147,8 +147,8 @@ struct Layout {
     o_point_list = take(c * 4);
     o_ranges = take((size_t)ntiles * 8 * kRngStride);
     o_tile_maxc = take((size_t)ntiles * 4);
-    o_final_T = take(hw * 4);
-    o_n_contrib = take(hw * 4);
+    o_final_T = take((size_t)ntiles * 64 * 8);   // per pixel (final T, last contributor), TILE-major: a wave's 64 pixels are 512 contiguous bytes
+    o_n_contrib = take(16);                      // (folded into o_final_T)
     o_block_touched = take(nb * 4);
     o_block_vis = take(nb * 4);
     o_block_base_t = take(nb * 4);
