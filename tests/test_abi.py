@@ -43,6 +43,25 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(nat.SgrAdamGroup) == 4 * 8 + 8 + 8
 
 
+def test_workspace_sizes_cover_every_carved_array():
+    """sgr_saved_bytes / sgr_scratch_bytes are pure host functions of (N, H, W, capacity): lower bounds that follow from
+    the layout described in DESIGN.md section 2 (the tile-major per-pixel state needs whole 8x8 tiles, also for ragged
+    image sizes), monotone in every argument."""
+    from splat_slam_amd import _native as nat
+    lib = nat.lib()
+    for (n, h, w, cap) in [(1, 1, 1, 1), (1000, 17, 9, 500), (20000, 320, 640, 40000), (300000, 480, 640, 200000),
+                           (300001, 481, 643, 200001)]:
+        tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        saved, scratch = lib.sgr_saved_bytes(n, h, w, cap), lib.sgr_scratch_bytes(n, h, w, cap)
+        # saved: 64-B record + 3 index words per Gaussian, 4 B per pair, (T, last contributor) per pixel of whole tiles
+        assert saved >= 64 * n + 12 * n + 4 * cap + 8 * 64 * tiles
+        # scratch: forward keys (runs + one 64-entry bucket per tile) and, aliased, 48-B partials + 64-B records
+        assert scratch >= max(8 * cap + 8 * 64 * tiles, 48 * cap + 64 * n)
+        assert lib.sgr_saved_bytes(n + 256, h, w, cap) > saved and lib.sgr_saved_bytes(n, h + 8, w, cap) > saved
+        assert lib.sgr_saved_bytes(n, h, w, cap + 4096) > saved and lib.sgr_scratch_bytes(n, h, w, cap + 4096) > scratch
+        assert saved % 16 == 0 and scratch % 16 == 0
+
+
 def test_product_path_has_no_cpu_fallback_and_never_imports_the_oracle():
     import torch
     import pytest
