@@ -3,7 +3,8 @@ matrix helpers in /root/reference/thirdparty/gaussian_splatting/utils/graphics_u
 
 Same attribute names and conventions (W2C as R,T; transposed matrices; tau deltas; exposure a,b).  The reference
 re-inverts a 4x4 twice per property access (graphics_utils.py:41-45, camera_utils.py:94-108: 4 linalg.inv launches per
-render); here the three matrices are cached and rebuilt only by update_RT -- same values, no launches on the hot path.
+render); here the three matrices are computed the same way ONCE per update_RT and cached -- bit-identical values, no
+launches on the hot path.
 """
 import math
 
@@ -11,34 +12,32 @@ import torch
 from torch import nn
 
 
-def getWorld2View2(R, t):
-    """graphics_utils.py:33-46 with translate=0, scale=1 (the only way the reference calls it): Rt itself."""
-    Rt = torch.zeros((4, 4), device=R.device, dtype=torch.float32)
-    Rt[:3, :3] = R
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    return Rt
+def getWorld2View2(R, t, translate=None, scale=1.0):
+    """World-to-camera 4x4 of graphics_utils.py:33-46: assembled from (R, t), taken to camera-to-world space where the
+    camera centre may be shifted / scaled, and inverted back.  The reference only calls it with the defaults, where the
+    result is [R|t] up to the rounding of the two inversions -- which are performed (not short-circuited), so the
+    matrices equal the reference's bit for bit on the same device.  (Cached by Camera: no launches on the hot path.)"""
+    w2c = torch.eye(4, device=R.device, dtype=torch.float32)
+    w2c[:3, :3] = R
+    w2c[:3, 3] = t
+    c2w = torch.linalg.inv(w2c)
+    if translate is not None or scale != 1.0:
+        centre = c2w[:3, 3] if translate is None else c2w[:3, 3] + translate.to(R.device)
+        c2w[:3, 3] = centre * scale
+    return torch.linalg.inv(c2w)
 
 
 def getProjectionMatrix2(znear, zfar, cx, cy, fx, fy, W, H):
-    """graphics_utils.py:72-93."""
-    left = ((2 * cx - W) / W - 1.0) * W / 2.0
-    right = ((2 * cx - W) / W + 1.0) * W / 2.0
-    top = ((2 * cy - H) / H + 1.0) * H / 2.0
-    bottom = ((2 * cy - H) / H - 1.0) * H / 2.0
-    left = znear / fx * left
-    right = znear / fx * right
-    top = znear / fy * top
-    bottom = znear / fy * bottom
+    """Pinhole projection with principal-point offset (graphics_utils.py:72-93), row-major, w_clip = z_view.
+    The frustum edges on the near plane are those of the pixel rectangle [0, W] x [0, H] shifted by (cx, cy)."""
+    edge = lambda c, n, f, sign: znear / f * ((((2 * c - n) / n) + sign) * n / 2.0)
+    left, right = edge(cx, W, fx, -1.0), edge(cx, W, fx, 1.0)
+    bottom, top = edge(cy, H, fy, -1.0), edge(cy, H, fy, 1.0)
     P = torch.zeros(4, 4)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    P[0, 0], P[0, 2] = 2.0 * znear / (right - left), (right + left) / (right - left)
+    P[1, 1], P[1, 2] = 2.0 * znear / (top - bottom), (top + bottom) / (top - bottom)
+    P[2, 2], P[2, 3] = zfar / (zfar - znear), -(zfar * znear) / (zfar - znear)
+    P[3, 2] = 1.0
     return P
 
 
@@ -84,8 +83,7 @@ class Camera(nn.Module):
                 w2c = getWorld2View2(self.R, self.T)
                 view = w2c.transpose(0, 1).contiguous()
                 full = (view.unsqueeze(0).bmm(self.projection_matrix.unsqueeze(0))).squeeze(0).contiguous()
-                # camera centre = -R^T t  (== world_view_transform.inverse()[3, :3], camera_utils.py:106-108)
-                center = (-(self.R.transpose(0, 1) @ self.T)).contiguous()
+                center = torch.linalg.inv(view)[3, :3].contiguous()      # camera_utils.py:106-108
             self._cache = (view, full, center)
         return self._cache
 

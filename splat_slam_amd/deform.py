@@ -29,62 +29,58 @@ def quaternion_multiply(q1, q2):
     return torch.stack((w, x, y, z), dim=-1)
 
 
+def _rigid_delta(w2c_new, w2c_old):
+    """World-space motion of the points anchored to a keyframe whose pose went w2c_old -> w2c_new
+    (mapper.py:167,231: inv(inv(w2c_old) @ w2c_new)) = c2w_new @ w2c_old, and its rotation as a (w, x, y, z) quaternion."""
+    delta = torch.linalg.inv(torch.linalg.inv(w2c_old) @ w2c_new)
+    return delta, rotation_matrix_to_quaternion(delta.unsqueeze(0))
+
+
+def ray_rescale_factors(p_cam, K, depth_new, depth_old):
+    """Per-point factor along the old camera's ray (mapper.py:196-228): 1 + (d_new - d_old) / z at the pixel the point
+    projects to (truncated to integers, clamped to the image border); 1 where either depth map is empty there or the
+    factor would not be positive."""
+    h, w = depth_new.shape
+    uvw = p_cam @ K.T
+    u = (uvw[:, 0] / uvw[:, 2]).long().clamp(0, w - 1)
+    v = (uvw[:, 1] / uvw[:, 2]).long().clamp(0, h - 1)
+    d_new, d_old = depth_new[v, u], depth_old[v, u]
+    f = 1 + (d_new - d_old) / p_cam[:, 2]
+    keep = (d_new == 0) | (d_old == 0) | (f <= 0)
+    return torch.where(keep, torch.ones_like(f), f)
+
+
 @torch.no_grad()
 def update_mapping_points(gaussians, frame_idx, w2c, w2c_old, depth, depth_old, intrinsics, method=None):
-    """Moves (and, unless method == "rigid", depth-rescales) the Gaussians anchored to keyframe `frame_idx`.
-    Adam moments of the touched tensors are reset exactly like the reference (replace_tensor_to_optimizer)."""
-    frame_mask = gaussians.unique_kfIDs == frame_idx
-    if frame_mask.sum() == 0:
+    """Moves (and, unless method == "rigid", depth-rescales) the Gaussians anchored to keyframe `frame_idx`
+    (Mapper.update_mapping_points, mapper.py:154-255).  Adam moments of the touched tensors are reset exactly like the
+    reference (replace_tensor_to_optimizer).  Torch formulation: CPU models and the checker of sgr_deform_points."""
+    sel = gaussians.unique_kfIDs == frame_idx
+    if sel.sum() == 0:
         return
     dev = gaussians.get_xyz.device
     if dev.type == "cuda" and USE_HIP:
         return _update_mapping_points_hip(gaussians, frame_idx, w2c, w2c_old, depth, depth_old, intrinsics, method)
-    frame_mask = frame_mask.to(dev)
-    transformation = torch.linalg.inv(torch.linalg.inv(w2c_old) @ w2c)
-    if method == "rigid":
-        means = gaussians.get_xyz.detach()
-        ones = torch.ones(int(frame_mask.sum()), 1, device=dev).float()
-        pts4 = torch.cat((means[frame_mask], ones), dim=1)
-        means[frame_mask] = (transformation @ pts4.T).T[:, :3]
-        gaussians._xyz = gaussians.replace_tensor_to_optimizer(means, "xyz")["xyz"]
-        rots = gaussians.get_rotation.detach()
-        tq = rotation_matrix_to_quaternion(transformation.unsqueeze(0))
-        rots[frame_mask] = quaternion_multiply(tq.expand_as(rots[frame_mask]), rots[frame_mask])
-        gaussians._rotation = gaussians.replace_tensor_to_optimizer(rots, "rotation")["rotation"]
-        return
-    depth = depth.to(dev)
-    depth_old = depth_old.to(dev)
-    means = gaussians.get_xyz.detach()[frame_mask]
-    ones = torch.ones(means.shape[0], 1, device=dev).float()
-    pts4 = torch.cat((means, ones), dim=1)
-    pix = (intrinsics @ (w2c_old @ pts4.T)[:3, :]).T
-    pix[:, 0] /= pix[:, 2]
-    pix[:, 1] /= pix[:, 2]
-    pix = pix[:, :2].long()
-    height, width = depth.shape
-    pix[:, 0] = torch.clamp(pix[:, 0], min=0, max=width - 1)
-    pix[:, 1] = torch.clamp(pix[:, 1], min=0, max=height - 1)
-    d_new = depth[pix[:, 1], pix[:, 0]]
-    d_old = depth_old[pix[:, 1], pix[:, 0]]
-    means_cam = (w2c_old @ pts4.T).T[:, :3]
-    rescale = (1 + 1 / (means_cam[:, 2]) * (d_new - d_old)).unsqueeze(-1)
-    rescale[torch.logical_or(d_new == 0, d_old == 0)] = 1
-    rescale[rescale <= 0.0] = 1
-    means_cam = rescale.repeat(1, 3) * means_cam
-    pts4 = torch.cat((means_cam, ones), dim=1)
-    means = (torch.linalg.inv(w2c_old) @ pts4.T).T[:, :3]
-    pts4 = torch.cat((means, ones), dim=1)
-    means = (transformation @ pts4.T).T[:, :3]
-    global_means = gaussians.get_xyz.detach()
-    global_means[frame_mask] = means
-    gaussians._xyz = gaussians.replace_tensor_to_optimizer(global_means, "xyz")["xyz"]
-    rots = gaussians.get_rotation.detach()
-    tq = rotation_matrix_to_quaternion(transformation.unsqueeze(0))
-    rots[frame_mask] = quaternion_multiply(tq.expand_as(rots[frame_mask]), rots[frame_mask])
+    sel = sel.to(dev)
+    delta, dq = _rigid_delta(w2c, w2c_old)
+    xyz = gaussians.get_xyz.detach()
+    pts = xyz[sel]
+    log_f = None
+    if method != "rigid":
+        c2w_old = torch.linalg.inv(w2c_old)
+        p_cam = pts @ w2c_old[:3, :3].T + w2c_old[:3, 3]
+        f = ray_rescale_factors(p_cam, intrinsics, depth.to(dev), depth_old.to(dev))
+        pts = (f[:, None] * p_cam) @ c2w_old[:3, :3].T + c2w_old[:3, 3]
+        log_f = torch.log(f)[:, None]
+    xyz[sel] = pts @ delta[:3, :3].T + delta[:3, 3]
+    gaussians._xyz = gaussians.replace_tensor_to_optimizer(xyz, "xyz")["xyz"]
+    rots = gaussians.get_rotation.detach()               # activated (normalised) rotations are written back, :240-250
+    rots[sel] = quaternion_multiply(dq.expand_as(rots[sel]), rots[sel])
     gaussians._rotation = gaussians.replace_tensor_to_optimizer(rots, "rotation")["rotation"]
-    scales = gaussians._scaling.detach()
-    scales[frame_mask] = scales[frame_mask] + torch.log(rescale)
-    gaussians._scaling = gaussians.replace_tensor_to_optimizer(scales, "scaling")["scaling"]
+    if log_f is not None:
+        scales = gaussians._scaling.detach()
+        scales[sel] = scales[sel] + log_f
+        gaussians._scaling = gaussians.replace_tensor_to_optimizer(scales, "scaling")["scaling"]
 
 
 USE_HIP = True

@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Generates tests/golden/reference_loop.npz by running the REFERENCE's own mapping loops on the CPU:
-`Mapper.initialize_map`, `Mapper.map`, `Mapper.final_refine`'s iteration, `GaussianModel` (Adam groups, densify / prune
-with optimiser-state surgery, opacity reset), `render()`, `get_loss_mapping`, `Camera` -- imported unmodified from
-/root/reference -- against the oracle rasterizer injected under the module name `diff_gaussian_rasterization`
-(SURVEY.md 8c "reference's own callers run on CPU against an injected rasterizer").
+`Mapper.initialize_map`, `Mapper.map` (incl. the prune pass), `Mapper.final_refine` (src/mapper.py:617-710: its whole
+body, numpy RNG, exposure Adam), `Mapper.update_mapping_points` (src/mapper.py:154-255: depth-rescale and rigid branches
+with the Adam-moment reset), `GaussianModel` (Adam groups, densify / prune with optimiser-state surgery, opacity reset),
+`render()`, `get_loss_mapping`, `Camera` -- imported unmodified from /root/reference -- against the oracle rasterizer
+injected under the module name `diff_gaussian_rasterization` (SURVEY.md 8c "reference's own callers run on CPU against
+an injected rasterizer").
 
-What it pins: rows A6-A13 of SURVEY.md 8a (loss, loop order and quirks, Adam hyper-parameters, learning-rate schedule,
-densification statistics, clone / split / prune rules, RNG consumption) for splat_slam_amd.mapper / gaussian_model,
-which tests/test_loop_parity.py replays with the same injected oracle.  It does NOT pin the rasterizer itself.
+What it pins: rows A6-A13, A9 (final_refine) and A15 (update_mapping_points) of SURVEY.md 8a (loss, loop order and
+quirks, Adam hyper-parameters, learning-rate schedule, densification statistics, clone / split / prune rules, RNG
+consumption, map deformation) for splat_slam_amd.mapper / gaussian_model / deform, which tests/test_loop_parity.py
+replays with the same injected oracle (and tests/test_gpu_aux.py / test_gpu_fused.py on the HIP path).  It does NOT pin
+the rasterizer itself.
 
 Run in the build container only:   python tests/golden/make_golden_loop.py
 """
@@ -122,6 +126,36 @@ def scenario(seed=7, n=220):
     return dict(xyz=xyz, feats=feats, scales=scales, rots=rots, opac=opac), cams
 
 
+def deformation_cases(seed=23):
+    """Two moved keyframes (mapper.py:1021-1055 calls update_mapping_points once per moved keyframe): keyframe 1 through
+    the depth-rescale branch -- with zero depths (rigid fallback per point, :224-226) and a depth drop large enough to
+    make the rescale factor negative (:227-228) --, keyframe 2 through the rigid branch (:155-182)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def pose(ax, ang, t):
+        c, s_ = np.cos(ang), np.sin(ang)
+        R = {0: [[1, 0, 0], [0, c, -s_], [0, s_, c]], 1: [[c, 0, s_], [0, 1, 0], [-s_, 0, c]], 2: [[c, -s_, 0], [s_, c, 0], [0, 0, 1]]}[ax]
+        m = torch.eye(4)
+        m[:3, :3] = torch.tensor(R, dtype=torch.float32)
+        m[:3, 3] = torch.tensor(t, dtype=torch.float32)
+        return m
+    K = torch.tensor([[FX, 0.0, CX], [0.0, FY, CY], [0.0, 0.0, 1.0]])
+    d_old = 1.5 + 1.5 * torch.rand(H, W, generator=g)
+    d_new = d_old + 0.2 * torch.randn(H, W, generator=g)
+    d_new[2:4, 3:9] = 0.0                 # no new depth: those points only move rigidly
+    d_old[10:12, 15:20] = 0.0
+    d_new[6:9, 10:14] = d_old[6:9, 10:14] - 6.0      # rescale factor <= 0 -> reset to 1
+    return [dict(frame_idx=1, method=None, w2c_old=pose(1, 0.0, [0.0, 0.0, 0.0]), w2c_new=pose(1, 0.07, [0.03, -0.01, 0.02]),
+                 depth=d_new, depth_old=d_old, K=K),
+            dict(frame_idx=2, method="rigid", w2c_old=pose(0, 0.02, [0.05, 0.0, 0.04]), w2c_new=pose(2, -0.05, [0.0, 0.02, -0.03]),
+                 depth=d_new, depth_old=d_old, K=K)]
+
+
+def anchor_ids(n):
+    """Synthetic keyframe anchors for the deformation stage (the tiny scenario seeds everything from keyframe 0)."""
+    return (torch.arange(n) % 3).int()
+
+
 def keyframe_cases(seed=11):
     g = torch.Generator().manual_seed(seed)
     cases = []
@@ -157,6 +191,7 @@ def main():
     from thirdparty.monogs.utils.camera_utils import Camera
     import torch as T
     T.autograd.set_detect_anomaly(False)
+    T.set_num_threads(1)        # single-threaded reductions: the replay (same setting) is then comparable bit for bit on any host
     T.manual_seed(43)
     np.random.seed(43)
     init, camdata = scenario()
@@ -213,6 +248,36 @@ def main():
     Mapper.map(fake, fake.current_window, prune=True)
     out["prune_occ1"] = fake.occ_aware_visibility[1].numpy()
     out["prune_iteration_count"] = np.array(fake.iteration_count)
+
+    def put_adam(tag):
+        for g in gm.optimizer.param_groups:
+            st = gm.optimizer.state.get(g["params"][0])
+            if st is not None and g["name"] != "f_rest":
+                out[f"{tag}_m_{g['name']}"] = st["exp_avg"].numpy().copy()
+                out[f"{tag}_v_{g['name']}"] = st["exp_avg_sq"].numpy().copy()
+                out[f"{tag}_step_{g['name']}"] = np.array(float(st["step"]))
+
+    # 2b. final refinement (mapper.py:617-710, the whole method): no keyframes to re-read from the tracker (empty
+    # video_idxs), then 9 iterations of ONE numpy-random view + Adam + lr update + exposure Adam of the last window
+    from src.utils.Printer import FontColor  # noqa: F401  (imported by mapper.py itself)
+    fake.video_idxs, fake.keyframe_idxs = [], []
+    np.random.seed(1234)
+    Mapper.final_refine(fake, iters=9)
+    put("refine")
+    put_adam("refine")
+    out["refine_exposure"] = np.array([[cams[i].exposure_a.item(), cams[i].exposure_b.item()] for i in (0, 1, 2)])
+    # 2c. map deformation (mapper.py:154-255) for two moved keyframes, then 3 more refinement iterations so that the
+    # Adam-moment reset (replace_tensor_to_optimizer) is observable in the trajectory
+    fake.device = "cpu"
+    gm.unique_kfIDs = anchor_ids(gm.get_xyz.shape[0])
+    for ci, c in enumerate(deformation_cases()):
+        Mapper.update_mapping_points(fake, c["frame_idx"], c["w2c_new"].clone(), c["w2c_old"].clone(), c["depth"].clone(),
+                                     c["depth_old"].clone(), c["K"].clone(), method=c["method"])
+        put(f"deform{ci}")
+        put_adam(f"deform{ci}")
+    np.random.seed(4321)
+    Mapper.final_refine(fake, iters=3)
+    put("refine2")
     # 3. keyframe management on the consumers of n_touched (mapper.py:744-831): random masks / poses, fixed seed
     kf = keyframe_cases()
     fake.config["mapping"]["Training"].update(kf_translation=0.04, kf_min_translation=0.02, kf_overlap=0.95)

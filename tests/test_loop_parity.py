@@ -43,6 +43,12 @@ def oracle_as_rasterizer(monkeypatch):
         sys.modules.pop(m, None)
 
 
+# The loops, Adam(eps=1e-15) included, replay the reference's trajectory to the last bit when every matrix and reduction is
+# computed like the reference computes it (Camera re-inverts W2C twice like graphics_utils.py:41-45); 1e-6 only leaves
+# room for a different BLAS / libm build.  A sign flip of a rounding-noise gradient would show up as ~lr (1e-3).
+EXACT = 1e-6
+
+
 def _close(a, b, tol, what):
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
@@ -65,6 +71,8 @@ def test_loops_reproduce_the_reference_trajectory(oracle_as_rasterizer):
                    gaussian_reset=HYPER["gaussian_reset"], size_threshold=HYPER["size_threshold"]))
     torch.manual_seed(43)
     np.random.seed(43)
+    monkey_threads = torch.get_num_threads()
+    torch.set_num_threads(1)          # like the generator: reductions are then independent of the host's core count
     init, camdata = scenario()
     loop = mapper.MappingLoop(cfg, device="cpu", fused_loss=False)
     gm = loop.gaussians
@@ -93,14 +101,14 @@ def test_loops_reproduce_the_reference_trajectory(oracle_as_rasterizer):
     loop.viewpoints[0] = cams[0]
     loop.current_window = [0]
     loop.initialize_map(0, cams[0])
-    check("init", 2e-5)
+    check("init", EXACT)
     assert torch.equal(loop.occ_aware_visibility[0], torch.from_numpy(G["init_occ0"]))
     # 2. online mapping with exposure optimisers, a densify + prune (iteration 14), a non-visible opacity reset (15)
     loop.viewpoints = {0: cams[0], 1: cams[1], 2: cams[2]}
     loop.current_window = [2, 1]
     loop.build_keyframe_optimizers()
     loop.map(loop.current_window, iters=7)
-    check("map", 3e-4)      # Adam(eps=1e-15) turns 1e-7 differences (Camera builds W2C directly, the reference inverts twice) into fractions of one lr step
+    check("map", EXACT)
     exp = np.array([[cams[i].exposure_a.item(), cams[i].exposure_b.item()] for i in (0, 1, 2)])
     assert np.abs(exp - G["map_exposure"]).max() < 1e-6
     assert torch.equal(loop.occ_aware_visibility[2], torch.from_numpy(G["map_occ2"]))
@@ -110,6 +118,48 @@ def test_loops_reproduce_the_reference_trajectory(oracle_as_rasterizer):
     assert torch.equal(before, gm._xyz.detach())
     assert loop.iteration_count == int(G["prune_iteration_count"])
     assert torch.equal(loop.occ_aware_visibility[1], torch.from_numpy(G["prune_occ1"]))
+
+    def check_adam(tag, tol):
+        for g in gm.optimizer.param_groups:
+            if g["name"] == "f_rest":
+                continue
+            st = gm.optimizer.state[g["params"][0]]
+            _close(st["exp_avg"], G[f"{tag}_m_{g['name']}"], tol, f"{tag}/exp_avg/{g['name']}")
+            _close(st["exp_avg_sq"], G[f"{tag}_v_{g['name']}"], tol * tol, f"{tag}/exp_avg_sq/{g['name']}")
+            assert float(st["step"]) == float(G[f"{tag}_step_{g['name']}"]), (tag, g["name"])
+
+    # 4. final refinement (mapper.py:617-710): one numpy-random view per step, Adam, lr schedule, exposure Adam
+    np.random.seed(1234)
+    loop.final_refine(iters=9)
+    check("refine", EXACT)
+    check_adam("refine", EXACT)
+    exp = np.array([[cams[i].exposure_a.item(), cams[i].exposure_b.item()] for i in (0, 1, 2)])
+    assert np.abs(exp - G["refine_exposure"]).max() < 2e-6
+    assert exp[0].tolist() == [0.0, 0.0]             # keyframe 0 is not in the keyframe optimiser: never stepped
+    # 5. map deformation (mapper.py:154-255): depth-rescale branch for keyframe 1, rigid branch for keyframe 2
+    from make_golden_loop import anchor_ids, deformation_cases
+    from splat_slam_amd.deform import update_mapping_points
+    gm.unique_kfIDs = anchor_ids(gm.get_xyz.shape[0])
+    for ci, c in enumerate(deformation_cases()):
+        before = {k: getattr(gm, k).detach().clone() for k in ("_xyz", "_rotation", "_scaling")}
+        update_mapping_points(gm, c["frame_idx"], c["w2c_new"], c["w2c_old"], c["depth"], c["depth_old"], c["K"], method=c["method"])
+        moved = gm.unique_kfIDs == c["frame_idx"]
+        assert torch.equal(gm._xyz.detach()[~moved], before["_xyz"][~moved])
+        assert (gm._xyz.detach()[moved] - before["_xyz"][moved]).abs().max() > 1e-2
+        if c["method"] is None:      # the case is built to hit the three per-point outcomes of :218-228
+            ds = (gm._scaling.detach() - before["_scaling"])[moved][:, 0]
+            assert int((ds == 0).sum()) >= 5 and int((ds != 0).sum()) >= 50
+        else:
+            assert torch.equal(gm._scaling.detach(), before["_scaling"])
+        check(f"deform{ci}", 2e-6)     # (the torch formulation here composes the same maps in another order)
+        check_adam(f"deform{ci}", 1e-6)
+        for name in ("xyz", "rotation") + (("scaling",) if c["method"] is None else ()):
+            st = gm.optimizer.state[[g for g in gm.optimizer.param_groups if g["name"] == name][0]["params"][0]]
+            assert st["exp_avg"].abs().max() == 0 and st["exp_avg_sq"].abs().max() == 0       # moments reset, step kept
+    np.random.seed(4321)
+    loop.final_refine(iters=3)
+    check("refine2", 5e-6)
+    torch.set_num_threads(monkey_threads)
 
 
 def test_keyframe_management_matches_reference():
