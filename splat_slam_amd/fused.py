@@ -17,8 +17,12 @@ Numerically this is the same computation as the autograd loop (tests/test_gpu_fu
 trajectories; the run / step / fused-tail / multi-rank variants are bitwise identical among themselves); only the order
 of fp32 additions differs from autograd (views are accumulated in place).
 
-Deliberate deviation: the reference's `map(prune=True)` pass runs a full backward whose only
-lasting effect is a stale `.grad` on the exposure parameters; here the prune pass is forward-only.
+The reference's `map(prune=True)` pass (src/mapper.py:490-520) runs forward AND backward and returns before
+optimizer.step() / zero_grad(): its gradients stay on every parameter tensor that is not replaced before the next step
+(new keyframe points and map deformation replace the Gaussian tensors; exposure parameters and -- before final_refine
+-- f_dc / opacity keep them) and are added to the next iteration's.  The fused loop reproduces that: the prune pass
+leaves its gradients in the sinks, its isotropy term and exposure gradients are carried as "stale" state and consumed by
+the first optimiser step that follows (tests/test_gpu_fused.py replays the reference fixture through it).
 """
 import ctypes as C
 
@@ -69,24 +73,63 @@ class _ExposureSlab:
         self.step = z(capacity, dt=torch.int32)
         self.active = z(capacity, dt=torch.int32)
         self.ones = torch.ones(capacity, dtype=torch.int32, device=device)
-        self.rows = {}
+        self.stale = z(capacity, 2)        # exposure gradients a prune pass left behind (the reference never zeroes them)
+        self.stale_rows = set()
+        self.rows = {}                     # camera uid -> row
+        self.owner = {}                    # row -> the Camera object whose exposure_a/b are views of it
 
     def row_of(self, cam):
-        return self.rows.get(id(cam))
+        r = self.rows.get(cam.uid)
+        return r if r is not None and self.owner.get(r) is cam else None
 
     def attach(self, cam):
-        r = self.rows.get(id(cam))
+        r = self.row_of(cam)
         if r is None:
-            r = len(self.rows)
-            if r >= self.param.shape[0]:
-                raise RuntimeError("exposure slab full")
-            self.rows[id(cam)] = r
+            r = self.rows.get(cam.uid)             # a new Camera object with a known uid takes the row over
+            if r is None:
+                r = len(self.rows)
+                if r >= self.param.shape[0]:
+                    self._grow()
+                self.rows[cam.uid] = r
+            self.owner[r] = cam
+            self.stale[r] = 0
+            self.stale_rows.discard(r)
             with torch.no_grad():
                 self.param[r, 0] = cam.exposure_a.detach()[0]
                 self.param[r, 1] = cam.exposure_b.detach()[0]
             cam.exposure_a = torch.nn.Parameter(self.param[r, 0:1])     # views: the slab IS the parameter storage
             cam.exposure_b = torch.nn.Parameter(self.param[r, 1:2])
         return r
+
+    def _grow(self):
+        """Doubles the slab; Camera.exposure_a/b of attached cameras are re-bound to their rows."""
+        old = self.param.shape[0]
+        for name in ("param", "grad", "m", "v", "stale"):
+            t = getattr(self, name)
+            setattr(self, name, torch.cat([t, torch.zeros_like(t)]))
+        self.step = torch.cat([self.step, torch.zeros_like(self.step)])
+        self.active = torch.cat([self.active, torch.zeros_like(self.active)])
+        self.ones = torch.ones(2 * old, dtype=torch.int32, device=self.param.device)
+        for r, cam in self.owner.items():
+            cam.exposure_a = torch.nn.Parameter(self.param[r, 0:1])
+            cam.exposure_b = torch.nn.Parameter(self.param[r, 1:2])
+
+    def keep_stale(self, rows):
+        """A prune pass wrote its exposure gradients into grad[rows]; like `.grad` in the reference they are ADDED to."""
+        if rows:
+            idx = torch.tensor(sorted(set(rows)), dtype=torch.long, device=self.param.device)
+            self.stale[idx] += self.grad[idx]
+            self.stale_rows.update(int(r) for r in rows)
+
+    def add_stale(self, rows):
+        """grad[rows] += stale[rows] for the rows an optimiser is about to step (and then zero_grad's): returns those rows."""
+        hit = sorted(r for r in rows if r in self.stale_rows)
+        if hit:
+            idx = torch.tensor(hit, dtype=torch.long, device=self.param.device)
+            self.grad[idx] += self.stale[idx]
+            self.stale[idx] = 0
+            self.stale_rows.difference_update(hit)
+        return hit
 
     def reset(self, rows):
         self.active.zero_()
@@ -132,6 +175,14 @@ class FusedMappingLoop(MappingLoop):
         self._plan_obj = None
         self.world = 1              # ranks exchanging gradients (set by the multi-GPU driver together with dist_group)
         self.dist_group = None
+        self._acc_ids = None        # id() of the five parameter tensors the sinks belong to
+        self._stale_iso = 0.0       # isotropy weight whose gradient a prune pass left on the current `_scaling` tensor
+
+    def reset(self):
+        super().reset()
+        self._views, self._acc, self._acc_key, self._acc_ids, self._acc_clean = {}, None, None, None, True
+        self._exp, self._exp_rows, self._cap, self._stale_iso = None, [], 0, 0.0
+        self._plan_key = self._plan_obj = None
 
     # ------------------------------------------------------------------------------------------------ state
     def _all_reduce_sum(self, t):
@@ -144,8 +195,19 @@ class FusedMappingLoop(MappingLoop):
 
     def _ensure_state(self):
         gm = self.gaussians
-        key = (gm._xyz.data_ptr(), gm._xyz.shape[0])
-        if self._acc_key == key:
+        key = gm._xyz.shape[0]
+        ids = tuple(id(p) for p in (gm._xyz, gm._features_dc, gm._opacity, gm._scaling, gm._rotation))
+        if self._acc_key == key and self._acc_ids == ids:
+            return
+        if self._acc_key == key and self._acc is not None:
+            # same N, some tensors replaced (opacity reset, map deformation: replace_tensor_to_optimizer): the new
+            # Parameters have no .grad in the reference, i.e. whatever a prune pass left for THOSE groups is gone
+            for name, old, new in zip(_GROUPS, self._acc_ids, ids):
+                if old != new and not self._acc_clean:
+                    self._acc[name].zero_()
+                if old != new and name == "scaling":
+                    self._stale_iso = 0.0
+            self._acc_ids = ids
             return
         N, dev = gm._xyz.shape[0], self.device
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
@@ -156,8 +218,9 @@ class FusedMappingLoop(MappingLoop):
                      "opacity": flat[6 * N: 7 * N].view(N, 1), "scaling": flat[7 * N: 10 * N].view(N, 3),
                      "rotation": flat[10 * N: 14 * N].view(N, 4),
                      "act_scale": z(N, 3), "act_rot": z(N, 4), "act_opac": z(N, 1)}
-        self._acc_key = key
+        self._acc_key, self._acc_ids = key, ids
         self._acc_clean = True     # the gradient sinks are all-zero (every Adam step leaves them so)
+        self._stale_iso = 0.0      # (every tensor is new: nothing a prune pass left behind survives)
         self._views = {}           # N changed: per-camera buffers are re-made lazily
         self._cap = 0
         if gm.active_sh_degree != 0 or gm._features_rest.numel() != 0:
@@ -262,7 +325,7 @@ class FusedMappingLoop(MappingLoop):
         """The cached SgrMapView of a camera: pointers into its persistent buffers, sized for the shared capacity.
         images=False: loss + gradients only (the rendered colour / depth / opacity are not written to HBM)."""
         vb = self._view(cam)
-        key = (cam._version, self._cap, id(cam.exposure_a), id(cam.original_image), initialization,
+        key = (cam._version, self._cap, id(cam.exposure_a), id(cam.original_image), vb.gt_depth.data_ptr(), initialization,
                self.keyframe_optimizers is not None)
         if vb.mv is None:
             vb.mv = {}
@@ -459,6 +522,8 @@ class FusedMappingLoop(MappingLoop):
         """ONE host call: activate -> batched views (forward / loss / backward) -> Adam -> exposure Adam."""
         pl = self._plan()
         arr = self._views_array(cams, initialization)
+        if adam and not forward_only and "scaling" not in skip and self._stale_iso:
+            iso_weight, self._stale_iso = iso_weight + self._stale_iso, 0.0     # the prune pass's share rides in this step
         st = self._setup(pl, iso_weight, adam, skip, stats, forward_only, exposure)
         st.num_views, st.views = len(cams), arr
         if not activate:
@@ -554,12 +619,17 @@ class FusedMappingLoop(MappingLoop):
     def _exposure_step(self, cams, only_rendered=False):
         if self._exp is None or not self._exp_rows:
             pass
-        elif only_rendered:       # final_refine: torch's Adam only touches parameters that received a gradient
-            for cam in cams:
-                row = self._exp.row_of(cam)
-                if row in self._exp_rows:
-                    self._exp.step_rows(self.lib, row, 1, self._stream())
+        elif only_rendered:       # final_refine: torch's Adam only touches parameters that HAVE a gradient: the rendered
+            rows = {self._exp.row_of(cam) for cam in cams}        # camera and whatever a prune pass left a .grad on
+            rendered = [r for r in rows if r in self._exp_rows]
+            stale_only = [r for r in self._exp_rows if r in self._exp.stale_rows and r not in rows]
+            if stale_only:
+                self._exp.grad[torch.tensor(stale_only, dtype=torch.long, device=self.device)] = 0
+            self._exp.add_stale(self._exp_rows)
+            for row in sorted(set(rendered) | set(stale_only)):
+                self._exp.step_rows(self.lib, row, 1, self._stream())
         else:
+            self._exp.add_stale(self._exp_rows)
             self._exp.step_mask(self.lib, self._exp_rows, self._stream())
         if self.keyframe_optimizers is not None:
             for cam in cams:
@@ -663,7 +733,7 @@ class FusedMappingLoop(MappingLoop):
             it += 1
             # a span of regular iterations (no densification / opacity reset, no pose optimiser) is ONE host call
             n = 0
-            if not prune and not pose_opt and self.span_calls:
+            if not prune and not pose_opt and self.span_calls and not self._has_stale():
                 while it + n < iters and not self._is_special(self.iteration_count + n + 1):
                     n += 1
             if n > 0:
@@ -688,19 +758,29 @@ class FusedMappingLoop(MappingLoop):
                 continue
             self.iteration_count += 1
             self._ensure_state()
-            if prune:
-                self._step(viewpoint_stack, adam=False, forward_only=True)
-                self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
-                                             for kf, c in zip(current_window, viewpoint_stack)}
-                return False
             used = list(viewpoint_stack)
             for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2].tolist():
                 used.append(random_viewpoint_stack[cam_idx])
+            if prune:
+                # mapper.py:490-520: the whole iteration up to loss.backward(), then `return False` before the statistics,
+                # optimizer.step() and zero_grad(): the gradients stay where they are
+                self._step(used, adam=False, stats=False)
+                self._stale_iso += 10.0
+                if self._exp is not None:
+                    self._exp.keep_stale([r for r in (self._exp.row_of(c) for c in used) if r is not None])
+                self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
+                                             for kf, c in zip(current_window, viewpoint_stack)}
+                self.last_used = used
+                return False
             update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
             reset = (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian)
             special = update_gaussian or reset
             # regular iteration: everything in one host call; densify / reset iterations split around the torch-side surgery
-            self._step(used, iso_weight=10.0, adam=not special, exposure="none" if (special or pose_opt) else "window")
+            exp_stale = self._exp is not None and bool(self._exp.stale_rows)
+            self._step(used, iso_weight=10.0, adam=not special,
+                       exposure="none" if (special or pose_opt or exp_stale) else "window")
+            if exp_stale and not (special or pose_opt):
+                self._exposure_step(used)
             if special or pose_opt or it == iters - 1:
                 with torch.no_grad():
                     if it == iters - 1 or update_gaussian:
@@ -735,6 +815,10 @@ class FusedMappingLoop(MappingLoop):
             self._tick()
         return gaussian_split
 
+    def _has_stale(self):
+        """A prune pass left gradients behind that the next optimiser step must include (see the module docstring)."""
+        return (not self._acc_clean) or self._stale_iso != 0.0 or (self._exp is not None and bool(self._exp.stale_rows))
+
     def _is_special(self, count):
         update_gaussian = count % self.gaussian_update_every == self.gaussian_update_offset
         return update_gaussian or (count % self.gaussian_reset) == 0
@@ -747,6 +831,16 @@ class FusedMappingLoop(MappingLoop):
     def final_refine(self, iters=26000):
         stack = list(self.viewpoints.values())
         done = 0
+        while done < iters and self._has_stale():        # what the last prune pass left behind goes into this step
+            self.iteration_count += 1
+            self._ensure_state()
+            cam = stack[np.random.randint(0, len(stack))]
+            self._step([cam], adam=True, stats=False, exposure="none")
+            self._exposure_step([cam], only_rendered=True)
+            self.gaussians.update_learning_rate(self.iteration_count)
+            self.last_used = [cam]
+            self._tick()
+            done += 1
         while self.world == 1 and self.span_calls and done < iters:
             n = min(iters - done, 512)           # (the overflow check runs between chunks)
             self._ensure_state()

@@ -214,17 +214,13 @@ class GaussianModel:
     # ---- PLY checkpoint (gaussian_model.py:331-380, 397-486): one all-float32 `vertex` element, binary little endian,
     # property order x y z nx ny nz f_dc_* f_rest_* opacity scale_* rot_*  (what plyfile writes for that dtype list)
     def construct_list_of_attributes(self):
-        l = ["x", "y", "z", "nx", "ny", "nz"]
-        for i in range(self._features_dc.shape[1] * self._features_dc.shape[2]):
-            l.append("f_dc_{}".format(i))
-        for i in range(self._features_rest.shape[1] * self._features_rest.shape[2]):
-            l.append("f_rest_{}".format(i))
-        l.append("opacity")
-        for i in range(self._scaling.shape[1]):
-            l.append("scale_{}".format(i))
-        for i in range(self._rotation.shape[1]):
-            l.append("rot_{}".format(i))
-        return l
+        blocks = (("f_dc", self._features_dc.shape[1] * self._features_dc.shape[2]),
+                  ("f_rest", self._features_rest.shape[1] * self._features_rest.shape[2]),
+                  ("opacity", None), ("scale", self._scaling.shape[1]), ("rot", self._rotation.shape[1]))
+        names = ["x", "y", "z", "nx", "ny", "nz"]
+        for prefix, count in blocks:
+            names += [prefix] if count is None else [f"{prefix}_{i}" for i in range(count)]
+        return names
 
     def save_ply(self, path):
         import os
@@ -292,34 +288,33 @@ class GaussianModel:
             opacities_new[filter] = self.get_opacity[filter]
         self._opacity = self.replace_tensor_to_optimizer(opacities_new, "opacity")["opacity"]
 
-    # ---- optimiser surgery (gaussian_model.py:488-593)
-    def replace_tensor_to_optimizer(self, tensor, name):
-        optimizable_tensors = {}
+    # ---- optimiser surgery (gaussian_model.py:488-593).  Every map edit is the same operation on the Adam groups: the
+    # group's tensor becomes a fresh leaf Parameter, its two moments are transformed alongside, and the state dict (with
+    # its `step`) moves to the new Parameter -- which is also why the new tensor has no .grad until the next backward.
+    def _remap_groups(self, new_tensor, new_moment, only=None):
+        out = {}
         for group in self.optimizer.param_groups:
-            if group["name"] == name:
-                stored_state = self.optimizer.state.get(group["params"][0], None)
-                stored_state["exp_avg"] = torch.zeros_like(tensor)
-                stored_state["exp_avg_sq"] = torch.zeros_like(tensor)
-                del self.optimizer.state[group["params"][0]]
-                group["params"][0] = nn.Parameter(tensor.requires_grad_(True))
-                self.optimizer.state[group["params"][0]] = stored_state
-                optimizable_tensors[group["name"]] = group["params"][0]
-        return optimizable_tensors
+            name = group["name"]
+            if only is not None and name != only:
+                continue
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+            fresh = nn.Parameter(new_tensor(name, old).requires_grad_(True))
+            if state is not None:
+                state["exp_avg"] = new_moment(name, state["exp_avg"])
+                state["exp_avg_sq"] = new_moment(name, state["exp_avg_sq"])
+                self.optimizer.state[fresh] = state
+            group["params"][0] = fresh
+            out[name] = fresh
+        return out
+
+    def replace_tensor_to_optimizer(self, tensor, name):
+        """New values for one group, moments reset to zero (opacity resets, map deformation)."""
+        return self._remap_groups(lambda n, old: tensor, lambda n, m: torch.zeros_like(tensor), only=name)
 
     def _prune_optimizer(self, mask):
-        optimizable_tensors = {}
-        for group in self.optimizer.param_groups:
-            stored_state = self.optimizer.state.get(group["params"][0], None)
-            if stored_state is not None:
-                stored_state["exp_avg"] = stored_state["exp_avg"][mask]
-                stored_state["exp_avg_sq"] = stored_state["exp_avg_sq"][mask]
-                del self.optimizer.state[group["params"][0]]
-                group["params"][0] = nn.Parameter((group["params"][0][mask].requires_grad_(True)))
-                self.optimizer.state[group["params"][0]] = stored_state
-            else:
-                group["params"][0] = nn.Parameter(group["params"][0][mask].requires_grad_(True))
-            optimizable_tensors[group["name"]] = group["params"][0]
-        return optimizable_tensors
+        """Rows where `mask` is True survive, in every group."""
+        return self._remap_groups(lambda n, old: old[mask], lambda n, m: m[mask])
 
     def _adopt(self, t):
         self._xyz, self._features_dc, self._features_rest = t["xyz"], t["f_dc"], t["f_rest"]
@@ -411,21 +406,10 @@ class GaussianModel:
         self.n_obs = self.n_obs[valid]
 
     def cat_tensors_to_optimizer(self, tensors_dict):
-        optimizable_tensors = {}
-        for group in self.optimizer.param_groups:
-            assert len(group["params"]) == 1
-            ext = tensors_dict[group["name"]]
-            stored_state = self.optimizer.state.get(group["params"][0], None)
-            if stored_state is not None:
-                stored_state["exp_avg"] = torch.cat((stored_state["exp_avg"], torch.zeros_like(ext)), dim=0)
-                stored_state["exp_avg_sq"] = torch.cat((stored_state["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
-                del self.optimizer.state[group["params"][0]]
-                group["params"][0] = nn.Parameter(torch.cat((group["params"][0], ext), dim=0).requires_grad_(True))
-                self.optimizer.state[group["params"][0]] = stored_state
-            else:
-                group["params"][0] = nn.Parameter(torch.cat((group["params"][0], ext), dim=0).requires_grad_(True))
-            optimizable_tensors[group["name"]] = group["params"][0]
-        return optimizable_tensors
+        """Appends rows to every group; the new rows start with zero moments."""
+        assert all(len(g["params"]) == 1 for g in self.optimizer.param_groups)
+        return self._remap_groups(lambda n, old: torch.cat((old, tensors_dict[n]), dim=0),
+                                  lambda n, m: torch.cat((m, torch.zeros_like(tensors_dict[n])), dim=0))
 
     def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling,
                               new_rotation, new_kf_ids=None, new_n_obs=None):
@@ -486,16 +470,19 @@ class GaussianModel:
                                    new_kf_ids=self.unique_kfIDs[selected], new_n_obs=self.n_obs[selected])
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
-        grads = self.xyz_gradient_accum / self.denom
-        grads[grads.isnan()] = 0.0
-        self.densify_and_clone(grads, max_grad, extent)
-        self.densify_and_split(grads, max_grad, extent)
-        prune_mask = (self.get_opacity < min_opacity).squeeze()
+        """Clone small / split large Gaussians whose mean screen-space gradient reached `max_grad`, then drop the
+        near-transparent ones and -- when a screen-size limit is given -- those that got too large on screen (radius) or in
+        the world (largest axis > 10 % of the extent); gaussian_model.py:721-736."""
+        mean_grad = self.xyz_gradient_accum / self.denom
+        mean_grad = torch.where(mean_grad.isnan(), torch.zeros_like(mean_grad), mean_grad)      # never observed: 0 / 0
+        self.densify_and_clone(mean_grad, max_grad, extent)
+        self.densify_and_split(mean_grad, max_grad, extent)
+        doomed = (self.get_opacity < min_opacity).squeeze()
         if max_screen_size:
-            big_points_vs = self.max_radii2D > max_screen_size
-            big_points_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
-            prune_mask = torch.logical_or(torch.logical_or(prune_mask, big_points_vs), big_points_ws)
-        self.prune_points(prune_mask)
+            too_wide_on_screen = self.max_radii2D > max_screen_size
+            too_wide_in_world = self.get_scaling.max(dim=1).values > 0.1 * extent
+            doomed = doomed | too_wide_on_screen | too_wide_in_world
+        self.prune_points(doomed)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)

@@ -35,17 +35,15 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
 
 
 def get_median_depth(depth, opacity=None, mask=None, return_std=False):
-    depth = depth.detach().clone()
-    opacity = opacity.detach()
-    valid = depth > 0
-    if opacity is not None:
-        valid = torch.logical_and(valid, opacity > 0.95)
-    if mask is not None:
-        valid = torch.logical_and(valid, mask)
-    valid_depth = depth[valid]
-    if return_std:
-        return valid_depth.median(), valid_depth.std(), valid
-    return valid_depth.median()
+    """Median (and optionally std) of the rendered depth over pixels that are covered (depth > 0), nearly opaque
+    (opacity > 0.95) and inside `mask` -- slam_utils.py:108-119; scales the keyframe baseline test (mapper.py:984)."""
+    depth = depth.detach()
+    use = depth > 0
+    for extra in ((opacity.detach() > 0.95) if opacity is not None else None, mask):
+        if extra is not None:
+            use = use & extra
+    picked = depth[use]
+    return (picked.median(), picked.std(), use) if return_std else picked.median()
 
 
 class _FusedMappingLoss(torch.autograd.Function):

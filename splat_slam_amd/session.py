@@ -32,55 +32,51 @@ class MappingSession:
         self.median_depth = 1.0
         self.move_points = self.config["mapping"].get("move_points", True)
 
-    # ---- mapper.py:744-772
-    def is_keyframe(self, cur_frame_idx, last_keyframe_idx, cur_vis, occ_aware_visibility):
-        tr = self.config["mapping"]["Training"]
-        curr_frame, last_kf = self.cameras[cur_frame_idx], self.cameras[last_keyframe_idx]
-        pose_CW = getWorld2View2(curr_frame.R, curr_frame.T)
-        last_kf_WC = torch.linalg.inv(getWorld2View2(last_kf.R, last_kf.T))
-        dist = torch.norm((pose_CW @ last_kf_WC)[0:3, 3])
-        dist_check = dist > tr["kf_translation"] * self.median_depth
-        dist_check2 = dist > tr["kf_min_translation"] * self.median_depth
-        union = torch.logical_or(cur_vis, occ_aware_visibility[last_keyframe_idx]).count_nonzero()
-        intersection = torch.logical_and(cur_vis, occ_aware_visibility[last_keyframe_idx]).count_nonzero()
-        point_ratio_2 = intersection / union
-        return bool((point_ratio_2 < tr["kf_overlap"] and dist_check2) or dist_check)
+    # ---- keyframe management on the consumers of n_touched (mapper.py:744-831), batched over the window
+    def _w2c(self, idxs):
+        return torch.stack([getWorld2View2(self.cameras[k].R, self.cameras[k].T) for k in idxs])
 
-    # ---- mapper.py:774-831
+    @staticmethod
+    def _shared(vis_a, vis_b):
+        return torch.logical_and(vis_a, vis_b).count_nonzero()
+
+    def is_keyframe(self, cur_frame_idx, last_keyframe_idx, cur_vis, occ_aware_visibility):
+        """New keyframe if the camera moved far (relative to the median depth), or moved a little AND sees a set of
+        Gaussians whose IoU with the last keyframe's dropped below kf_overlap (mapper.py:744-772)."""
+        tr = self.config["mapping"]["Training"]
+        cur, last = self._w2c([cur_frame_idx, last_keyframe_idx])
+        baseline = torch.norm((cur @ torch.linalg.inv(last))[:3, 3])
+        last_vis = occ_aware_visibility[last_keyframe_idx]
+        iou = self._shared(cur_vis, last_vis) / torch.logical_or(cur_vis, last_vis).count_nonzero()
+        far = baseline > tr["kf_translation"] * self.median_depth
+        moved = baseline > tr["kf_min_translation"] * self.median_depth
+        return bool(far or (moved and iou < tr["kf_overlap"]))
+
     def add_to_window(self, cur_frame_idx, cur_vis, occ_aware_visibility, window):
-        N_dont_touch = 2
+        """Pushes the new keyframe in front; the two newest entries are never evicted.  First the OLDEST window entry whose
+        overlap coefficient (Szymkiewicz-Simpson) with the new frame is <= kf_cutoff goes; if the window is still too long,
+        the entry that is most redundant -- sqrt(distance to the new frame) * sum of inverse distances to the others --
+        goes (mapper.py:774-831)."""
+        keep_newest = 2
         window = [cur_frame_idx] + window
-        curr_frame = self.cameras[cur_frame_idx]
-        to_remove, removed_frame = [], None
         cut_off = self.config["mapping"]["Training"].get("kf_cutoff", 0.4)
-        for i in range(N_dont_touch, len(window)):
-            kf_idx = window[i]
-            intersection = torch.logical_and(cur_vis, occ_aware_visibility[kf_idx]).count_nonzero()
-            denom = min(cur_vis.count_nonzero(), occ_aware_visibility[kf_idx].count_nonzero())
-            if intersection / denom <= cut_off:
-                to_remove.append(kf_idx)
-        if to_remove:
-            window.remove(to_remove[-1])
-            removed_frame = to_remove[-1]
-        kf_0_WC = torch.linalg.inv(getWorld2View2(curr_frame.R, curr_frame.T))
+        removed_frame = None
+        n_cur = cur_vis.count_nonzero()
+        low_overlap = [k for k in window[keep_newest:]
+                       if self._shared(cur_vis, occ_aware_visibility[k]) / min(n_cur, occ_aware_visibility[k].count_nonzero()) <= cut_off]
+        if low_overlap:
+            removed_frame = low_overlap[-1]
+            window.remove(removed_frame)
         if len(window) > self.loop.window_size:
-            inv_dist = []
-            for i in range(N_dont_touch, len(window)):
-                inv_dists = []
-                kf_i = self.cameras[window[i]]
-                kf_i_CW = getWorld2View2(kf_i.R, kf_i.T)
-                for j in range(N_dont_touch, len(window)):
-                    if i == j:
-                        continue
-                    kf_j = self.cameras[window[j]]
-                    kf_j_WC = torch.linalg.inv(getWorld2View2(kf_j.R, kf_j.T))
-                    T_CiCj = kf_i_CW @ kf_j_WC
-                    inv_dists.append(1.0 / (torch.norm(T_CiCj[0:3, 3]) + 1e-6).item())
-                T_CiC0 = kf_i_CW @ kf_0_WC
-                k = torch.sqrt(torch.norm(T_CiC0[0:3, 3])).item()
-                inv_dist.append(k * sum(inv_dists))
-            idx = int(np.argmax(inv_dist))
-            removed_frame = window[N_dont_touch + idx]
+            cand = window[keep_newest:]
+            w2c = self._w2c(cand)
+            c2w = torch.linalg.inv(w2c)
+            pair = (w2c[:, None] @ c2w[None, :])[..., :3, 3].norm(dim=-1)            # |t| of T_CiCj, [n, n]
+            inv = (1.0 / (pair + 1e-6)).double()
+            inv.fill_diagonal_(0.0)
+            cur_c2w = torch.linalg.inv(self._w2c([cur_frame_idx])[0])
+            to_cur = (w2c @ cur_c2w)[:, :3, 3].norm(dim=-1).sqrt().double()
+            removed_frame = cand[int(torch.argmax(to_cur * inv.sum(dim=1)))]
             window.remove(removed_frame)
         return window, removed_frame
 

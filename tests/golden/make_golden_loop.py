@@ -226,6 +226,14 @@ def main():
         out[f"{tag}_iteration_count"] = np.array(fake.iteration_count)
         out[f"{tag}_xyz_lr"] = np.array([g["lr"] for g in gm.optimizer.param_groups if g["name"] == "xyz"][0])
 
+    def put_adam(tag):
+        for g in gm.optimizer.param_groups:
+            st = gm.optimizer.state.get(g["params"][0])
+            if st is not None and g["name"] != "f_rest":
+                out[f"{tag}_m_{g['name']}"] = st["exp_avg"].numpy().copy()
+                out[f"{tag}_v_{g['name']}"] = st["exp_avg_sq"].numpy().copy()
+                out[f"{tag}_step_{g['name']}"] = np.array(float(st["step"]))
+
     # 1. initialize_map on keyframe 0 (densify at it 0,5,10; opacity reset at iteration_count 3)
     fake.viewpoints[0] = cams[0]
     fake.current_window = [0]
@@ -243,26 +251,30 @@ def main():
     fake.keyframe_optimizers = T.optim.Adam(opt_params)
     Mapper.map(fake, fake.current_window, iters=7)
     put("map")
+    put_adam("map")
+    # keyframe (exposure) optimiser state, rows = cameras 0..2, columns = (a, b); camera 0 is not in the optimiser
+    kst = np.zeros((3, 2, 3))
+    for g in fake.keyframe_optimizers.param_groups:
+        st = fake.keyframe_optimizers.state[g["params"][0]]
+        kind, idx = g["name"].rsplit("_", 1)
+        kst[int(idx), 0 if kind == "exposure_a" else 1] = [float(st["exp_avg"]), float(st["exp_avg_sq"]), float(st["step"])]
+    out["map_exposure_adam"] = kst
     out["map_exposure"] = np.array([[cams[i].exposure_a.item(), cams[i].exposure_b.item()] for i in (0, 1, 2)])
     out["map_occ2"] = fake.occ_aware_visibility[2].numpy()
     Mapper.map(fake, fake.current_window, prune=True)
     out["prune_occ1"] = fake.occ_aware_visibility[1].numpy()
     out["prune_iteration_count"] = np.array(fake.iteration_count)
 
-    def put_adam(tag):
-        for g in gm.optimizer.param_groups:
-            st = gm.optimizer.state.get(g["params"][0])
-            if st is not None and g["name"] != "f_rest":
-                out[f"{tag}_m_{g['name']}"] = st["exp_avg"].numpy().copy()
-                out[f"{tag}_v_{g['name']}"] = st["exp_avg_sq"].numpy().copy()
-                out[f"{tag}_step_{g['name']}"] = np.array(float(st["step"]))
-
     # 2b. final refinement (mapper.py:617-710, the whole method): no keyframes to re-read from the tracker (empty
     # video_idxs), then 9 iterations of ONE numpy-random view + Adam + lr update + exposure Adam of the last window
     from src.utils.Printer import FontColor  # noqa: F401  (imported by mapper.py itself)
     fake.video_idxs, fake.keyframe_idxs = [], []
     np.random.seed(1234)
-    Mapper.final_refine(fake, iters=9)
+    Mapper.final_refine(fake, iters=1)       # the step that also carries what the prune pass left in every .grad
+    put("refine1")
+    put_adam("refine1")
+    out["refine1_exposure"] = np.array([[cams[i].exposure_a.item(), cams[i].exposure_b.item()] for i in (0, 1, 2)])
+    Mapper.final_refine(fake, iters=8)
     put("refine")
     put_adam("refine")
     out["refine_exposure"] = np.array([[cams[i].exposure_a.item(), cams[i].exposure_b.item()] for i in (0, 1, 2)])

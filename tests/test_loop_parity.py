@@ -130,7 +130,10 @@ def test_loops_reproduce_the_reference_trajectory(oracle_as_rasterizer):
 
     # 4. final refinement (mapper.py:617-710): one numpy-random view per step, Adam, lr schedule, exposure Adam
     np.random.seed(1234)
-    loop.final_refine(iters=9)
+    loop.final_refine(iters=1)      # includes the gradients the prune pass above left on every parameter (no zero_grad there)
+    check("refine1", EXACT)
+    check_adam("refine1", EXACT)
+    loop.final_refine(iters=8)
     check("refine", EXACT)
     check_adam("refine", EXACT)
     exp = np.array([[cams[i].exposure_a.item(), cams[i].exposure_b.item()] for i in (0, 1, 2)])
