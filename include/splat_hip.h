@@ -28,7 +28,8 @@
  *   sgr_keep_list,
  *   sgr_gather_rows        -> prune_points / _prune_optimizer and the row selects of densify_and_clone,
  *                             thirdparty/gaussian_splatting/scene/gaussian_model.py:519-557, 690-719
- *   sgr_query*, sgr_profile_* -> (no reference counterpart) capacity protocol, work counters, per-kernel HIP-event timing
+ *   sgr_query*, sgr_profile_*,
+ *   sgr_set_option         -> (no reference counterpart) capacity protocol, work counters, per-kernel HIP-event timing, options
  *   sknn_dist2             -> simple_knn._C.distCUDA2, thirdparty/gaussian_splatting/scene/gaussian_model.py:18,194-200
  *   se3_*                  -> lietorch SE3 ops used on the mapping path, thirdparty/glorie_slam/depth_video.py:327-330
  *                             (SE3(pose).inv().matrix()), and the tau convention of
@@ -52,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 5
+#define SGR_ABI_VERSION 6
 
 typedef enum SgrStatus {
   SGR_OK = 0,
@@ -169,13 +170,28 @@ int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_h
  *   stats[3] = number of non-empty 8x8 tiles */
 int sgr_query_stats(const SgrWorkspace* ws, int32_t num_gaussians, int32_t image_height, int32_t image_width,
                     const int32_t* radii, int64_t stats_host[4], void* stream);
+/* The fp32 view-space depth of every Gaussian with radii > 0 as the forward computed it (0 elsewhere) -- the bit pattern
+ * that orders the splats of a tile.  Parity tooling: lets a comparison break depth near-ties (equal to the last ulp) the way
+ * this forward did.  depth_out: device [N]. */
+int sgr_query_depth_keys(const SgrWorkspace* ws, int32_t num_gaussians, int32_t image_height, int32_t image_width,
+                         const int32_t* radii, float* depth_out, void* stream);
 /* Histogram of the per-tile list lengths the blend kernels walk (same synchronous, accounting-only use):
  * bins 0, 1-4, 5-8, 9-16, 17-32, 33-64, 65-256, >256 splats. */
 int sgr_query_list_histogram(const SgrWorkspace* ws, int32_t num_gaussians, int32_t image_height, int32_t image_width,
                              int64_t hist_host[8], void* stream);
 
+/* Run-time options of the library (process-wide; no reference counterpart).
+ *   SGR_OPT_FUSED_BLEND (default 1): sgr_map_views / sgr_map_step / sgr_map_run composite a tile, evaluate the mapping loss
+ *     and run the tile's backward in ONE kernel (the same wave, pixel state in registers).  0: the two halves run as the
+ *     separate kernels sgr_forward / sgr_backward use (bitwise identical results) -- for timing the halves on their own. */
+#define SGR_OPT_FUSED_BLEND 0
+#define SGR_OPT_COUNT 1
+int sgr_set_option(int32_t option, int32_t value);
+int sgr_get_option(int32_t option);
+
 /* Per-kernel HIP-event timing.  kind: 0 preprocess_fwd (+ per-tile pair counting), 1 tile_scan, 2 scatter,
- * 3/4/6 unused, 5 blend_fwd (+ in-wave tile sort), 7 blend_bwd, 8 preprocess_bwd (+ pose reduce).  sgr_profile_enable(mask) arms event pairs around the kinds whose
+ * 3 fused tile kernel (blend forward + loss + blend backward), 4/6 unused, 5 blend_fwd (+ in-wave tile sort), 7 blend_bwd,
+ * 8 preprocess_bwd (+ pose reduce).  sgr_profile_enable(mask) arms event pairs around the kinds whose
  * bit is set (0 disarms); sgr_profile_read() synchronises, returns accumulated milliseconds and launch counts per
  * kind since the last read, and resets them. Events are recorded on the stream the kernel is launched on. */
 #define SGR_PROFILE_KINDS 9

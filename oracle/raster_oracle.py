@@ -240,8 +240,13 @@ def preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotatio
     return Preprocessed(visible, radii, xy, tz, conic, opacities.reshape(N), rgb, rect)
 
 
-def build_tile_lists(pp: Preprocessed, H: int, W: int):
-    """(tile, depth, idx)-ordered duplication list: returns (tile_ids[R], gauss_ids[R]) sorted."""
+def build_tile_lists(pp: Preprocessed, H: int, W: int, depth_sort_key=None):
+    """(tile, depth, idx)-ordered duplication list: returns (tile_ids[R], gauss_ids[R]) sorted.
+
+    depth_sort_key (optional, fp32 [N]): the sort key of upstream is the fp32 BIT PATTERN of the view-space depth as the
+    kernel computed it.  Two Gaussians whose depths agree to the last ulp or two are therefore ordered by fp32 rounding;
+    a comparison against another implementation can hand that implementation's fp32 depths in here so that such near
+    ties are broken the same way (the caller checks that the keys equal this oracle's depths to a few ulp)."""
     gx = (W + TILE - 1) // TILE
     vis = torch.nonzero(pp.visible).flatten()
     if vis.numel() == 0:
@@ -259,7 +264,7 @@ def build_tile_lists(pp: Preprocessed, H: int, W: int):
     tile = ty * gx + tx
     gid = vis[owner]
     # stable sort by depth (fp32 bit pattern, like the upstream key), then stable by tile
-    dkey = pp.depth.detach().to(torch.float32)[gid]
+    dkey = (pp.depth.detach().to(torch.float32) if depth_sort_key is None else depth_sort_key.to(torch.float32))[gid]
     o1 = torch.argsort(dkey, stable=True)
     tile, gid = tile[o1], gid[o1]
     o2 = torch.argsort(tile, stable=True)
@@ -323,7 +328,7 @@ def blend(pp: Preprocessed, tile_ids, gauss_ids, s: OracleSettings, dt):
 
 
 def rasterize(means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
-              rotations=None, cov3D_precomp=None, theta=None, rho=None, *, settings: OracleSettings):
+              rotations=None, cov3D_precomp=None, theta=None, rho=None, *, settings: OracleSettings, depth_sort_key=None):
     """Oracle for GaussianRasterizer.forward (call site gaussian_renderer/__init__.py:130-141).
 
     Returns (color[3,H,W], radii int32[N], depth[1,H,W], opacity[1,H,W], n_touched int32[N]).
@@ -331,7 +336,7 @@ def rasterize(means3D, means2D, opacities, shs=None, colors_precomp=None, scales
     dt = means3D.dtype
     pp = preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
                     cov3D_precomp, theta, rho, settings)
-    tile_ids, gauss_ids = build_tile_lists(pp, int(settings.image_height), int(settings.image_width))
+    tile_ids, gauss_ids = build_tile_lists(pp, int(settings.image_height), int(settings.image_width), depth_sort_key)
     color, depth, opac, n_touched = blend(pp, tile_ids, gauss_ids, settings, dt)
     return color, pp.radii, depth, opac, n_touched
 

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsplat_hip.so")
 
+SGR_OPT_FUSED_BLEND = 0
 SGR_OK, SGR_ERR_INVALID, SGR_ERR_WORKSPACE, SGR_ERR_CAPACITY, SGR_ERR_HIP = 0, -1, -2, -3, -4
 
 _fp = C.c_void_p
@@ -97,7 +98,10 @@ SIGNATURES = {
                                C.POINTER(SgrGradInputs), C.POINTER(SgrWorkspace), _fp]),
     "sgr_query": (C.c_int, [_fp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _fp]),
     "sgr_query_stats": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(C.c_int64), _fp]),
+    "sgr_query_depth_keys": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp]),
     "sgr_query_list_histogram": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _fp]),
+    "sgr_set_option": (C.c_int, [C.c_int32, C.c_int32]),
+    "sgr_get_option": (C.c_int, [C.c_int32]),
     "sgr_profile_enable": (C.c_int, [C.c_uint32]),
     "sgr_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "sgr_mapping_loss": (C.c_int, [C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float,
@@ -147,7 +151,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.sgr_abi_version() != 5:
+        if h.sgr_abi_version() != 6:
             raise ImportError("libsplat_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -20,6 +20,10 @@ void launch_binning(const ViewTab&, int, const LOff&, hipStream_t);
 void launch_zero_heads(const ViewTab&, int, const LOff&, size_t, hipStream_t);
 void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
 void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
+void launch_blend_fused(const ViewTab&, int, const LOff&, const float*, const LossTab&, const LossCoef&, hipStream_t);
+
+// run-time options (sgr_set_option)
+static int g_opt[SGR_OPT_COUNT] = {1};
 
 static thread_local char g_err[512] = "";
 int set_error(int code, const char* fmt, ...) {
@@ -103,6 +107,12 @@ __global__ void __launch_bounds__(256) hist_kernel(int ntiles, const uint2* __re
   }
 }
 
+
+__global__ void __launch_bounds__(256) depth_keys_kernel(int N, const GRec* __restrict__ grec, const int32_t* __restrict__ radii,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[i] = radii[i] > 0 ? grec[i].depth : 0.f;
+}
 
 static int check_settings(const SgrSettings* s, const SgrInputs* in) {
   const int N = s->num_gaussians, H = s->image_height, W = s->image_width;
@@ -313,7 +323,11 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
     // the mapping loss rides in the compositing epilogue (no second pass over the images); only its tiny fixed-order
     // reduction is a separate launch
     LossCoef lc = {alpha / (3.f * (float)HW), (1.f - alpha) / (float)HW, rgb_boundary_threshold};
-    launch_blend_fwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
+    // forward, loss and backward of a tile run in the same wave (one launch) unless the option is off (profiling the two
+    // halves separately, bitwise A/B tests)
+    const bool fused_blend = g_opt[SGR_OPT_FUSED_BLEND] != 0;
+    if (fused_blend) launch_blend_fused(tab, nv, d, f.settings.bg, lt, lc, st);
+    else launch_blend_fwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
     const bool fuse = fused && num_views <= kMaxViews;
     if (fuse) {        // the loss sums (and the exposure step that consumes them) ride in the optimiser launch
       fused->tail_views = nv; fused->tail_nparts = L.ntiles;
@@ -324,7 +338,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
     } else {
       launch_mapping_loss_final(lt, nv, HW, L.ntiles, alpha, st);
     }
-    launch_blend_bwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
+    if (!fused_blend) launch_blend_bwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
     launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, fuse ? fused : nullptr, st);
     if (fuse && fused_done) *fused_done = true;
   }
@@ -501,6 +515,16 @@ int sgr_query_stats(const SgrWorkspace* ws, int32_t N, int32_t H, int32_t W, con
   return SGR_OK;
 }
 
+int sgr_query_depth_keys(const SgrWorkspace* ws, int32_t N, int32_t H, int32_t W, const int32_t* radii, float* depth_out, void* stream) {
+  if (!ws || !ws->saved || !radii || !depth_out) return set_error(SGR_ERR_INVALID, "null argument");
+  Layout L = make_layout(N, H, W, ws->capacity);
+  if (N > 0)
+    hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N,
+                       (const GRec*)((const char*)ws->saved + L.o_grec), radii, depth_out);
+  HIP_TRY(hipGetLastError());
+  return SGR_OK;
+}
+
 int sgr_query_list_histogram(const SgrWorkspace* ws, int32_t N, int32_t H, int32_t W, int64_t hist_host[8], void* stream) {
   if (!ws || !ws->saved || !ws->scratch || !hist_host) return set_error(SGR_ERR_INVALID, "null argument");
   Layout L = make_layout(N, H, W, ws->capacity);
@@ -515,6 +539,14 @@ int sgr_query_list_histogram(const SgrWorkspace* ws, int32_t N, int32_t H, int32
   for (int i = 0; i < 8; ++i) hist_host[i] = (int64_t)h[i];
   return SGR_OK;
 }
+
+int sgr_set_option(int32_t option, int32_t value) {
+  if (option < 0 || option >= SGR_OPT_COUNT) return set_error(SGR_ERR_INVALID, "unknown option %d", option);
+  g_opt[option] = value;
+  return SGR_OK;
+}
+
+int sgr_get_option(int32_t option) { return option >= 0 && option < SGR_OPT_COUNT ? g_opt[option] : -1; }
 
 int sgr_profile_enable(uint32_t kind_mask) {
   g_prof.mask = kind_mask & ((1u << SGR_PROFILE_KINDS) - 1);

@@ -91,247 +91,6 @@ __device__ __forceinline__ bool code_bytes_tiled(const LOff& L) {
   return (uint64_t)L.ntiles * 64ull <= 12ull * (uint64_t)L.H * (uint64_t)L.W;
 }
 
-// ------------------------------------------------------------------------------------------------ forward
-template <int SORT_MAX>
-__global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
-                                                        LossCoef lc) {
-  const int vw = blockIdx.y;
-  char* saved = tab.saved[vw];
-  const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
-  const int64_t cap = L.cap;
-  const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
-  uint64_t* __restrict__ entries = (uint64_t*)(tab.scratch[vw] + L.o_entries);
-  uint32_t* __restrict__ point_list = (uint32_t*)(saved + L.o_point_list);
-  const GRec* __restrict__ grec = grec_of(saved, L);
-  float* __restrict__ out_color = tab.color[vw];
-  float* __restrict__ out_depth = tab.depth[vw];
-  float* __restrict__ out_opacity = tab.opacity[vw];
-  float2* __restrict__ pix_state = (float2*)(saved + L.o_final_T);
-  uint32_t* __restrict__ tile_maxc = (uint32_t*)(saved + L.o_tile_maxc);
-  int32_t* __restrict__ n_touched = tab.n_touched[vw];
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // per wave: SORT_MAX keys (8 B) + 64 splats x 48 B
-  const int nblocks = sgx * sgy;
-  const int st = super_tile_of_block(blockIdx.x, nblocks);
-  if (st >= nblocks) return;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave-uniform: tile state in SGPRs
-  constexpr int kLdsSortMax = SORT_MAX;
-  char* slice = smem + (size_t)wv * (SORT_MAX * 8 + kWave * 48);
-  const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
-  if (tx >= gx || ty >= gy) return;          // whole wave outside the image
-  const int tile = ty * gx + tx;
-  const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  uint64_t* keys = (uint64_t*)slice;
-  float4* lds = (float4*)(slice + SORT_MAX * 8);
-
-  // ground truth of the fused loss epilogue: fetched NOW so that the round trip hides behind sorting and blending
-  const float* __restrict__ gt_image = lt.gt_image[vw];
-  float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, gtd = 0.f, ea = 1.f, eb = 0.f;
-  if (gt_image && inside) {
-    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
-    gt0 = gt_image[pix]; gt1 = gt_image[hw + pix]; gt2 = gt_image[2 * hw + pix];
-    gtd = lt.gt_depth[vw][pix];
-    ea = lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f;
-    eb = lt.exp_b[vw] ? lt.exp_b[vw][0] : 0.f;
-  }
-
-  // unsorted keys: the tile's bucket (filled by K1) unless the tile had more than kBucket pairs (then its exact run).
-  // The bucket's address does not depend on the tile's range: lane j fetches bucket entry j (kBucket = one wave) in the
-  // same round trip as the range -- the first half of the bucket, which covers 98 % of the tiles of a SLAM view; the
-  // rest follows once the count is known (entries behind the tile's count are ignored).
-  const uint64_t* __restrict__ bucket = (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
-  static_assert(kBucket == kWave, "one bucket entry per lane");
-  uint64_t key_spec = lane < 32 ? bucket[lane] : ~0ull;
-  const uint2 rng = ranges[(size_t)tile * kRngStride];
-  const int64_t begin = rng.x & ~kOverfull;
-  const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
-  const int count = endc > begin ? (int)(endc - begin) : 0;
-  const bool overfull = (rng.x & kOverfull) != 0;
-  const uint64_t* __restrict__ keys_in = overfull ? entries + begin : bucket;
-
-  // ---- sort this tile's run by (depth bits, Gaussian index) and publish the index list for the backward
-  int mode = 0;                               // 0: registers, 1: LDS, 2: global
-  if (count <= kWave) {
-    // One chunk.  Every lane keeps ITS (unsorted) key and finds the key's position in the sorted list by counting
-    // smaller keys (keys are unique; broadcast through SGPRs: count short steps and no LDS round trips instead of a
-    // 21-step shuffle network), fetches the key's record and files it under that position.
-    if (count > 32 && lane >= 32 && lane < count) key_spec = keys_in[lane];
-    const uint64_t key = overfull ? (lane < count ? keys_in[lane] : ~0ull) : (lane < count ? key_spec : ~0ull);
-    const uint32_t g = (uint32_t)key;
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-    uint32_t rank = 0;
-    for (int j = 0; j < count; ++j) {
-      const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, j) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
-      rank += kj < key ? 1u : 0u;
-    }
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
-    if (lane < count) {
-      const float4* rec = (const float4*)(grec + g);
-      m = rec[0];
-      co = rec[1];
-      cd = rec[2];
-    }
-    if (lane >= count) rank = (uint32_t)lane;        // lane == count files the zero splat that pads an odd list
-    if (lane < count) point_list[begin + rank] = g;
-    if (lane <= count) {
-      float* f = (float*)lds + (rank >> 1) * 24 + (rank & 1);
-      f[0] = m.x; f[2] = m.y; f[4] = co.x; f[6] = co.y;
-      f[8] = co.z; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
-      f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
-    }
-  } else if (count <= kLdsSortMax) {
-    mode = 1;
-    for (int i = lane; i < count; i += kWave) keys[i] = keys_in[i];
-    __builtin_amdgcn_wave_barrier();
-    wave_sort_any(count, lane, [&](int i) { return keys[i]; }, [&](int i, uint64_t v) { keys[i] = v; },
-                  [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); });
-    for (int i = lane; i < count; i += kWave) point_list[begin + i] = (uint32_t)keys[i];
-  } else {
-    mode = 2;                                 // slow path: in place in HBM through device-coherent accesses
-    uint64_t* e = entries + begin;
-    wave_sort_any(count, lane,
-                  [&](int i) { return __hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
-                  [&](int i, uint64_t v) { __hip_atomic_store(e + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
-                  [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); __builtin_amdgcn_wave_barrier(); });
-    for (int i = lane; i < count; i += kWave)
-      point_list[begin + i] = (uint32_t)__hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-
-  float T = 1.f;
-  v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, Dd = {0.f, 0.f};   // (even, odd) list positions, added at the end
-  uint32_t last = 0;
-  bool done = !inside;
-  const v2f px2 = splat2(pxf), py2 = splat2(pyf);
-
-  for (int base = 0; base < count; base += kWave) {
-    const int n = min(kWave, count - base);
-    // gather this chunk: lane j fetches splat j (one 64-byte record: centre | conic, opacity | colour, depth) and stores
-    // it PAIR-INTERLEAVED (splats 2p, 2p+1 side by side, 6 float4 per pair) so that the walk reads 2-vectors;
-    // an odd chunk is padded with a splat of opacity 0 (never contributes)
-    if (mode != 0 && lane <= n) {
-      float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
-      uint32_t g = 0;
-      if (lane < n) {
-        if (mode == 1) g = (uint32_t)keys[base + lane];
-        else g = (uint32_t)__hip_atomic_load(entries + begin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float4* rec = (const float4*)(grec + g);
-        m = rec[0];
-        co = rec[1];
-        cd = rec[2];
-      }
-      float* f = (float*)lds + (lane >> 1) * 24 + (lane & 1);
-      f[0] = m.x; f[2] = m.y; f[4] = co.x; f[6] = co.y;
-      f[8] = co.z; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
-      f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // Two splats per trip, branch free.  blend_fwd is VALU-issue bound like the backward, so the footprint (eval_alpha's
-    // operation sequence, packed), alpha * T and the four accumulate FMAs issue once per PAIR (v_pk_*_f32); exp, the
-    // tests and the transmittance chain stay per splat.  The "every pixel finished" exit is polled every 4 splats.
-    auto walk = [&](auto count_touched) {
-#pragma clang fp contract(off)      // the two instantiations must round alike (T * (1 - alpha) is not to become an fma in one)
-      for (int j = 0; j < n; j += 2) {
-        if ((j & 3) == 0 && __builtin_amdgcn_ballot_w64(!done) == 0) break;
-        const float4* e = lds + (j >> 1) * 6;
-        const float4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4];
-        const float2 q5 = *(const float2*)&e[5];
-        const v2f dx = (v2f){q0.x, q0.y} - px2, dy = (v2f){q0.z, q0.w} - py2;
-        const v2f qf = __builtin_elementwise_fma((v2f){q1.x, q1.y} * dx, dx, ((v2f){q2.x, q2.y} * dy) * dy);
-        const v2f bdxdy = ((v2f){q1.z, q1.w} * dx) * dy;
-        const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
-        const v2f G = {__expf(power.x), __expf(power.y)};
-        const v2f og = (v2f){q2.z, q2.w} * G;
-        const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
-        const bool ok0 = (power.x <= 0.0f) && (alpha.x >= kAlphaMin);
-        const bool ok1 = (power.y <= 0.0f) && (alpha.y >= kAlphaMin);
-        const v2f one_m = splat2(1.f) - alpha;
-        const float test0 = T * one_m.x;
-        const bool live0 = !done && ok0;
-        const bool term0 = live0 && (test0 < kTEps);
-        const bool comp0 = live0 && !term0;
-        done = done || term0;
-        const float T1 = comp0 ? test0 : T;
-        const float test1 = T1 * one_m.y;
-        const bool live1 = !done && ok1;
-        const bool term1 = live1 && (test1 < kTEps);
-        const bool comp1 = live1 && !term1;
-        done = done || term1;
-        v2f w = alpha * (v2f){T, T1};
-        w.x = comp0 ? w.x : 0.f;
-        w.y = comp1 ? w.y : 0.f;
-        Cr = __builtin_elementwise_fma((v2f){q4.x, q4.y}, w, Cr);
-        Cg = __builtin_elementwise_fma((v2f){q4.z, q4.w}, w, Cg);
-        Cb = __builtin_elementwise_fma((v2f){q5.x, q5.y}, w, Cb);
-        Dd = __builtin_elementwise_fma((v2f){q3.x, q3.y}, w, Dd);
-        if (decltype(count_touched)::value) {
-          unsigned long long tm = __builtin_amdgcn_ballot_w64(comp0 && test0 > kTouchedT);
-          if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.z)], (int)__popcll(tm));
-          tm = __builtin_amdgcn_ballot_w64(comp1 && test1 > kTouchedT);
-          if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.w)], (int)__popcll(tm));
-        }
-        T = comp1 ? test1 : T1;
-        last = comp1 ? (uint32_t)(base + j + 2) : (comp0 ? (uint32_t)(base + j + 1) : last);
-      }
-    };
-    if (n_touched) walk(std::true_type{}); else walk(std::false_type{});
-    __builtin_amdgcn_wave_barrier();
-    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-  }
-  const float C0 = Cr.x + Cr.y, C1 = Cg.x + Cg.y, C2 = Cb.x + Cb.y, D = Dd.x + Dd.y;
-
-  // per-tile bound for the backward: it never has to look past the last contributor of any pixel
-  const uint32_t mx = wave_max_u32(last);
-  if (lane == 0) tile_maxc[tile] = mx;
-
-  float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;
-  const uint32_t tpix = (uint32_t)tile * 64u + (uint32_t)lane;
-  pix_state[tpix] = make_float2(T, __uint_as_float(last));       // (lanes outside the image: T = 1, no contributor)
-  uint32_t code = 0;
-  if (inside) {
-    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
-    const float I[3] = {C0 + T * bg[0], C1 + T * bg[1], C2 + T * bg[2]};
-    if (out_color) {            // (a training iteration that only needs the loss passes no image buffers)
-      out_color[pix] = I[0];
-      out_color[hw + pix] = I[1];
-      out_color[2 * hw + pix] = I[2];
-      out_depth[pix] = D;
-      out_opacity[pix] = 1.f - T;
-    }
-    if (gt_image) {
-      // fused mapping loss (slam_utils.py:71-105): this pixel's residuals, the gradients the backward consumes, and
-      // its share of the four sums (|rgb|, |depth|, d/da, d/db)
-      // The L1 gradients are +-constant or 0 per value: dL/dC_c = sign * (w_rgb * e^a), dL/dD = sign * w_dep.  The backward
-      // gets ONE code byte per pixel (2 bits per value: 0, 1 = +, 2 = -) in the first H*W bytes of the view's dL_dimage
-      // scratch and rebuilds the same floats (16 -> 1 byte per pixel written here and read there).
-      const float g[3] = {gt0, gt1, gt2};
-      const bool m = (g[0] + g[1] + g[2]) > lc.thr;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float r = m ? (ea * I[c] + eb) - g[c] : 0.f;
-        l_rgb += fabsf(r);
-        float sgn = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
-        code |= ((r > 0.f) ? 1u : ((r < 0.f) ? 2u : 0u)) << (2 * c);
-        float dab = lc.w_rgb * sgn;
-        l_da += dab * ea * I[c];
-        l_db += dab;
-      }
-      const float gd = gtd;
-      const float rd = (gd > 0.01f) ? D - gd : 0.f;
-      l_dep = fabsf(rd);
-      code |= ((rd > 0.f) ? 1u : ((rd < 0.f) ? 2u : 0u)) << 6;
-      if (!code_bytes_tiled(L)) ((uint8_t*)lt.dimage[vw])[pix] = (uint8_t)code;
-    }
-  }
-  if (gt_image && code_bytes_tiled(L)) ((uint8_t*)lt.dimage[vw])[tpix] = (uint8_t)code;
-  if (gt_image) {      // uniform per view
-    wave_sum4(l_rgb, l_dep, l_da, l_db);
-    if (lane == 0) ((LossPart*)lt.parts[vw])[tile] = {l_rgb, l_dep, l_da, l_db};
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ backward
 // inclusive scans restricted to groups of GW lanes (GW = 16: one DPP row, 32: two rows, 64: whole wave)
 // One scan step as a single VALU op: v_mul_f32_dpp with vdst = src0 = src1.  A lane whose DPP source is out of range
@@ -416,34 +175,69 @@ __device__ __forceinline__ int pair_first_pixel(int g) {
   return 2 * PP * (g / PP) + (g % PP);
 }
 
+// What a lane needs to know about ITS splat: footprint, colour, depth and the slot of this (tile, Gaussian) pair inside
+// the Gaussian's run of partials (0xffffffff: not stored -- beyond the capacity).
+struct SplatRec { float mx, my, A, B, C, op, r, g, b, dep; uint32_t slot; };
+__device__ __forceinline__ uint32_t pair_slot(const char* __restrict__ saved, const LOff& L, uint32_t g, uint32_t rel, uint32_t rect01,
+                                              uint32_t rect23, int tx, int ty, int64_t cap) {
+  const Rect r = unpack_rect(rect01, rect23);
+  const uint64_t s = (uint64_t)abs_offset(saved, L, g, rel) + (uint32_t)((ty - r.y0) * (r.x1 - r.x0) + (tx - r.x0));
+  return (int64_t)s < cap ? (uint32_t)s : 0xffffffffu;
+}
+__device__ __forceinline__ SplatRec splat_from_grec(const GRec* __restrict__ grec, const char* __restrict__ saved, const LOff& L,
+                                                    uint32_t g, int tx, int ty, int64_t cap) {
+  // everything that depends on g in ONE round trip (the slot is only needed after the loop, its latency is not)
+  const float4* rec = (const float4*)(grec + g);
+  const float4 m = rec[0], co = rec[1], cd = rec[2];
+  const uint32_t rel = ((const uint32_t*)(rec + 3))[1];
+  SplatRec s;
+  s.slot = pair_slot(saved, L, g, rel, __float_as_uint(m.z), __float_as_uint(m.w), tx, ty, cap);
+  s.mx = m.x; s.my = m.y; s.A = co.x; s.B = co.y; s.C = co.z; s.op = co.w; s.r = cd.x; s.g = cd.y; s.b = cd.z; s.dep = cd.w;
+  return s;
+}
+// list position -> Gaussian through the index list the forward kernel published (blend_bwd_kernel)
+struct SrcPointList {
+  const uint32_t* __restrict__ point_list; int64_t begin; const GRec* __restrict__ grec; const char* __restrict__ saved; int tx, ty; int64_t cap;
+  __device__ __forceinline__ SplatRec load(int idx, const LOff& L) const { return splat_from_grec(grec, saved, L, point_list[begin + idx], tx, ty, cap); }
+};
+// fused kernel, list longer than one chunk: the sorted keys are still where the wave sorted them (LDS, or HBM for huge lists)
+struct SrcKeys {
+  const uint64_t* keys_lds; const uint64_t* __restrict__ keys_hbm; const GRec* __restrict__ grec; const char* __restrict__ saved; int tx, ty; int64_t cap;
+  __device__ __forceinline__ uint32_t gaussian(int idx) const {
+    return keys_lds ? (uint32_t)keys_lds[idx] : (uint32_t)__hip_atomic_load(keys_hbm + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ SplatRec load(int idx, const LOff& L) const { return splat_from_grec(grec, saved, L, gaussian(idx), tx, ty, cap); }
+};
+// fused kernel, list of one chunk (98 % of the tiles of a SLAM view): the forward walk's pair-interleaved staging area
+// still holds every splat of the tile (12 floats each, the 12th = the pair's partial slot): no second gather from HBM
+struct SrcStaged {
+  const float* lds;
+  __device__ __forceinline__ SplatRec load(int idx, const LOff&) const {
+    const float* f = lds + (idx >> 1) * 24 + (idx & 1);
+    SplatRec s;
+    s.mx = f[0]; s.my = f[2]; s.A = f[4]; s.B = f[6]; s.C = f[8]; s.op = f[10]; s.dep = f[12];
+    s.r = f[16]; s.g = f[18]; s.b = f[20]; s.slot = __float_as_uint(f[22]);
+    return s;
+  }
+};
+
 // One chunk of <= GW splats against the 64 pixels of the tile, 2*64/GW pixels per iteration.
 // Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix scan.
 // LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | nc0,nc1, -,-) for pair g.
-template <int GW>
+template <int GW, typename SRC>
 __device__ __forceinline__ void bwd_chunk2(
-    int lane, int c, int eff, int64_t begin, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/,
-    const uint32_t* __restrict__ point_list, const GRec* __restrict__ grec, const char* __restrict__ saved, const LOff& L,
-    int tx, int ty, float halfW, float halfH, float4* __restrict__ partials, int64_t cap) {
+    int lane, int c, int eff, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
+    const LOff& L, float halfW, float halfH, float4* __restrict__ partials) {
   constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
   const int sub = lane / GW;                     // which of them this lane works on
   const int sl = lane % GW;
   const int idx = c * GW + (GW - 1 - sl);        // list position of this lane's splat
   const bool valid = idx < eff;
-  uint32_t g = 0;
   float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
   uint32_t slot = 0xffffffffu;                   // this (tile, Gaussian) pair's slot inside the Gaussian's run of partials
   if (valid) {
-    g = point_list[begin + idx];
-    // everything that depends on g in ONE round trip (the slot is only needed after the loop, its latency is not)
-    const float4* rec = (const float4*)(grec + g);
-    float4 m = rec[0];
-    float4 co = rec[1];
-    float4 cd = rec[2];
-    const uint32_t rel = ((const uint32_t*)(rec + 3))[1];
-    const Rect r = unpack_rect(__float_as_uint(m.z), __float_as_uint(m.w));
-    uint64_t sl64 = (uint64_t)abs_offset(saved, L, g, rel) + (uint32_t)((ty - r.y0) * (r.x1 - r.x0) + (tx - r.x0));
-    if ((int64_t)sl64 < cap) slot = (uint32_t)sl64;
-    mx = m.x; my = m.y; A = co.x; B = co.y; Cc = co.z; op = co.w; cr = cd.x; cg = cd.y; cb = cd.z; dep = cd.w;
+    const SplatRec sr = src.load(idx, L);
+    mx = sr.mx; my = sr.my; A = sr.A; B = sr.B; Cc = sr.C; op = sr.op; cr = sr.r; cg = sr.g; cb = sr.b; dep = sr.dep; slot = sr.slot;
   }
   v2f s_gx = {0.f, 0.f}, s_gy = {0.f, 0.f}, s_gxx = {0.f, 0.f}, s_gxy = {0.f, 0.f}, s_gyy = {0.f, 0.f};
   v2f a_o = {0.f, 0.f}, a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
@@ -537,9 +331,341 @@ __device__ __forceinline__ void bwd_chunk2(
   }
 }
 
+// The backward of one tile given this lane's pixel state (pxA = dL/dC r, g, b and dL/dD; pxB[0] = final transmittance,
+// pxB[2] = last contributor as uint bits) and a source for the tile's sorted splats.  Used by blend_bwd_kernel (state read
+// back from HBM) and by the fused tile kernel (state still in the forward walk's registers).
+template <typename SRC>
+__device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty, const float pxA[4], float pxB[3],
+                                              const float* __restrict__ bg, float4* pixA /*LDS*/, float4* pixB /*LDS*/, const SRC& src,
+                                              const LOff& L, float4* __restrict__ partials) {
+  // the background term -T_final/(1-alpha_j) * (bg . dL/dC) has the same shape as "colour behind splat j"
+  pxB[1] = pxB[0] * (bg[0] * pxA[0] + bg[1] * pxA[1] + bg[2] * pxA[2]);
+  // pair layout depends on the group width (see bwd_chunk2): pixel p -> pair g, half h
+  auto stage = [&](auto gw_tag) {
+    constexpr int GW = decltype(gw_tag)::value, PP = kWave / GW;
+    const int q2 = lane % (2 * PP), h = q2 / PP, gidx = (lane / (2 * PP)) * PP + (q2 % PP);
+    float* fa = (float*)pixA + gidx * 8 + h;
+    float* fb = (float*)pixB + gidx * 8 + h;
+    fa[0] = pxA[0]; fa[2] = pxA[1]; fa[4] = pxA[2]; fa[6] = pxA[3];
+    fb[0] = pxB[0]; fb[2] = pxB[1]; fb[4] = pxB[2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const float halfW = 0.5f * (float)L.W, halfH = 0.5f * (float)L.H;
+  const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+  if (eff <= 8) {          // half of the iterations of the 16-lane form: 16 pixels per iteration
+    stage(std::integral_constant<int, 8>{});
+    bwd_chunk2<8>(lane, 0, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+  } else if (eff <= 16) {
+    stage(std::integral_constant<int, 16>{});
+    bwd_chunk2<16>(lane, 0, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+  } else if (eff <= 32) {
+    stage(std::integral_constant<int, 32>{});
+    bwd_chunk2<32>(lane, 0, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+  } else {
+    stage(std::integral_constant<int, 64>{});
+    const int nchunks = (eff + kWave - 1) / kWave;
+    for (int c = nchunks - 1; c >= 0; --c) {
+      bwd_chunk2<64>(lane, c, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // PACKED: the pixel gradients come as the forward's loss epilogue left them (one code byte per pixel, see blend_fwd)
 struct SignGrad { const float* exp_a[kMaxViews]; float w_rgb, w_dep; };
 __device__ __forceinline__ float sign_code(uint32_t c, float k) { return (c & 1u) ? k : ((c & 2u) ? -k : 0.f); }
+
+// ------------------------------------------------------------------------------------------------ forward
+// FUSED (the mapping iteration: loss in the epilogue, backward in the SAME wave): the pixel state the backward needs --
+// final transmittance, last contributor, the L1 loss gradient (sign x per-view constant) -- is still in this lane's
+// registers and the tile's sorted splats are still staged in LDS, so the wave goes straight on with tile_backward():
+// no final_T / n_contrib / code-byte / index-list round trip through HBM, no second launch, one tile prologue.
+template <int SORT_MAX, bool FUSED>
+__global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
+                                                        LossCoef lc) {
+  const int vw = blockIdx.y;
+  char* saved = tab.saved[vw];
+  const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
+  const int64_t cap = L.cap;
+  const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
+  uint64_t* __restrict__ entries = (uint64_t*)(tab.scratch[vw] + L.o_entries);
+  uint32_t* __restrict__ point_list = (uint32_t*)(saved + L.o_point_list);
+  const GRec* __restrict__ grec = grec_of(saved, L);
+  float* __restrict__ out_color = tab.color[vw];
+  float* __restrict__ out_depth = tab.depth[vw];
+  float* __restrict__ out_opacity = tab.opacity[vw];
+  float2* __restrict__ pix_state = (float2*)(saved + L.o_final_T);
+  uint32_t* __restrict__ tile_maxc = (uint32_t*)(saved + L.o_tile_maxc);
+  int32_t* __restrict__ n_touched = tab.n_touched[vw];
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // per wave: SORT_MAX keys (8 B) + 64 splats x 48 B (+ FUSED: 2 x 64 float4 of pixel state)
+  constexpr size_t kSlice = (size_t)SORT_MAX * 8 + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0);
+  const int nblocks = sgx * sgy;
+  const int st = super_tile_of_block(blockIdx.x, nblocks);
+  if (st >= nblocks) return;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave-uniform: tile state in SGPRs
+  constexpr int kLdsSortMax = SORT_MAX;
+  char* slice = smem + (size_t)wv * kSlice;
+  const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
+  if (tx >= gx || ty >= gy) return;          // whole wave outside the image
+  const int tile = ty * gx + tx;
+  const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  uint64_t* keys = (uint64_t*)slice;
+  float4* lds = (float4*)(slice + SORT_MAX * 8);
+
+  // ground truth of the fused loss epilogue: fetched NOW so that the round trip hides behind sorting and blending
+  const float* __restrict__ gt_image = lt.gt_image[vw];
+  float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, gtd = 0.f, ea = 1.f, eb = 0.f;
+  if (gt_image && inside) {
+    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
+    gt0 = gt_image[pix]; gt1 = gt_image[hw + pix]; gt2 = gt_image[2 * hw + pix];
+    gtd = lt.gt_depth[vw][pix];
+    ea = lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f;
+    eb = lt.exp_b[vw] ? lt.exp_b[vw][0] : 0.f;
+  }
+
+  // unsorted keys: the tile's bucket (filled by K1) unless the tile had more than kBucket pairs (then its exact run).
+  // The bucket's address does not depend on the tile's range: lane j fetches bucket entry j (kBucket = one wave) in the
+  // same round trip as the range -- the first half of the bucket, which covers 98 % of the tiles of a SLAM view; the
+  // rest follows once the count is known (entries behind the tile's count are ignored).
+  const uint64_t* __restrict__ bucket = (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
+  static_assert(kBucket == kWave, "one bucket entry per lane");
+  uint64_t key_spec = lane < 32 ? bucket[lane] : ~0ull;
+  const uint2 rng = ranges[(size_t)tile * kRngStride];
+  const int64_t begin = rng.x & ~kOverfull;
+  const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
+  const int count = endc > begin ? (int)(endc - begin) : 0;
+  const bool overfull = (rng.x & kOverfull) != 0;
+  const uint64_t* __restrict__ keys_in = overfull ? entries + begin : bucket;
+
+  // ---- sort this tile's run by (depth bits, Gaussian index) and publish the index list for the backward
+  int mode = 0;                               // 0: registers, 1: LDS, 2: global
+  if (count <= kWave) {
+    // One chunk.  Every lane keeps ITS (unsorted) key and finds the key's position in the sorted list by counting
+    // smaller keys (keys are unique; broadcast through SGPRs: count short steps and no LDS round trips instead of a
+    // 21-step shuffle network), fetches the key's record and files it under that position.
+    if (count > 32 && lane >= 32 && lane < count) key_spec = keys_in[lane];
+    const uint64_t key = overfull ? (lane < count ? keys_in[lane] : ~0ull) : (lane < count ? key_spec : ~0ull);
+    const uint32_t g = (uint32_t)key;
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    uint32_t rank = 0;
+    for (int j = 0; j < count; ++j) {
+      const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, j) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
+      rank += kj < key ? 1u : 0u;
+    }
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
+    uint32_t slot = 0xffffffffu;
+    if (lane < count) {
+      const float4* rec = (const float4*)(grec + g);
+      m = rec[0];
+      co = rec[1];
+      cd = rec[2];
+      if (FUSED) slot = pair_slot(saved, L, g, ((const uint32_t*)(rec + 3))[1], __float_as_uint(m.z), __float_as_uint(m.w), tx, ty, cap);
+    }
+    if (lane >= count) rank = (uint32_t)lane;        // lane == count files the zero splat that pads an odd list
+    if (!FUSED && lane < count) point_list[begin + rank] = g;      // (the fused backward reads the staged records instead)
+    if (lane <= count) {
+      float* f = (float*)lds + (rank >> 1) * 24 + (rank & 1);
+      f[0] = m.x; f[2] = m.y; f[4] = co.x; f[6] = co.y;
+      f[8] = co.z; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
+      f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
+      if (FUSED) f[22] = __uint_as_float(slot);
+    }
+  } else if (count <= kLdsSortMax) {
+    mode = 1;
+    for (int i = lane; i < count; i += kWave) keys[i] = keys_in[i];
+    __builtin_amdgcn_wave_barrier();
+    wave_sort_any(count, lane, [&](int i) { return keys[i]; }, [&](int i, uint64_t v) { keys[i] = v; },
+                  [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); });
+    if (!FUSED)
+      for (int i = lane; i < count; i += kWave) point_list[begin + i] = (uint32_t)keys[i];
+  } else {
+    mode = 2;                                 // slow path: in place in HBM through device-coherent accesses
+    uint64_t* e = entries + begin;
+    wave_sort_any(count, lane,
+                  [&](int i) { return __hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                  [&](int i, uint64_t v) { __hip_atomic_store(e + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                  [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); __builtin_amdgcn_wave_barrier(); });
+    if (!FUSED)
+      for (int i = lane; i < count; i += kWave)
+        point_list[begin + i] = (uint32_t)__hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  float T = 1.f;
+  v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, Dd = {0.f, 0.f};   // (even, odd) list positions, added at the end
+  uint32_t last = 0;
+  bool done = !inside;
+  const v2f px2 = splat2(pxf), py2 = splat2(pyf);
+
+  for (int base = 0; base < count; base += kWave) {
+    const int n = min(kWave, count - base);
+    // gather this chunk: lane j fetches splat j (one 64-byte record: centre | conic, opacity | colour, depth) and stores
+    // it PAIR-INTERLEAVED (splats 2p, 2p+1 side by side, 6 float4 per pair) so that the walk reads 2-vectors;
+    // an odd chunk is padded with a splat of opacity 0 (never contributes)
+    if (mode != 0 && lane <= n) {
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
+      uint32_t g = 0;
+      if (lane < n) {
+        if (mode == 1) g = (uint32_t)keys[base + lane];
+        else g = (uint32_t)__hip_atomic_load(entries + begin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float4* rec = (const float4*)(grec + g);
+        m = rec[0];
+        co = rec[1];
+        cd = rec[2];
+      }
+      float* f = (float*)lds + (lane >> 1) * 24 + (lane & 1);
+      f[0] = m.x; f[2] = m.y; f[4] = co.x; f[6] = co.y;
+      f[8] = co.z; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
+      f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // Two splats per trip, branch free.  blend_fwd is VALU-issue bound like the backward, so the footprint (eval_alpha's
+    // operation sequence, packed), alpha * T and the four accumulate FMAs issue once per PAIR (v_pk_*_f32); exp, the
+    // tests and the transmittance chain stay per splat.  The "every pixel finished" exit is polled every 4 splats.
+    auto walk = [&](auto count_touched) {
+#pragma clang fp contract(off)      // the two instantiations must round alike (T * (1 - alpha) is not to become an fma in one)
+      for (int j = 0; j < n; j += 2) {
+        if ((j & 3) == 0 && __builtin_amdgcn_ballot_w64(!done) == 0) break;
+        const float4* e = lds + (j >> 1) * 6;
+        const float4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4];
+        const float2 q5 = *(const float2*)&e[5];
+        const v2f dx = (v2f){q0.x, q0.y} - px2, dy = (v2f){q0.z, q0.w} - py2;
+        const v2f qf = __builtin_elementwise_fma((v2f){q1.x, q1.y} * dx, dx, ((v2f){q2.x, q2.y} * dy) * dy);
+        const v2f bdxdy = ((v2f){q1.z, q1.w} * dx) * dy;
+        const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
+        const v2f G = {__expf(power.x), __expf(power.y)};
+        const v2f og = (v2f){q2.z, q2.w} * G;
+        const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
+        const bool ok0 = (power.x <= 0.0f) && (alpha.x >= kAlphaMin);
+        const bool ok1 = (power.y <= 0.0f) && (alpha.y >= kAlphaMin);
+        const v2f one_m = splat2(1.f) - alpha;
+        const float test0 = T * one_m.x;
+        const bool live0 = !done && ok0;
+        const bool term0 = live0 && (test0 < kTEps);
+        const bool comp0 = live0 && !term0;
+        done = done || term0;
+        const float T1 = comp0 ? test0 : T;
+        const float test1 = T1 * one_m.y;
+        const bool live1 = !done && ok1;
+        const bool term1 = live1 && (test1 < kTEps);
+        const bool comp1 = live1 && !term1;
+        done = done || term1;
+        v2f w = alpha * (v2f){T, T1};
+        w.x = comp0 ? w.x : 0.f;
+        w.y = comp1 ? w.y : 0.f;
+        Cr = __builtin_elementwise_fma((v2f){q4.x, q4.y}, w, Cr);
+        Cg = __builtin_elementwise_fma((v2f){q4.z, q4.w}, w, Cg);
+        Cb = __builtin_elementwise_fma((v2f){q5.x, q5.y}, w, Cb);
+        Dd = __builtin_elementwise_fma((v2f){q3.x, q3.y}, w, Dd);
+        if (decltype(count_touched)::value) {
+          unsigned long long tm = __builtin_amdgcn_ballot_w64(comp0 && test0 > kTouchedT);
+          if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.z)], (int)__popcll(tm));
+          tm = __builtin_amdgcn_ballot_w64(comp1 && test1 > kTouchedT);
+          if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.w)], (int)__popcll(tm));
+        }
+        T = comp1 ? test1 : T1;
+        last = comp1 ? (uint32_t)(base + j + 2) : (comp0 ? (uint32_t)(base + j + 1) : last);
+      }
+    };
+    if (n_touched) walk(std::true_type{}); else walk(std::false_type{});
+    __builtin_amdgcn_wave_barrier();
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+  }
+  const float C0 = Cr.x + Cr.y, C1 = Cg.x + Cg.y, C2 = Cb.x + Cb.y, D = Dd.x + Dd.y;
+
+  // per-tile bound for the backward: it never has to look past the last contributor of any pixel
+  const uint32_t mx = wave_max_u32(last);
+  if (lane == 0) tile_maxc[tile] = mx;
+
+  float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;
+  const uint32_t tpix = (uint32_t)tile * 64u + (uint32_t)lane;
+  if (!FUSED) pix_state[tpix] = make_float2(T, __uint_as_float(last));       // (lanes outside the image: T = 1, no contributor)
+  uint32_t code = 0;
+  if (inside) {
+    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
+    const float I[3] = {C0 + T * bg[0], C1 + T * bg[1], C2 + T * bg[2]};
+    if (out_color) {            // (a training iteration that only needs the loss passes no image buffers)
+      out_color[pix] = I[0];
+      out_color[hw + pix] = I[1];
+      out_color[2 * hw + pix] = I[2];
+      out_depth[pix] = D;
+      out_opacity[pix] = 1.f - T;
+    }
+    if (gt_image) {
+      // fused mapping loss (slam_utils.py:71-105): this pixel's residuals, the gradients the backward consumes, and
+      // its share of the four sums (|rgb|, |depth|, d/da, d/db)
+      // The L1 gradients are +-constant or 0 per value: dL/dC_c = sign * (w_rgb * e^a), dL/dD = sign * w_dep.  The backward
+      // gets ONE code byte per pixel (2 bits per value: 0, 1 = +, 2 = -) in the first H*W bytes of the view's dL_dimage
+      // scratch and rebuilds the same floats (16 -> 1 byte per pixel written here and read there).
+      const float g[3] = {gt0, gt1, gt2};
+      const bool m = (g[0] + g[1] + g[2]) > lc.thr;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float r = m ? (ea * I[c] + eb) - g[c] : 0.f;
+        l_rgb += fabsf(r);
+        float sgn = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+        code |= ((r > 0.f) ? 1u : ((r < 0.f) ? 2u : 0u)) << (2 * c);
+        float dab = lc.w_rgb * sgn;
+        l_da += dab * ea * I[c];
+        l_db += dab;
+      }
+      const float gd = gtd;
+      const float rd = (gd > 0.01f) ? D - gd : 0.f;
+      l_dep = fabsf(rd);
+      code |= ((rd > 0.f) ? 1u : ((rd < 0.f) ? 2u : 0u)) << 6;
+      if (!FUSED && !code_bytes_tiled(L)) ((uint8_t*)lt.dimage[vw])[pix] = (uint8_t)code;
+    }
+  }
+  if (!FUSED && gt_image && code_bytes_tiled(L)) ((uint8_t*)lt.dimage[vw])[tpix] = (uint8_t)code;
+  if (gt_image) {      // uniform per view
+    wave_sum4(l_rgb, l_dep, l_da, l_db);
+    if (lane == 0) ((LossPart*)lt.parts[vw])[tile] = {l_rgb, l_dep, l_da, l_db};
+  }
+  if (!FUSED) return;
+
+  // ---- the backward of this tile, right here
+  if (count == 0) return;
+  const int eff = min(count, (int)mx);
+  float4* __restrict__ partials = (float4*)(tab.scratch[vw] + L.o_partials);
+  // pairs the walk never reached (behind every pixel's last contributor) still own a slot: define it as zero
+  const float k_rgb = lc.w_rgb * (lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f);     // the floats blend_bwd<true> rebuilds from the code byte
+  float pxA[4] = {sign_code(code, k_rgb), sign_code(code >> 2, k_rgb), sign_code(code >> 4, k_rgb), sign_code(code >> 6, lc.w_dep)};
+  float pxB[3] = {T, 0.f, __uint_as_float(last)};
+  float4* pixA = (float4*)(slice + (size_t)SORT_MAX * 8 + kWave * 48);
+  float4* pixB = pixA + kWave;
+  if (mode == 0) {
+    const SrcStaged src = {(const float*)lds};
+    for (int idx = eff + lane; idx < count; idx += kWave) {
+      const uint32_t slot = src.load(idx, L).slot;
+      if (slot != 0xffffffffu) {
+        partials[(size_t)slot * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        partials[(size_t)slot * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        partials[(size_t)slot * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (eff == 0) return;
+    tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixA, pixB, src, L, partials);
+  } else {
+    const SrcKeys src = {mode == 1 ? keys : nullptr, entries + begin, grec, saved, tx, ty, cap};
+    for (int idx = eff + lane; idx < count; idx += kWave) {
+      const uint32_t g = src.gaussian(idx);
+      const float4 q0 = ((const float4*)(grec + g))[0];
+      const uint32_t slot = pair_slot(saved, L, g, grec[g].offset, __float_as_uint(q0.z), __float_as_uint(q0.w), tx, ty, cap);
+      if (slot != 0xffffffffu) {
+        partials[(size_t)slot * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        partials[(size_t)slot * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        partials[(size_t)slot * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (eff == 0) return;
+    tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixA, pixB, src, L, partials);
+  }
+}
 
 template <bool PACKED>
 __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
@@ -596,71 +722,30 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, con
   for (int idx = eff + lane; idx < count; idx += kWave) {
     uint32_t g = point_list[begin + idx];
     const float4 q0 = ((const float4*)(grec + g))[0];
-    const Rect r = unpack_rect(__float_as_uint(q0.z), __float_as_uint(q0.w));
-    uint64_t slot = (uint64_t)abs_offset(saved, L, g, grec[g].offset) + (uint32_t)((ty - r.y0) * (r.x1 - r.x0) + (tx - r.x0));
-    if ((int64_t)slot < cap) {
-      partials[slot * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
-      partials[slot * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      partials[slot * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t slot = pair_slot(saved, L, g, grec[g].offset, __float_as_uint(q0.z), __float_as_uint(q0.w), tx, ty, cap);
+    if (slot != 0xffffffffu) {
+      partials[(size_t)slot * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      partials[(size_t)slot * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      partials[(size_t)slot * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   if (eff == 0) return;
-
-  // pixel state into the wave's LDS slice
-  float4* pixA = pixbuf[wv][0];
-  float4* pixB = pixbuf[wv][1];
-  // the background term -T_final/(1-alpha_j) * (bg . dL/dC) has the same shape as "colour behind splat j"
-  pxB[1] = pxB[0] * (bg[0] * pxA[0] + bg[1] * pxA[1] + bg[2] * pxA[2]);
-  // pair layout depends on the group width (see bwd_chunk2): pixel p -> pair g, half h
-  auto stage = [&](auto gw_tag) {
-    constexpr int GW = decltype(gw_tag)::value, PP = kWave / GW;
-    const int q2 = lane % (2 * PP), h = q2 / PP, gidx = (lane / (2 * PP)) * PP + (q2 % PP);
-    float* fa = (float*)pixA + gidx * 8 + h;
-    float* fb = (float*)pixB + gidx * 8 + h;
-    fa[0] = pxA[0]; fa[2] = pxA[1]; fa[4] = pxA[2]; fa[6] = pxA[3];
-    fb[0] = pxB[0]; fb[2] = pxB[1]; fb[4] = pxB[2];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
-  const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
-
-  if (eff <= 8) {          // half of the iterations of the 16-lane form: 16 pixels per iteration
-    stage(std::integral_constant<int, 8>{});
-    bwd_chunk2<8>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty, halfW,
-                  halfH, partials, cap);
-  } else if (eff <= 16) {
-    stage(std::integral_constant<int, 16>{});
-    bwd_chunk2<16>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty, halfW,
-                   halfH, partials, cap);
-  } else if (eff <= 32) {
-    stage(std::integral_constant<int, 32>{});
-    bwd_chunk2<32>(lane, 0, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty, halfW,
-                   halfH, partials, cap);
-  } else {
-    stage(std::integral_constant<int, 64>{});
-    const int nchunks = (eff + kWave - 1) / kWave;
-    for (int c = nchunks - 1; c >= 0; --c) {
-      bwd_chunk2<64>(lane, c, eff, begin, tx0, ty0, pixA, pixB, point_list, grec, saved, L, tx, ty,
-                     halfW, halfH, partials, cap);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
+  const SrcPointList src = {point_list, begin, grec, saved, tx, ty, cap};
+  tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixbuf[wv][0], pixbuf[wv][1], src, L, partials);
 }
 
-template <int SORT_MAX>
+template <int SORT_MAX, bool FUSED>
 static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab& lt,
                                const LossCoef& lc, hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
-  constexpr size_t lds = 4 * (size_t)(SORT_MAX * 8 + kWave * 48);
+  constexpr size_t lds = 4 * ((size_t)SORT_MAX * 8 + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0));
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(blend_fwd_kernel<SORT_MAX>, dim3(grid, nviews), dim3(256), lds, st, tab, L, bg, lt, lc);
+  hipLaunchKernelGGL((blend_fwd_kernel<SORT_MAX, FUSED>), dim3(grid, nviews), dim3(256), lds, st, tab, L, bg, lt, lc);
 }
 
 // lt: per-view loss pointers (gt_image[v] == NULL -> plain render).  With a loss, every 8x8 tile also leaves one
@@ -674,8 +759,17 @@ void launch_blend_fwd(const ViewTab& tab, int nviews, const LOff& L, const float
   const LossCoef& c = lc ? *lc : nocoef;
   // the caller sizes `capacity` at ~2x the pair count it has seen: capacity / tiles / 2 estimates the mean list length
   const int64_t mean_len = L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
-  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy>(tab, nviews, L, bg, t, c, st);
-  else launch_blend_fwd_t<kSortLight>(tab, nviews, L, bg, t, c, st);
+  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy, false>(tab, nviews, L, bg, t, c, st);
+  else launch_blend_fwd_t<kSortLight, false>(tab, nviews, L, bg, t, c, st);
+}
+
+// forward + mapping loss + backward of every tile in ONE launch (needs lt / lc: the loss is what links the two halves)
+void launch_blend_fused(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab& lt, const LossCoef& lc,
+                        hipStream_t st) {
+  ProfScope prof(PK_BLEND_FUSED, st);
+  const int64_t mean_len = L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
+  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy, true>(tab, nviews, L, bg, lt, lc, st);
+  else launch_blend_fwd_t<kSortLight, true>(tab, nviews, L, bg, lt, lc, st);
 }
 
 // lt / lc given: the pixel gradients are the code bytes blend_fwd's loss epilogue wrote for these views

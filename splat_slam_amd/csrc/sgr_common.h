@@ -122,7 +122,7 @@ struct Layout {
       o_seg_list, o_vismask, saved_bytes, zero_bytes;
   // scratch (forward)
   size_t o_entries, o_bucket;
-  // scratch (backward) -- aliases the forward scratch
+  // scratch (backward)
   size_t o_partials, o_tau_part, o_gradrec, o_taurec, scratch_bytes;
   int pre_blocks, nseg;
 
@@ -161,13 +161,13 @@ struct Layout {
     o = 0;
     o_entries = take(c * 8);
     o_bucket = take((size_t)ntiles * kBucket * 8);
-    size_t fwd = o;
-    o = 0;
+    // (the backward arrays FOLLOW the forward ones: in the fused tile kernel one tile's wave writes its partials while the
+    // waves of other tiles still read their buckets / runs)
     o_partials = take(c * 48);
     o_tau_part = take((size_t)(pre_blocks > 0 ? pre_blocks : 1) * 6 * 4);
     o_gradrec = take(n * 64);          // per visible Gaussian: 16-float gradient record of this view
     o_taurec = take(n * 24);           // per visible Gaussian: its 6 pose-gradient terms (only when requested)
-    scratch_bytes = fwd > o ? fwd : o;
+    scratch_bytes = o;
   }
   __host__ LOff dev() const {
     LOff d;
@@ -235,7 +235,7 @@ int gaussian_adam_step_act(int64_t n, const SgrAdamGroup groups[5], float beta1,
 void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st);
 
 // ---- optional per-kernel event timing (sgr_profile_enable / sgr_profile_read)
-enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_SCATTER, PK_UNUSED3, PK_UNUSED4, PK_BLEND_FWD, PK_UNUSED6, PK_BLEND_BWD, PK_PRE_BWD };
+enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_SCATTER, PK_BLEND_FUSED, PK_UNUSED4, PK_BLEND_FWD, PK_UNUSED6, PK_BLEND_BWD, PK_PRE_BWD };
 void prof_begin(int kind, hipStream_t st);
 void prof_end(int kind, hipStream_t st);
 struct ProfScope {

@@ -776,7 +776,7 @@ class FusedMappingLoop(MappingLoop):
             reset = (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian)
             special = update_gaussian or reset
             # regular iteration: everything in one host call; densify / reset iterations split around the torch-side surgery
-            exp_stale = self._exp is not None and bool(self._exp.stale_rows)
+            exp_stale = self._exp_stale()
             self._step(used, iso_weight=10.0, adam=not special,
                        exposure="none" if (special or pose_opt or exp_stale) else "window")
             if exp_stale and not (special or pose_opt):
@@ -817,7 +817,12 @@ class FusedMappingLoop(MappingLoop):
 
     def _has_stale(self):
         """A prune pass left gradients behind that the next optimiser step must include (see the module docstring)."""
-        return (not self._acc_clean) or self._stale_iso != 0.0 or (self._exp is not None and bool(self._exp.stale_rows))
+        return (not self._acc_clean) or self._stale_iso != 0.0 or self._exp_stale()
+
+    def _exp_stale(self):
+        """Rows of the CURRENT keyframe optimiser that carry a prune pass's exposure gradient (cameras outside it keep theirs,
+        like the reference's never-zeroed .grad, but no optimiser ever looks at them again)."""
+        return self._exp is not None and any(r in self._exp.stale_rows for r in self._exp_rows)
 
     def _is_special(self, count):
         update_gaussian = count % self.gaussian_update_every == self.gaussian_update_offset

@@ -15,8 +15,28 @@ def hip_settings(s, dev):
         projmatrix_raw=f(s.projmatrix_raw), sh_degree=s.sh_degree, campos=f(s.campos), prefiltered=False, debug=False)
 
 
-def run_hip(inp, s, wc=None, wd=None, dev="cuda:0"):
-    """inp: dict of CPU tensors (any float dtype). Returns (outputs on CPU, grads dict on CPU or None)."""
+def hip_depth_keys(saved, capacity, n, H, W, radii):
+    """fp32 view-space depths the forward that filled `saved` sorted by (sgr_query_depth_keys), on the CPU."""
+    import ctypes as C
+    from splat_slam_amd import _native as nat
+    out = torch.empty(n, dtype=torch.float32, device=radii.device)
+    ws = nat.SgrWorkspace(saved.data_ptr(), saved.numel(), None, 0, int(capacity))
+    nat.check(nat.lib().sgr_query_depth_keys(C.byref(ws), n, H, W, radii.data_ptr(), out.data_ptr(),
+                                             torch.cuda.current_stream(radii.device).cuda_stream), "sgr_query_depth_keys")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def check_depth_keys(keys, radii, ref_depth, ulps=8):
+    """The override may only re-order near ties: every key must equal the oracle's depth to a few fp32 ulp."""
+    vis = radii > 0
+    k, d = keys[vis].double(), ref_depth.detach()[vis].double()
+    rel = ((k - d).abs() / d.abs()).max().item() if k.numel() else 0.0
+    assert rel <= ulps * 2.0 ** -24, f"HIP depth keys differ from the oracle's depths by {rel / 2.0 ** -24:.1f} ulp"
+
+
+def run_hip(inp, s, wc=None, wd=None, dev="cuda:0", want_depth_keys=False):
+    """inp: dict of CPU tensors (any float dtype). Returns (outputs on CPU, grads dict on CPU or None[, depth keys])."""
     from diff_gaussian_rasterization import GaussianRasterizer
     x = {k: v.detach().to(device=dev, dtype=torch.float32).requires_grad_(wc is not None) for k, v in inp.items()}
     rast = GaussianRasterizer(raster_settings=hip_settings(s, dev))
@@ -24,21 +44,27 @@ def run_hip(inp, s, wc=None, wd=None, dev="cuda:0"):
                opacities=x["opacities"], scales=x.get("scales"), rotations=x.get("rotations"),
                cov3D_precomp=x.get("cov3D_precomp"), theta=x.get("theta"), rho=x.get("rho"))
     grads = None
+    keys = None
+    if want_depth_keys:
+        fn = out[0].grad_fn
+        keys = hip_depth_keys(fn.saved_tensors[-1], fn.capacity, x["means3D"].shape[0], s.image_height, s.image_width, out[1])
     if wc is not None:
         loss = (out[0] * wc.to(dev).float()).sum() + (out[2] * wd.to(dev).float()).sum()
         loss.backward()
         grads = {k: (v.grad.detach().cpu() if v.grad is not None else None) for k, v in x.items()}
     torch.cuda.synchronize()
-    return [o.detach().cpu() for o in out], grads
+    res = [o.detach().cpu() for o in out]
+    return (res, grads, keys) if want_depth_keys else (res, grads)
 
 
-def run_oracle(inp, s, wc=None, wd=None, dtype=torch.float64):
+def run_oracle(inp, s, wc=None, wd=None, dtype=torch.float64, depth_sort_key=None):
     x = {k: v.detach().to(dtype).requires_grad_(wc is not None) for k, v in inp.items()}
     s2 = s._replace(bg=s.bg.to(dtype), viewmatrix=s.viewmatrix.to(dtype), projmatrix=s.projmatrix.to(dtype),
                     projmatrix_raw=s.projmatrix_raw.to(dtype), campos=s.campos.to(dtype))
     out = O.rasterize(x["means3D"], x["means2D"], x["opacities"], shs=x.get("shs"),
                       colors_precomp=x.get("colors_precomp"), scales=x.get("scales"), rotations=x.get("rotations"),
-                      cov3D_precomp=x.get("cov3D_precomp"), theta=x.get("theta"), rho=x.get("rho"), settings=s2)
+                      cov3D_precomp=x.get("cov3D_precomp"), theta=x.get("theta"), rho=x.get("rho"), settings=s2,
+                      depth_sort_key=depth_sort_key)
     grads = None
     if wc is not None:
         loss = (out[0] * wc.to(dtype)).sum() + (out[2] * wd.to(dtype)).sum()

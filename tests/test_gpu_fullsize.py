@@ -13,8 +13,13 @@ Two code paths are pinned against the fp64 oracle (oracle/raster_oracle.py):
       preprocess_bwd_dense and the gather pass -- against  sum over views of oracle-autograd through the reference's
       mapping loss (/root/reference/thirdparty/monogs/utils/slam_utils.py:71-105, pinned by golden G5).
 
-Tolerance: 1e-4 relative (max|a-b| / max|b| per tensor), BASELINE.json north_star.  Two knife-edge effects are handled
+Tolerance: 1e-4 relative (max|a-b| / max|b| per tensor), BASELINE.json north_star.  Three knife-edge effects are handled
 explicitly instead of by a looser tolerance:
+  * splats of a tile are ordered by the fp32 BIT PATTERN of their view-space depth.  With 300 k Gaussians on planar walls
+    a handful of overlapping pairs per view have depths equal to the last ulp; which of the two comes first is decided by
+    the rounding of the depth itself (first full-size run: 17 pixels / 3e-3, gradients off by up to 7e-3 of the maximum
+    for exactly those Gaussians).  The oracle therefore takes the HIP forward's fp32 depths as its SORT KEY only
+    (sgr_query_depth_keys), after the test has checked that they equal its own depths to <= 8 ulp;
   * radii = ceil(3 sqrt(lambda)): with ~19 k visible Gaussians per view a handful sit within fp32 rounding of an
     integer; at most 3 may differ, by one (their extra / missing ring of pixels has alpha < 1/255: no image effect);
   * the L1 loss gradient is sign(residual): where the fp64 residual is smaller than 1e-5 the sign is decided by fp32
@@ -26,7 +31,7 @@ import math
 import pytest
 import torch
 
-from gpu_utils import GRAD_KEYS, outlier_report, rel_linf, run_hip, run_oracle
+from gpu_utils import GRAD_KEYS, check_depth_keys, hip_depth_keys, outlier_report, rel_linf, run_hip, run_oracle
 from oracle import raster_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -105,8 +110,10 @@ def test_autograd_api_matches_oracle_at_config_size(case):
     g = torch.Generator().manual_seed(5)
     wc = torch.randn(3, intr["H"], intr["W"], generator=g, dtype=torch.float64)
     wd = torch.randn(1, intr["H"], intr["W"], generator=g, dtype=torch.float64)
-    hip_out, hip_g = run_hip(inp, s, wc, wd)
-    ref_out, ref_g = run_oracle(inp, s, wc, wd, dtype=torch.float64)
+    hip_out, hip_g, keys = run_hip(inp, s, wc, wd, want_depth_keys=True)
+    view = s.viewmatrix.double().t()
+    check_depth_keys(keys, hip_out[1], inp["means3D"] @ view[2, :3] + view[2, 3])
+    ref_out, ref_g = run_oracle(inp, s, wc, wd, dtype=torch.float64, depth_sort_key=keys)
     soft = Soft()
     _check_radii(soft, hip_out[1], ref_out[1], name)
     assert int((ref_out[1] > 0).sum()) > (1000 if n < 100000 else 10000), "scene is not visible enough to mean anything"
@@ -176,8 +183,11 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
         vb = f._views[cam.uid]
         s = _oracle_settings(cam, intr)
         x["means2D"].grad = None
+        keys = hip_depth_keys(vb.saved, f._cap, n, H, W, vb.radii)
+        view = s.viewmatrix.t()
+        check_depth_keys(keys, vb.radii.cpu(), inp["means3D"] @ view[2, :3] + view[2, 3])
         col, radii, dep, opa, nt = O.rasterize(x["means3D"], x["means2D"], x["opacities"], shs=x["shs"], scales=x["scales"],
-                                               rotations=x["rotations"], settings=s)
+                                               rotations=x["rotations"], settings=s, depth_sort_key=keys)
         _check_radii(soft, vb.radii.cpu(), radii, f"view {k}")
         a = torch.tensor(float(cam.exposure_a.item()), dtype=torch.float64, requires_grad=True)
         b = torch.tensor(float(cam.exposure_b.item()), dtype=torch.float64, requires_grad=True)
