@@ -4,11 +4,21 @@
 One STEP = one iteration of the keyframe mapping loop (/root/reference/src/mapper.py:414-568) on the synthetic room
 (SURVEY.md 8d): 10 window views + 2 random views rendered forward AND backward through the HIP rasterizer, the
 mapping loss per view, the isotropy regulariser, one Adam step on all Gaussian parameters (6 groups), the xyz lr
-update, and the exposure (keyframe) Adam step.  A mapped keyframe costs 60 such iterations + 1 prune pass
-(configs/splat_slam.yaml:44, mapper.py:1113-1114), so   mapping frames/sec = steps/sec / 61.
+update, and the exposure (keyframe) Adam step.  A mapped keyframe costs 60 such iterations + 1 prune pass (forward +
+backward, no optimiser step: configs/splat_slam.yaml:44, mapper.py:1113-1114), so  mapping frames/sec = steps/sec / 61.
 
-N > 1 (weak scaling): every rank renders its own 12 views of a replicated map; gradients are summed with RCCL and the
-Adam step runs on the summed gradient -- a 12*N-view batch per step.  value = N * steps/sec / 61 (keyframe-equivalents/s).
+N > 1, --scaling strong (default): the 12 views of ONE iteration are split round-robin over the ranks -- the reference's
+iteration, parallelised; gradients meet in one RCCL reduce-scatter, Adam runs on each rank's 1/N slice of the Gaussians,
+an all-gather returns the parameters (ZeRO-1).  value = steps/sec / 61, no factor N.
+--scaling weak: every rank renders its own 12 views (a 12*N-view batch per step); value = N * steps/sec / 61.
+
+Besides the headline the line carries (all measured in this run, outside the headline's timed region):
+  roofline            blend_bwd_kernel<true> -- the north-star kernel -- event-timed with the tile kernels UN-fused
+  roofline_fused      the fused tile kernel (forward + loss + backward of a tile in one wave) that the headline runs
+  dropin_keyframes_per_s   the same map() iteration through the drop-in autograd API (GaussianRasterizer per view, reference
+                      loop structure intact, torch.optim.Adam)
+  extra.opaque_scene  the same N with log-scale + 1.6: a converged, surface-covering map (long per-tile lists)
+  cpu_baseline        the oracle on the host cores, one view of the same scene
 
 Prints ONE JSON line (rank 0).
 """
@@ -24,9 +34,12 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-KINDS = ["preprocess_fwd", "tile_scan", "scatter", "unused3", "unused4", "blend_fwd_incl_tile_sort", "unused6", "blend_bwd", "preprocess_bwd"]
+KINDS = ["preprocess_fwd", "tile_scan", "scatter", "blend_fused_fwd_loss_bwd", "unused4", "blend_fwd_incl_tile_sort", "unused6",
+         "blend_bwd", "preprocess_bwd"]
+PK_FUSED, PK_FWD, PK_BWD = 3, 5, 7
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
+HIST_BINS = ["0", "1-4", "5-8", "9-16", "17-32", "33-64", "65-256", ">256"]
 
 
 def trace(msg):
@@ -37,244 +50,318 @@ def trace(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--camera", default="metric", choices=["metric", "replica", "tiny"])
     ap.add_argument("--views", type=int, default=16, help="keyframes in the map (10 window + pool of random views)")
     ap.add_argument("--loop", default="fused", choices=["fused", "autograd"],
-                    help="fused: autograd-free C-ABI sequence (product path); autograd: torch.autograd mirror of the reference loop")
+                    help="fused: autograd-free C-ABI sequence (product path); autograd: the drop-in autograd API per view")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="multi-GPU mode (see the module docstring)")
+    ap.add_argument("--sync", default="zero1", choices=["zero1", "allreduce"],
+                    help="multi-GPU gradient exchange: reduce-scatter + sliced Adam + all-gather, or one all-reduce + replicated Adam")
+    ap.add_argument("--scale-add", type=float, default=0.0, help="added to every log-scale of the room (1.6 = opaque surfaces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the drop-in and opaque-scene legs")
     ap.add_argument("--refine-iters", type=int, default=200, help="final_refine iterations timed for refine it/s (0 = skip)")
-    ap.add_argument("--profile-all", action="store_true", help="event-time every kernel kind (adds overhead)")
+    ap.add_argument("--profile-all", action="store_true", help="event-time every kernel kind inside the timed region (adds overhead)")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+class Bench:
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world)
+            self.dist = dist
+        from splat_slam_amd import _native as nat
+        from splat_slam_amd import synthetic as syn
+        self.nat, self.syn, self.lib = nat, syn, nat.lib()
+        self.intr = syn.INTRINSICS[args.camera]
 
-    from splat_slam_amd import _native as nat
-    from splat_slam_amd import synthetic as syn
-    from splat_slam_amd.mapper import MappingLoop
-    from splat_slam_amd.parallel import GradientSync
-    import diff_gaussian_rasterization as dgr
+    # ------------------------------------------------------------------------------------------------ scene + loop
+    def build(self, loop_kind, scale_add, seed_shift=0):
+        """The room at `scale_add`, `views` keyframes around it, and a mapping loop in the state right after a densification
+        point (149 iterations without map surgery follow: the metric is quoted AT 300k Gaussians)."""
+        import numpy as np
+        from splat_slam_amd.fused import FusedMappingLoop
+        from splat_slam_amd.mapper import MappingLoop
+        args, syn, dev = self.args, self.syn, self.dev
+        torch.manual_seed(43)
+        np.random.seed(43)
+        params = syn.room_parameters(args.gaussians, seed=43, device=dev)
+        if scale_add:
+            params["scaling"] = params["scaling"] + scale_add
+        # strong scaling: every rank holds the SAME views (it renders its share of them); weak: its own set
+        seed = 43 + (self.rank if (self.world > 1 and args.scaling == "weak") else 0) + seed_shift
+        cams = syn.make_views(params, args.views, self.intr, dev, seed=seed)
+        loop = (FusedMappingLoop if loop_kind == "fused" else MappingLoop)(syn.DEFAULT_CONFIG, device=dev)
+        loop.gaussians = syn.model_from_parameters(params, device=dev)
+        loop.viewpoints = {c.uid: c for c in cams}
+        loop.current_window = list(range(min(10, args.views)))
+        loop.build_keyframe_optimizers()
+        loop.iteration_count = 50
+        if self.world > 1:
+            if loop_kind == "fused":
+                loop.set_parallel(self.world, self.rank, split_views=(args.scaling == "strong"), sync=args.sync)
+            else:
+                from splat_slam_amd.parallel import GradientSync
+                loop.grad_sync = GradientSync(loop.gaussians, self.world)
+        return loop, cams
 
-    lib = nat.lib()
-    torch.manual_seed(43)
-    import numpy as np
-    np.random.seed(43)
-
-    intr = syn.INTRINSICS[args.camera]
-    N = args.gaussians
-    params = syn.room_parameters(N, seed=43, device=dev)
-    # every rank maps a different set of views of the same room (weak scaling): rotate the orbit by rank
-    cams = syn.make_views(params, args.views, intr, dev, seed=43 + rank)
-    from splat_slam_amd.fused import FusedMappingLoop
-    loop = (FusedMappingLoop if args.loop == "fused" else MappingLoop)(syn.DEFAULT_CONFIG, device=dev)
-    loop.gaussians = syn.model_from_parameters(params, device=dev)
-    loop.viewpoints = {c.uid: c for c in cams}
-    loop.current_window = list(range(min(10, args.views)))
-    loop.build_keyframe_optimizers()
-    # keep the workload stationary: densify_and_prune fires when iteration_count % 150 == 50 (mapper.py:531-541) and
-    # would change N (the metric is quoted AT 300k Gaussians); start right after such a point -> 149 clean iterations
-    loop.iteration_count = 50
-    if world > 1:
-        if args.loop == "fused":
-            loop.world = world                                  # flat accumulator buffer, one all-reduce per step
-        else:
-            loop.grad_sync = GradientSync(loop.gaussians, world)
-
-    def steps(k):
-        # exactly k iterations of the mapping loop, driven the way the reference drives it: map(window, iters=...) calls
-        # (mapper.py:1113 uses iters=60; here up to 90 per call so that any --steps stays clear of the densification
-        # points, see above); per-call bookkeeping is paid once per call, as in the reference
+    @staticmethod
+    def run_steps(loop, k):
+        """Exactly k iterations, driven the way the reference drives them: map(window, iters=...) calls (mapper.py:1113 uses
+        iters=60; here up to 90 per call so that any k stays clear of the densification points)."""
         while k > 0:
             n = min(k, 90)
             loop.iteration_count = 50
             loop.map(loop.current_window, iters=n)
             k -= n
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
         torch.cuda.synchronize()
 
-    trace("setup done")
-    if args.warmup:
-        steps(args.warmup)
-    barrier()
-    trace("warmup done")
-    mask = (1 << 7) if not args.profile_all else (1 << len(KINDS)) - 1
-    lib.sgr_profile_enable(mask)            # HIP events around blend_bwd only (12 pairs per step) on the launch stream
-    t0 = time.perf_counter()
-    steps(args.steps)
-    host_issue = time.perf_counter() - t0          # time the host needed to ENQUEUE the steps (no sync inside)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    trace("timed loop done")
-    ms = (C.c_float * len(KINDS))()
-    cnt = (C.c_int64 * len(KINDS))()
-    lib.sgr_profile_read(ms, cnt)
-    lib.sgr_profile_enable(0)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(self, loop, steps):
+        """(elapsed seconds MAX over ranks, seconds the host needed to enqueue)."""
+        self.barrier()
+        t0 = time.perf_counter()
+        self.run_steps(loop, steps)
+        host_issue = time.perf_counter() - t0
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, host_issue
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    views_per_step = len(loop.current_window) + min(2, args.views - len(loop.current_window))
-    value = world * (args.steps / elapsed) / 61.0
+    def profiled(self, loop, steps, mask, fused_blend):
+        """HIP-event times (on the launch stream) of the kernel kinds in `mask` over `steps` iterations."""
+        lib, nat = self.lib, self.nat
+        lib.sgr_set_option(nat.SGR_OPT_FUSED_BLEND, int(fused_blend))
+        try:
+            self.run_steps(loop, 3)
+            torch.cuda.synchronize()
+            lib.sgr_profile_enable(mask)
+            self.run_steps(loop, steps)
+            torch.cuda.synchronize()
+            ms = (C.c_float * len(KINDS))()
+            cnt = (C.c_int64 * len(KINDS))()
+            lib.sgr_profile_read(ms, cnt)
+        finally:
+            lib.sgr_profile_enable(0)
+            lib.sgr_set_option(nat.SGR_OPT_FUSED_BLEND, 1)
+        return {i: (float(ms[i]) / max(1, int(cnt[i])), int(cnt[i])) for i in range(len(KINDS))}
 
-    # ---- single-render timings + work counters (outside the timed region)
-    from splat_slam_amd.renderer import render
-    from splat_slam_amd.mapper import PipelineParams
-    bg = loop.background
-    cam0 = cams[0]
-
-    def timed(fn, reps=10):
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - a) / reps
-
-    def fwd_only():
-        with torch.no_grad():
-            render(cam0, loop.gaussians, PipelineParams(), bg)
-
-    def fwd_bwd():
-        pkg = render(cam0, loop.gaussians, PipelineParams(), bg)
-        loss = loop.loss_fn(loop.config["mapping"], pkg["render"], pkg["depth"], cam0, pkg["opacity"])
-        loss.backward()
-        loop.gaussians.optimizer.zero_grad(set_to_none=True)
-
-    trace("profile read")
-    fwd_only(); torch.cuda.synchronize(); trace("fwd_only ok"); fwd_bwd(); torch.cuda.synchronize(); trace("fwd_bwd ok")
-    render_fwd_ms = timed(fwd_only)
-    trace("timed fwd ok")
-    render_fwd_bwd_ms = timed(fwd_bwd)
-    trace("timed fwd_bwd ok")
-    render_fused_ms = None
-    if args.loop == "fused":       # the loop's own forward-only render (persistent buffers, no host sync): keyframe selection
-        loop.render_forward(cam0)
-        render_fused_ms = timed(lambda: loop.render_forward(cam0), reps=50)
-
-    # ---- work counters of the views of the last timed step (saved blocks of the fused loop; one sync each)
-    stats = (C.c_int64 * 4)()
-    HW = intr["H"] * intr["W"]
-    assert loop.gaussians.get_xyz.shape[0] == N, "N changed during the benchmark"
-    per_view = []
-    if args.loop == "fused":
+    def work_counters(self, loop):
+        """(V, R, R_eff, non-empty tiles) of every view of the last iteration + walked-list histogram of the last one."""
+        nat, lib, intr = self.nat, self.lib, self.intr
+        N = loop.gaussians.get_xyz.shape[0]
+        stats, per_view = (C.c_int64 * 4)(), []
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
         for cam in loop.last_used:
             vb = loop._views[cam.uid]
             ws = nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), loop._cap)
-            nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], vb.radii.data_ptr(), stats,
-                                          torch.cuda.current_stream(dev).cuda_stream), "sgr_query_stats")
+            nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], vb.radii.data_ptr(), stats, stream), "sgr_query_stats")
             per_view.append([int(x) for x in stats])
         hist = (C.c_int64 * 8)()
-        nat.check(lib.sgr_query_list_histogram(C.byref(ws), N, intr["H"], intr["W"], hist, torch.cuda.current_stream(dev).cuda_stream),
-                  "sgr_query_list_histogram")
-        list_hist = dict(zip(["0", "1-4", "5-8", "9-16", "17-32", "33-64", "65-256", ">256"], [int(x) for x in hist]))
-    else:
-        list_hist = None
-        pkg = render(cam0, loop.gaussians, PipelineParams(), bg)
-        fn = pkg["render"].grad_fn
-        saved = fn.saved_tensors[-1]
-        st = dgr._state(dev)
-        ws = nat.SgrWorkspace(saved.data_ptr(), saved.numel(), st.scratch.data_ptr(), st.scratch.numel(), fn.capacity)
-        nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], pkg["radii"].data_ptr(), stats,
-                                      torch.cuda.current_stream(dev).cuda_stream), "sgr_query_stats")
-        per_view.append([int(x) for x in stats])
-    trace("stats ok")
-    # ---- final-refinement throughput (mapper.py:656-708: ONE random view fwd+bwd + Adam on all N per iteration);
-    # measured after the counters were read because it keeps optimising the map.  Outside the headline timed region.
-    refine_its = None
-    if args.loop == "fused" and args.refine_iters > 0:
-        loop.final_refine(iters=5)
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        loop.final_refine(iters=args.refine_iters)
-        torch.cuda.synchronize()
-        refine_its = args.refine_iters / (time.perf_counter() - a)
-        trace("refine ok")
-    nv = len(per_view)
-    V = sum(p[0] for p in per_view) // nv
-    R = sum(p[1] for p in per_view) // nv
-    R_eff_sum = sum(p[2] for p in per_view)
-    tiles_nonempty = sum(p[3] for p in per_view) // nv
+        nat.check(lib.sgr_query_list_histogram(C.byref(ws), N, intr["H"], intr["W"], hist, stream), "sgr_query_list_histogram")
+        return per_view, dict(zip(HIST_BINS, [int(x) for x in hist]))
 
-    # ---- roofline of the dominant kernel (tile-blend backward).  One launch covers `views_in_launch` views (batched).
-    bwd_launches = int(cnt[7])
-    bwd_ms = float(ms[7]) / max(1, bwd_launches)
-    views_in_launch = nv if args.loop == "fused" else 1
-    r_eff_launch = R_eff_sum if args.loop == "fused" else per_view[0][2]
-    alg_bytes = 84 * r_eff_launch + (24 * HW + 40 * N) * views_in_launch          # SURVEY.md 8d figure
-    # what this design moves: 92 B per pair; per pixel 9 B in the fused loop (final_T, n_contrib, one code byte of
-    # loss-gradient signs) or 24 B through the autograd API (float gradients)
-    own_bytes = 92 * r_eff_launch + (9 if args.loop == "fused" else 24) * HW * views_in_launch
-    achieved = alg_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-    pair_evals = r_eff_launch * 64               # (pixel, splat) pairs the kernel evaluates
-    valu_tflops = pair_evals * 60 / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
-    traffic = None
-    try:                                         # PMC pass of this same command, committed under profiles/
-        pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_hbm_bytes.json")))
-        if pm.get("workload") == [N, intr["W"], intr["H"], views_in_launch]:
-            name = "sgr::blend_bwd_kernel<true>" if args.loop == "fused" else "sgr::blend_bwd_kernel<false>"
-            traffic = pm["kernels"][name]["hbm_bytes_per_launch_corrected"]
-    except Exception:
-        pass
-    roofline = {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "avg_launch_ms": round(bwd_ms, 5), "launches": bwd_launches, "views_per_launch": views_in_launch,
-                "algorithmic_bytes": alg_bytes, "own_formula_bytes": own_bytes,
+    def rooflines(self, loop, per_view, steps):
+        """blend_bwd (un-fused leg) and the fused tile kernel, each against its SURVEY.md 8d algorithmic bytes."""
+        intr, N = self.intr, loop.gaussians.get_xyz.shape[0]
+        HW, nv = intr["H"] * intr["W"], len(per_view)
+        r_eff = sum(p[2] for p in per_view)
+        unf = self.profiled(loop, steps, (1 << PK_FWD) | (1 << PK_BWD), fused_blend=False)
+        fus = self.profiled(loop, steps, 1 << PK_FUSED, fused_blend=True)
+        bwd_ms, bwd_n = unf[PK_BWD]
+        fwd_ms, _ = unf[PK_FWD]
+        fus_ms, fus_n = fus[PK_FUSED]
+        bytes_bwd = 84 * r_eff + (24 * HW + 40 * N) * nv                       # SURVEY.md 8d
+        bytes_fwd = 48 * r_eff + 28 * HW * nv
+        bytes_fused = bytes_bwd + bytes_fwd
+        own_bytes = 92 * r_eff + 9 * HW * nv          # what the un-fused backward of this design moves (DESIGN.md 3)
+        pair_evals = r_eff * 64
+        gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        try:                                          # PMC pass of this same command, committed under profiles/
+            pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_hbm_bytes.json")))
+            if pm.get("workload") == [N, intr["W"], intr["H"], nv]:
+                traffic = pm["kernels"]["sgr::blend_bwd_kernel<true>"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            pass
+        a = gbs(bytes_bwd, bwd_ms)
+        roof = {"kernel": "blend_bwd_kernel<true>", "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(bwd_ms, 5), "launches": bwd_n,
+                "views_per_launch": nv, "algorithmic_bytes": bytes_bwd, "own_formula_bytes": own_bytes,
                 "pixel_splat_pairs_per_launch": pair_evals,
-                "valu_frac_at_60flop_per_pair": round(valu_tflops / FP32_PEAK_TFLOPS, 4),
-                "note": "splat-list blending is VALU-issue bound (DESIGN.md 3): HBM fraction is small by construction"}
+                "valu_frac_at_60flop_per_pair": round(pair_evals * 60 / (bwd_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if bwd_ms > 0 else 0.0,
+                "blend_fwd_avg_launch_ms": round(fwd_ms, 5),
+                "note": "measured with SGR_OPT_FUSED_BLEND=0 (the two tile kernels launched separately) in this run; the headline "
+                        "runs them fused (roofline_fused). Splat-list blending is VALU-issue bound (DESIGN.md 3): the HBM "
+                        "fraction is small by construction"}
+        af = gbs(bytes_fused, fus_ms)
+        roof_f = {"kernel": "blend_fwd_kernel<*, FUSED=true> (forward + loss + backward of a tile in one wave)", "bound": "hbm",
+                  "achieved": round(af, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(af / HBM_PEAK_GBS, 5), "traffic": None,
+                  "avg_launch_ms": round(fus_ms, 5), "launches": fus_n, "views_per_launch": nv, "algorithmic_bytes": bytes_fused,
+                  "unfused_pair_avg_launch_ms": round(fwd_ms + bwd_ms, 5)}
+        return roof, roof_f
+
+    # ------------------------------------------------------------------------------------------------ legs
+    def dropin_leg(self, steps=6):
+        """The same map() iteration through the drop-in autograd API: splat_slam_amd.mapper.MappingLoop keeps the reference's
+        loop structure (render() per view -> GaussianRasterizer, loss, backward, torch.optim.Adam)."""
+        loop, cams = self.build("autograd", self.args.scale_add)
+        self.run_steps(loop, 3)
+        el, host = self.timed(loop, steps)
+        views = len(loop.current_window) + min(2, self.args.views - len(loop.current_window))
+        ms_it = 1e3 * el / steps
+        return {"dropin_keyframes_per_s": round((steps / el) / 61.0, 3), "ms_per_iteration": round(ms_it, 3),
+                "ms_per_view_fwd_loss_bwd_incl_adam_share": round(ms_it / views, 4),
+                "host_enqueue_ms_per_iteration": round(1e3 * host / steps, 3), "views_per_iteration": views}, loop, cams
+
+    def scene_leg(self, scale_add, steps=40):
+        loop, cams = self.build("fused", scale_add)
+        self.run_steps(loop, 10)
+        el, _ = self.timed(loop, steps)
+        per_view, hist = self.work_counters(loop)
+        roof, roof_f = self.rooflines(loop, per_view, 20)
+        nv = len(per_view)
+        return {"scale_add": scale_add, "ms_per_step": round(1e3 * el / steps, 4), "keyframes_per_s": round((steps / el) / 61.0, 3),
+                "visible_gaussians": sum(p[0] for p in per_view) // nv, "tile_pairs_R": sum(p[1] for p in per_view) // nv,
+                "tile_pairs_walked_R_eff": sum(p[2] for p in per_view) // nv, "tiles_by_walked_list_length_last_view": hist,
+                "blend_bwd_frac": roof["frac"], "blend_bwd_avg_launch_ms": roof["avg_launch_ms"],
+                "blend_fwd_avg_launch_ms": roof["blend_fwd_avg_launch_ms"], "fused_tile_kernel_avg_launch_ms": roof_f["avg_launch_ms"],
+                "fused_tile_kernel_frac": roof_f["frac"]}
+
+
+def main():
+    args = parse()
+    B = Bench(args)
+    world, rank, dev, intr, lib = B.world, B.rank, B.dev, B.intr, B.lib
+    N = args.gaussians
+    loop, cams = B.build(args.loop, args.scale_add)
+    trace("setup done")
+    if args.warmup:
+        B.run_steps(loop, args.warmup)
+    trace("warmup done")
+    if args.profile_all:
+        lib.sgr_profile_enable((1 << len(KINDS)) - 1)
+    elapsed, host_issue = B.timed(loop, args.steps)
+    trace("timed loop done")
+    kernel_ms = None
+    if args.profile_all:
+        ms, cnt = (C.c_float * len(KINDS))(), (C.c_int64 * len(KINDS))()
+        lib.sgr_profile_read(ms, cnt)
+        lib.sgr_profile_enable(0)
+        kernel_ms = {k: round(float(ms[i]) / max(1, int(cnt[i])), 5) for i, k in enumerate(KINDS) if int(cnt[i])}
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    views_per_step = len(loop.current_window) + min(2, args.views - len(loop.current_window))
+    weak = world > 1 and args.scaling == "weak"
+    value = (world if weak else 1) * (args.steps / elapsed) / 61.0
+    assert loop.gaussians.get_xyz.shape[0] == N, "N changed during the benchmark"
 
     out = {
         "metric": "mapping frames/sec + render ms @640x480, 300k Gaussians; PSNR vs ref",
         "value": round(value, 4), "unit": "mapped keyframes/s (61 map() iterations each)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
         "config": {"workload": "configs[1]-shaped: synthetic room (SURVEY 8d), %d Gaussians, %dx%d, %d views/step "
-                               "(10 window + 2 random) fwd+bwd + loss + isotropy + Adam, 1xMI355X per rank"
-                               % (N, intr["W"], intr["H"], views_per_step),
-                   "gaussians": N, "width": intr["W"], "height": intr["H"], "views_per_step": views_per_step, "loop": args.loop,
-                   "parallelism": "view-parallel x%d, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
+                               "(10 window + 2 random) fwd+bwd + loss + isotropy + Adam%s"
+                               % (N, intr["W"], intr["H"], views_per_step * (world if weak else 1),
+                                  "" if world == 1 else ("; views split over %d ranks" % world if not weak else "; %d views per rank" % views_per_step)),
+                   "gaussians": N, "width": intr["W"], "height": intr["H"], "views_per_step": views_per_step * (world if weak else 1),
+                   "loop": args.loop, "scale_add": args.scale_add,
+                   "parallelism": "single GPU" if world == 1 else
+                   ("view-parallel x%d, %s" % (world, "RCCL reduce-scatter + Adam on 1/%d of the Gaussians + all-gather (ZeRO-1)" % world
+                                                 if args.sync == "zero1" else "one RCCL all-reduce of the flat gradient buffer"))},
         "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4),
-        "render_ms": {"forward": round(render_fwd_ms, 4), "forward_backward_loss": round(render_fwd_bwd_ms, 4),
-                      "forward_fused_loop": None if render_fused_ms is None else round(render_fused_ms, 4),
-                      "note": "forward / forward_backward_loss: one view through the drop-in autograd API (one host sync per "
-                              "forward, like upstream); forward_fused_loop: FusedMappingLoop.render_forward, no sync"},
         "map_iterations_per_s": round(args.steps / elapsed, 2),
-        "refine_iterations_per_s": None if refine_its is None else round(refine_its, 1),
-        "work_per_view": {"visible_gaussians": V, "tile_pairs_R": R, "tile_pairs_walked_R_eff": R_eff_sum // nv,
-                          "nonempty_tiles": tiles_nonempty, "tiles_by_walked_list_length_last_view": list_hist},
-        "roofline": roofline,
     }
-    if args.profile_all:
-        out["kernel_ms"] = {k: round(float(ms[i]) / max(1, int(cnt[i])), 5) for i, k in enumerate(KINDS)}
+    if kernel_ms is not None:
+        out["kernel_ms"] = kernel_ms
 
-    # ---- CPU baseline: the oracle (a port, not the reference: the reference has no CPU path) on the host cores
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(loop, cam0, intr, views_per_step)
+    if args.loop == "fused":
+        per_view, hist = B.work_counters(loop)
+        nv = len(per_view)
+        out["work_per_view"] = {"visible_gaussians": sum(p[0] for p in per_view) // nv, "tile_pairs_R": sum(p[1] for p in per_view) // nv,
+                                "tile_pairs_walked_R_eff": sum(p[2] for p in per_view) // nv,
+                                "nonempty_tiles": sum(p[3] for p in per_view) // nv, "views_in_last_launch": nv,
+                                "tiles_by_walked_list_length_last_view": hist}
+    if args.loop == "fused" and world == 1:
+        roof, roof_f = B.rooflines(loop, per_view, 30)
+        out["roofline"], out["roofline_fused"] = roof, roof_f
+        trace("rooflines done")
+        # ---- single-render timings through the drop-in autograd API + the loop's own forward-only render
+        from splat_slam_amd.mapper import PipelineParams
+        from splat_slam_amd.renderer import render
+        cam0, bg = cams[0], loop.background
+
+        def rep(fn, reps=20):
+            fn()
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - a) / reps
+
+        def fwd_only():
+            with torch.no_grad():
+                render(cam0, loop.gaussians, PipelineParams(), bg)
+
+        def fwd_bwd():
+            pkg = render(cam0, loop.gaussians, PipelineParams(), bg)
+            loop.loss_fn(loop.config["mapping"], pkg["render"], pkg["depth"], cam0, pkg["opacity"]).backward()
+            loop.gaussians.optimizer.zero_grad(set_to_none=True)
+
+        out["render_ms"] = {"forward": round(rep(fwd_only), 4), "forward_backward_loss": round(rep(fwd_bwd), 4),
+                            "forward_fused_loop": round(rep(lambda: loop.render_forward(cam0), 50), 4),
+                            "note": "forward / forward_backward_loss: ONE view through the drop-in autograd API (no host "
+                                    "synchronisation, pooled workspaces); forward_fused_loop: FusedMappingLoop.render_forward"}
+        if args.refine_iters > 0:     # mapper.py:656-708: ONE random view fwd+bwd + Adam on all N per iteration
+            loop.final_refine(iters=5)
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            loop.final_refine(iters=args.refine_iters)
+            torch.cuda.synchronize()
+            out["refine_iterations_per_s"] = round(args.refine_iters / (time.perf_counter() - a), 1)
+        trace("render/refine done")
+        if not args.no_extras:
+            del loop
+            torch.cuda.empty_cache()
+            drop, dloop, dcams = B.dropin_leg()
+            out["dropin_keyframes_per_s"] = drop.pop("dropin_keyframes_per_s")
+            out["dropin"] = drop
+            trace("dropin done")
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(dloop, dcams[0], intr, views_per_step)
+            del dloop, dcams
+            torch.cuda.empty_cache()
+            out["extra"] = {"opaque_scene": B.scene_leg(args.scale_add + 1.6)}
+            trace("opaque done")
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(loop, cams[0], intr, views_per_step)
 
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if B.dist is not None:
+        B.dist.destroy_process_group()
 
 
 def usable_cores():

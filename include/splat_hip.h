@@ -18,7 +18,8 @@
  *                             thirdparty/gaussian_splatting/scene/gaussian_model.py:264-313, stepped at
  *                             src/mapper.py:352,557,703
  *   sgr_activate,
- *   sgr_gaussian_adam_step -> the activation getters (exp / normalize / sigmoid, gaussian_model.py:76-101) and the Adam step of
+ *   sgr_gaussian_adam_step,
+ *   sgr_gaussian_adam_shard -> the activation getters (exp / normalize / sigmoid, gaussian_model.py:76-101) and the Adam step of
  *                             the five per-Gaussian groups incl. the isotropy regulariser of src/mapper.py:487-489
  *   sgr_masked_adam        -> the keyframe (exposure) optimiser of src/mapper.py:1096-1111, stepped at :561
  *   sgr_map_views          -> the per-view body of Mapper.map (src/mapper.py:426-490): render, loss, backward for <= 16 views
@@ -164,6 +165,12 @@ int sgr_backward(const SgrSettings* settings, const SgrInputs* in, const int32_t
 /* Synchronous read-back of (pair count, overflow flag) from a saved block produced by sgr_forward. */
 int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_host, void* stream);
 
+/* Asynchronous variant: enqueues a 64-byte copy of the saved block's header (uint32 words: [0] pair count R, [1] overflow
+ * flag, [2] pairs binned, [3] visible Gaussians, [4] over-full tiles, [5..15] zero) into PINNED host memory on `stream`.
+ * The caller pre-sets word 15 to a non-zero sentinel and knows the copy has landed when it reads 0 there: a later call can
+ * then learn R without ever waiting (the drop-in package sizes its capacity this way). */
+int sgr_header_to_host(const void* saved, void* pinned_host64, void* stream);
+
 /* Work counters of one forward, read back synchronously (bench / roofline accounting only):
  *   stats[0] = V  Gaussians with radii > 0          stats[1] = R  (tile, Gaussian) pairs binned
  *   stats[2] = R_eff = sum over tiles of min(list length, last contributor): pairs the blend kernels walk
@@ -237,6 +244,14 @@ typedef struct SgrAdamGroup {
 } SgrAdamGroup;
 int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps,
                            float iso_weight, void* stream);
+
+/* The same step for a SLICE of the optimiser (multi-GPU ZeRO-1, SURVEY.md 8e: gradients reduce-scattered over the ranks,
+ * every rank steps the rows it owns, parameters all-gathered afterwards): group k is stepped for the Gaussians
+ * row0[k] <= i < row1[k] only; its four pointers still address ROW 0 of the (virtual) full arrays and are only
+ * dereferenced inside that range, so `grad` may point into a rank-local shard buffer.  The isotropy term is normalised by
+ * n_total (the whole map).  No activations are written: the caller re-activates after its all-gather. */
+int sgr_gaussian_adam_shard(int64_t n_total, const SgrAdamGroup groups[5], const int64_t row0[5], const int64_t row1[5],
+                            float beta1, float beta2, float eps, float iso_weight, void* stream);
 
 /* One mapping-loop view: render, mapping loss and its gradient, backward (src/mapper.py:426-456 for one viewpoint).
  * sgr_map_views runs the sequence  sgr_forward(async) -> sgr_mapping_loss -> sgr_backward  for `num_views` views

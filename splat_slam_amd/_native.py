@@ -97,6 +97,7 @@ SIGNATURES = {
     "sgr_backward": (C.c_int, [C.POINTER(SgrSettings), C.POINTER(SgrInputs), _fp, C.POINTER(SgrGradOutputs),
                                C.POINTER(SgrGradInputs), C.POINTER(SgrWorkspace), _fp]),
     "sgr_query": (C.c_int, [_fp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _fp]),
+    "sgr_header_to_host": (C.c_int, [_fp, _fp, _fp]),
     "sgr_query_stats": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(C.c_int64), _fp]),
     "sgr_query_depth_keys": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp]),
     "sgr_query_list_histogram": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _fp]),
@@ -110,6 +111,8 @@ SIGNATURES = {
                                 C.c_int64, _fp]),
     "sgr_activate": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sgr_gaussian_adam_step": (C.c_int, [C.c_int64, C.POINTER(SgrAdamGroup), C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
+    "sgr_gaussian_adam_shard": (C.c_int, [C.c_int64, C.POINTER(SgrAdamGroup), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                          C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
     "sgr_map_views": (C.c_int, [C.c_int32, C.POINTER(SgrMapView), C.POINTER(SgrInputs), C.POINTER(SgrGradInputs),
                                 C.c_float, C.c_float, C.c_int32, _fp]),
     "sgr_map_step": (C.c_int, [C.POINTER(SgrMapStep), _fp]),

@@ -564,6 +564,12 @@ int sgr_profile_read(float ms_host[SGR_PROFILE_KINDS], int64_t launches_host[SGR
   return SGR_OK;
 }
 
+int sgr_header_to_host(const void* saved, void* pinned_host64, void* stream) {
+  if (!saved || !pinned_host64) return set_error(SGR_ERR_INVALID, "null argument");
+  HIP_TRY(hipMemcpyAsync(pinned_host64, saved, sizeof(SavedHeader), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return SGR_OK;
+}
+
 int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_host, void* stream) {
   if (!saved) return set_error(SGR_ERR_INVALID, "null saved block");
   SavedHeader h;

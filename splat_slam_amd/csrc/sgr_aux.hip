@@ -6,6 +6,8 @@
 // All are HBM-streaming or tiny; each is a single pass with fixed-order reductions (bitwise reproducible).
 #include <cmath>
 
+#include <cstdint>
+
 #include "sgr_common.h"
 
 namespace sgr {
@@ -204,6 +206,7 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
 #pragma unroll
   for (int grp = 0; grp < 2; ++grp) {
     const SgrAdamGroup& A = G.g[grp];
+    if (i < G.r0[grp] || i >= G.r1[grp]) continue;
     float g[3];
     if (MODE == 2) {
       g[0] = e[3 * grp]; g[1] = e[3 * grp + 1]; g[2] = e[3 * grp + 2];
@@ -222,7 +225,7 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
     st3(A.exp_avg + 3 * i, F3{m[0], m[1], m[2]});
     st3(A.exp_avg_sq + 3 * i, F3{v[0], v[1], v[2]});
   }
-  {   // opacity: sigmoid
+  if (i >= G.r0[2] && i < G.r1[2]) {   // opacity: sigmoid
     const SgrAdamGroup& A = G.g[2];
     float p = A.param[i];
     float sg = 1.f / (1.f + expf(-p));
@@ -234,7 +237,7 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
     }
     if (o_out) o_out[i] = 1.f / (1.f + expf(-p));
   }
-  {   // scaling: exp, plus d/ds of iso_weight * mean_{N,3} |s - mean_3(s)|
+  if (i >= G.r0[3] && i < G.r1[3]) {   // scaling: exp, plus d/ds of iso_weight * mean_{N,3} |s - mean_3(s)|
     const SgrAdamGroup& A = G.g[3];
     const F3 p3 = ld3(A.param + 3 * i);
     float p[3] = {p3.x, p3.y, p3.z}, s[3];
@@ -268,7 +271,7 @@ __device__ __forceinline__ void gaussian_adam_one(int64_t i, const AdamGroups& G
     }
     if (s_out) st3(s_out + 3 * i, F3{expf(p[0]), expf(p[1]), expf(p[2])});
   }
-  {   // rotation: x / max(|x|, 1e-12)
+  if (i >= G.r0[4] && i < G.r1[4]) {   // rotation: x / max(|x|, 1e-12)
     const SgrAdamGroup& A = G.g[4];
     float4 x = *(const float4*)(A.param + 4 * i);
     float4 gy;
@@ -603,6 +606,8 @@ int make_fused_adam(int64_t n, const SgrAdamGroup groups[5], float beta1, float 
   fa.c.b1 = beta1; fa.c.b2 = beta2; fa.c.eps = eps;
   for (int k = 0; k < 5; ++k) {
     fa.G.g[k] = groups[k];
+    fa.G.r0[k] = 0;
+    fa.G.r1[k] = INT64_MAX;
     const SgrAdamGroup& g = fa.G.g[k];
     if (!g.grad || !g.param || (!g.skip && (!g.exp_avg || !g.exp_avg_sq || g.step < 1)))
       return set_error(SGR_ERR_INVALID, "gaussian_adam: null pointer / bad step in group %d", k);
@@ -665,6 +670,35 @@ int sgr_activate(int64_t n, const float* scaling, const float* rotation, const f
 int sgr_gaussian_adam_step(int64_t n, const SgrAdamGroup groups[5], float beta1, float beta2, float eps, float iso_weight,
                            void* stream) {
   return gaussian_adam_step_act(n, groups, beta1, beta2, eps, iso_weight, nullptr, nullptr, nullptr, stream);
+}
+
+int sgr_gaussian_adam_shard(int64_t n_total, const SgrAdamGroup groups[5], const int64_t row0[5], const int64_t row1[5],
+                            float beta1, float beta2, float eps, float iso_weight, void* stream) {
+  if (n_total < 0 || !groups || !row0 || !row1) return set_error(SGR_ERR_INVALID, "gaussian_adam_shard: bad argument");
+  SgrAdamGroup g[5];
+  int64_t lo = INT64_MAX, hi = 0;
+  for (int k = 0; k < 5; ++k) {
+    g[k] = groups[k];
+    if (row0[k] < 0 || row1[k] > n_total) return set_error(SGR_ERR_INVALID, "gaussian_adam_shard: rows of group %d outside [0, n]", k);
+    if (row1[k] <= row0[k]) { g[k].skip = 1; if (!g[k].param) g[k].param = (float*)8; if (!g[k].grad) g[k].grad = (float*)8; continue; }
+    lo = row0[k] < lo ? row0[k] : lo;
+    hi = row1[k] > hi ? row1[k] : hi;
+  }
+  if (hi <= lo) return SGR_OK;
+  FusedAdam fa;
+  if (int rc = make_fused_adam(n_total, g, beta1, beta2, eps, iso_weight, &fa)) return rc;
+  for (int k = 0; k < 5; ++k) { fa.G.r0[k] = row0[k] - lo; fa.G.r1[k] = (row1[k] > row0[k] ? row1[k] : row0[k]) - lo; }
+  // thread t works on Gaussian lo + t: shift every base pointer instead of the index
+  const int w[5] = {3, 3, 1, 3, 4};
+  for (int k = 0; k < 5; ++k) {
+    SgrAdamGroup& A = fa.G.g[k];
+    A.param += lo * w[k]; A.grad += lo * w[k];
+    if (A.exp_avg) A.exp_avg += lo * w[k];
+    if (A.exp_avg_sq) A.exp_avg_sq += lo * w[k];
+  }
+  hipLaunchKernelGGL(gaussian_adam_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, (hipStream_t)stream, hi - lo, fa.G,
+                     fa.c, fa.iso_coef, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "gaussian_adam_shard launch failed");
 }
 
 int sgr_masked_adam(int32_t rows, int32_t row_width, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

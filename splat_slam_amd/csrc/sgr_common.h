@@ -136,7 +136,7 @@ struct Layout {
     while ((1ll << tile_bits) < (long long)ntiles + 1) ++tile_bits;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
-    size_t n = (size_t)(N > 0 ? N : 1), hw = (size_t)H * W, c = (size_t)(cap > 0 ? cap : 1);
+    size_t n = (size_t)(N > 0 ? N : 1), c = (size_t)(cap > 0 ? cap : 1);
     pre_blocks = (N + 255) / 256;
     nseg = (N + kSeg - 1) / kSeg;
     size_t nb = (size_t)(pre_blocks > 0 ? pre_blocks : 1);
@@ -206,7 +206,9 @@ struct LossCoef { float w_rgb, w_dep, thr; };
 
 // ---- Adam constants of one step (host side computes the bias corrections in double like torch.optim.Adam does)
 struct AdamConst { float b1, b2, eps; float bc2_sqrt[5], step_size[5]; };
-struct AdamGroups { SgrAdamGroup g[5]; };   // xyz, f_dc, opacity, scaling, rotation
+// xyz, f_dc, opacity, scaling, rotation.  Group k is stepped for Gaussians r0[k] <= i < r1[k] only (the whole map unless a
+// rank owns a slice of the optimiser: sgr_gaussian_adam_shard); outside that range its pointers are never dereferenced.
+struct AdamGroups { SgrAdamGroup g[5]; int64_t r0[5], r1[5]; };
 // gradient gather (over the views of a batch) + activation chain rule + isotropy + Adam + next activations in ONE
 // pass over the Gaussians: the tail of a single-GPU mapping iteration
 struct FusedAdam {

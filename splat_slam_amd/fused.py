@@ -173,8 +173,13 @@ class FusedMappingLoop(MappingLoop):
         self._proj_raw = {}
         self._plan_key = None
         self._plan_obj = None
-        self.world = 1              # ranks exchanging gradients (set by the multi-GPU driver together with dist_group)
-        self.dist_group = None
+        # multi-GPU (set_parallel): ranks of one node share the views of an iteration and exchange gradients over RCCL
+        self.world, self.rank = 1, 0
+        self.split_views = True      # strong scaling: view v of an iteration is rendered by rank v mod world
+        self.sync = "zero1"          # "zero1": reduce-scatter + Adam on 1/world of the optimiser + all-gather; "allreduce"
+        self.comm = None
+        self._zero = None            # parallel.Zero1Plan + flat parameter / moment / shard buffers (sync == "zero1")
+        self._replicated = 0         # > 0: every rank runs the identical iteration, no exchange (initialize_map, final_refine)
         self._acc_ids = None        # id() of the five parameter tensors the sinks belong to
         self._stale_iso = 0.0       # isotropy weight whose gradient a prune pass left on the current `_scaling` tensor
 
@@ -185,10 +190,28 @@ class FusedMappingLoop(MappingLoop):
         self._plan_key = self._plan_obj = None
 
     # ------------------------------------------------------------------------------------------------ state
-    def _all_reduce_sum(self, t):
-        """RCCL all-reduce of the flat gradient buffer (backend "nccl" is RCCL on ROCm; it rides xGMI inside a node)."""
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dist_group)
+    def set_parallel(self, world, rank, split_views=True, sync="zero1", comm=None):
+        """Makes this loop one of `world` ranks that map the SAME keyframes of a replicated map (one process per GPU,
+        torch.distributed initialised by the caller; backend "nccl" is RCCL on ROCm and rides xGMI inside a node).
+
+        split_views  True: the views of one iteration are dealt round-robin to the ranks (the reference's iteration in
+                     parallel, mapper.py:426-490: <= 12 views, so <= 12 ranks have work); False: every rank renders all the
+                     views it is given (the caller hands each rank its own: a world-times larger batch per step).
+        sync         "zero1": gradients are reduce-scattered, every rank runs Adam on the rows it owns (1/world of the
+                     optimiser state is touched per rank) and the parameters are all-gathered -- SURVEY.md 8e;
+                     "allreduce": one all-reduce of the flat gradient buffer, replicated Adam."""
+        from splat_slam_amd.parallel import Comm
+        assert sync in ("zero1", "allreduce")
+        self.world, self.rank, self.split_views, self.sync = int(world), int(rank), bool(split_views), sync
+        self.comm = comm if comm is not None else Comm()
+        self._acc_key = None            # buffers are laid out per world size
+
+    def _parallel(self):
+        return self.world > 1 and self._replicated == 0
+
+    def _local(self, cams):
+        """The views of an iteration this rank renders."""
+        return list(cams[self.rank::self.world]) if (self._parallel() and self.split_views) else list(cams)
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -202,22 +225,33 @@ class FusedMappingLoop(MappingLoop):
         if self._acc_key == key and self._acc is not None:
             # same N, some tensors replaced (opacity reset, map deformation: replace_tensor_to_optimizer): the new
             # Parameters have no .grad in the reference, i.e. whatever a prune pass left for THOSE groups is gone
-            for name, old, new in zip(_GROUPS, self._acc_ids, ids):
-                if old != new and not self._acc_clean:
-                    self._acc[name].zero_()
-                if old != new and name == "scaling":
+            changed = [k for k, (old, new) in enumerate(zip(self._acc_ids, ids)) if old != new]
+            for k in changed:
+                if not self._acc_clean:
+                    self._acc[_GROUPS[k]].zero_()
+                if _GROUPS[k] == "scaling":
                     self._stale_iso = 0.0
             self._acc_ids = ids
+            if self._zero is not None:
+                self._rehome(changed)
             return
         N, dev = gm._xyz.shape[0], self.device
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        # the five gradient accumulators are views of ONE flat buffer (14 floats per Gaussian): a multi-GPU step
-        # exchanges it with a single collective (parallel.py), no packing
-        flat = z(N * 14)
-        self._acc = {"flat": flat, "xyz": flat[: 3 * N].view(N, 3), "f_dc": flat[3 * N: 6 * N].view(N, 1, 3),
-                     "opacity": flat[6 * N: 7 * N].view(N, 1), "scaling": flat[7 * N: 10 * N].view(N, 3),
-                     "rotation": flat[10 * N: 14 * N].view(N, 4),
-                     "act_scale": z(N, 3), "act_rot": z(N, 4), "act_opac": z(N, 1)}
+        # the five gradient accumulators are views of ONE flat buffer (14 floats per Gaussian, group-major): a multi-GPU
+        # step exchanges it with a single collective, no packing (parallel.Zero1Plan: rows padded so that equal shards of
+        # the buffer are whole-row segments)
+        from splat_slam_amd.parallel import Zero1Plan
+        plan = Zero1Plan(N, self.world, self.rank)
+        flat = z(plan.total)
+        shapes = {"xyz": (N, 3), "f_dc": (N, 1, 3), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
+        self._acc = {"flat": flat, "act_scale": z(N, 3), "act_rot": z(N, 4), "act_opac": z(N, 1)}
+        for name, shape in shapes.items():
+            self._acc[name] = plan.view(flat, name, shape)
+        self._zero = None
+        if self.world > 1 and self.sync == "zero1":
+            self._zero = {"plan": plan, "param": z(plan.total), "m": z(plan.total), "v": z(plan.total), "shard": z(plan.shard),
+                          "shapes": shapes}
+            self._rehome(range(5))
         self._acc_key, self._acc_ids = key, ids
         self._acc_clean = True     # the gradient sinks are all-zero (every Adam step leaves them so)
         self._stale_iso = 0.0      # (every tensor is new: nothing a prune pass left behind survives)
@@ -231,6 +265,79 @@ class FusedMappingLoop(MappingLoop):
             if st is None or len(st) == 0:
                 gm.optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(p),
                                          "exp_avg_sq": torch.zeros_like(p)}
+
+    def _rehome(self, which):
+        """ZeRO-1: parameters and Adam moments of the given groups become views of the flat buffers the collectives work on
+        (values copied once; the tensors keep their identity, so optimiser state and plans stay valid)."""
+        gm, zr = self.gaussians, self._zero
+        by_name = {g["name"]: g for g in gm.optimizer.param_groups}
+        with torch.no_grad():
+            for k in which:
+                name = _GROUPS[k]
+                p = by_name[name]["params"][0]
+                st = gm.optimizer.state[p]
+                for buf, src, put in ((zr["param"], p.data, lambda t, p=p: setattr(p, "data", t)),
+                                      (zr["m"], st["exp_avg"], lambda t, st=st: st.__setitem__("exp_avg", t)),
+                                      (zr["v"], st["exp_avg_sq"], lambda t, st=st: st.__setitem__("exp_avg_sq", t))):
+                    dst = zr["plan"].view(buf, name, zr["shapes"][name])
+                    dst.copy_(src.reshape(dst.shape))
+                    put(dst.view(src.shape))
+        self._plan_key = None
+
+    def _sync_moments(self):
+        """ZeRO-1: every rank only keeps the moments of its own rows current; before anything looks at (or re-shapes) the
+        whole optimiser state -- map surgery, replicated phases, the end of a map() call -- they are all-gathered."""
+        if self._zero is None or not self._zero.get("stale_moments"):
+            return
+        zr = self._zero
+        lo, hi = zr["plan"].lo, zr["plan"].hi
+        self.comm.all_gather(zr["m"], zr["m"][lo:hi])
+        self.comm.all_gather(zr["v"], zr["v"][lo:hi])
+        zr["stale_moments"] = False
+
+    def _exchange_and_adam(self, pl, iso_weight, skip=()):
+        """Second half of a multi-GPU iteration: the ranks' gradient sums meet, Adam steps, everybody ends with the same
+        parameters and the activations of the next forward.  pl.groups carry lr / step of this iteration."""
+        stream = self._stream()
+        a, gm = self._acc, self.gaussians
+        for k, name in enumerate(_GROUPS):
+            pl.groups[k].skip = int(name in skip)
+        if self._stale_iso and "scaling" not in skip:
+            iso_weight, self._stale_iso = iso_weight + self._stale_iso, 0.0
+        if self._zero is None:
+            self.comm.all_reduce(a["flat"])
+            adam_st = nat.SgrMapStep()
+            C.memmove(C.byref(adam_st), C.byref(pl.step), C.sizeof(adam_st))
+            # optimiser-only step: its Adam pass also writes the activations of the updated parameters
+            adam_st.num_views, adam_st.views, adam_st.adam_groups, adam_st.exp_rows = 0, None, pl.groups, 0
+            adam_st.iso_weight, adam_st.forward_only, adam_st.grads_clean = float(iso_weight), 0, 0
+            nat.check(self.lib.sgr_map_step(C.byref(adam_st), stream), "sgr_map_step")
+            return
+        zr = self._zero
+        plan = zr["plan"]
+        self.comm.reduce_scatter(zr["shard"], a["flat"])
+        a["flat"].zero_()
+        grp = (nat.SgrAdamGroup * 5)()
+        r0, r1 = (C.c_int64 * 5)(), (C.c_int64 * 5)()
+        for k, name in enumerate(_GROUPS):
+            g = pl.groups[k]
+            grp[k] = nat.SgrAdamGroup(g.param, zr["shard"].data_ptr() + 4 * plan.grad_base_offset(name), g.exp_avg, g.exp_avg_sq,
+                                      g.lr, g.skip, g.step)
+            r0[k], r1[k] = plan.rows[name]
+        st = pl.step
+        nat.check(self.lib.sgr_gaussian_adam_shard(gm._xyz.shape[0], grp, r0, r1, st.beta1, st.beta2, st.eps, float(iso_weight),
+                                                   stream), "sgr_gaussian_adam_shard")
+        self.comm.all_gather(zr["param"], zr["param"][plan.lo:plan.hi])
+        zr["stale_moments"] = True
+        nat.check(self.lib.sgr_activate(gm._xyz.shape[0], gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
+                                        a["act_scale"].data_ptr(), a["act_rot"].data_ptr(), a["act_opac"].data_ptr(), stream),
+                  "sgr_activate")
+
+    def _exposure_exchange(self, rows):
+        """Exposure gradients of the window rows: every camera was rendered by ONE rank, every rank steps every row."""
+        if self._parallel() and self._exp is not None and rows:
+            n = max(rows) + 1
+            self.comm.all_reduce(self._exp.grad[:n])
 
     def _view(self, cam):
         vb = self._views.get(cam.uid)
@@ -443,7 +550,7 @@ class FusedMappingLoop(MappingLoop):
         """len(lrs) regular iterations with ONE host call (sgr_map_run): iteration k renders window_cams plus
         pool_cams[picks[k]] and steps Adam with the xyz learning rate lrs[k]."""
         n_it = len(lrs)
-        if self.world > 1 or n_it == 0:
+        if self._parallel() or n_it == 0:
             raise RuntimeError("_run_span is the single-GPU fast path")
         pl = self._plan()
         self._views_array(list(window_cams) + list(pool_cams), initialization)   # probes new cameras, settles the capacity
@@ -477,50 +584,65 @@ class FusedMappingLoop(MappingLoop):
         pl.frest_state["step"] += n_it
 
     def _run_span_ranks(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True):
-        """The multi-GPU form of _run_span: per iteration (1) this rank's views, gradients summed into the flat buffer,
-        (2) ONE all-reduce of that buffer over the ranks (RCCL over xGMI), (3) the identical Adam step on every rank.
-        The all-reduce sits between two kernels of the same iteration, so the iterations are enqueued from a lean host
-        loop (two C-ABI calls + one collective each) instead of one sgr_map_run."""
+        """The multi-GPU form of _run_span.  Per iteration: (1) this rank's share of the views, gradient sums added into the
+        flat buffer (the gather pass of the fused form, no optimiser; the loss sums ride in that launch); (2) the exchange:
+        reduce-scatter -> Adam on this rank's rows -> all-gather (or all-reduce -> replicated Adam); (3) the exposure rows,
+        all-reduced (a few floats) and stepped identically everywhere.  The collectives sit between two kernels of the same
+        iteration, so the iterations are enqueued from a lean host loop instead of one sgr_map_run."""
         n_it = len(lrs)
         pl = self._plan()
-        self._views_array(list(window_cams) + list(pool_cams), False)      # probes new cameras, settles the capacity
         nw, per = len(window_cams), (len(picks) // n_it if picks else 0)
-        pool = self._views_array(pool_cams, False, images=False) if pool_cams else None
-        arr = (nat.SgrMapView * max(1, nw + per))()
-        for v, c in enumerate(window_cams):
-            arr[v] = self._map_view(c, False, images=False)
-        st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
-        views_st, adam_st = nat.SgrMapStep(), nat.SgrMapStep()
+        mine_w = self._local(list(window_cams) + [None] * per)               # positions of an iteration this rank renders
+        pos = list(range(nw + per))[self.rank::self.world] if self.split_views else list(range(nw + per))
+        del mine_w
+        cams_needed = [c for i, c in enumerate(window_cams) if i in pos] + (list(pool_cams) if any(i >= nw for i in pos) else [])
+        if cams_needed:
+            self._views_array(cams_needed, False)                          # probes new cameras, settles the capacity
+        st = self._setup(pl, iso_weight, True, (), stats, False, "none", bump=False)
+        views_st = nat.SgrMapStep()
         C.memmove(C.byref(views_st), C.byref(st), C.sizeof(st))
-        C.memmove(C.byref(adam_st), C.byref(st), C.sizeof(st))
-        # views half: gather pass of the fused form without the optimiser (sums added to the flat buffer; the loss sums and
-        # the exposure step -- per view, no collective -- ride in that launch); optimiser half: Gaussian groups only
-        views_st.adam_groups, views_st.grads_clean = None, -2
-        adam_st.exp_rows = 0
-        views_st.num_views, views_st.views = nw + per, arr
-        adam_st.num_views, adam_st.views = 0, None      # optimiser-only step: its Adam pass also writes the activations of
-        adam_st.adam_groups = pl.groups                 # the updated parameters, so only the first views call activates
+        views_st.adam_groups, views_st.grads_clean, views_st.exp_rows = None, -2, 0
+        arr = (nat.SgrMapView * max(1, len(pos)))()
+        views_st.num_views, views_st.views = len(pos), arr
         stream = self._stream()
+        gm, a = self.gaussians, self._acc
+        nat.check(self.lib.sgr_activate(gm._xyz.shape[0], gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
+                                        a["act_scale"].data_ptr(), a["act_rot"].data_ptr(), a["act_opac"].data_ptr(), stream),
+                  "sgr_activate")
+        views_st.scaling, views_st.rotation, views_st.opacity = None, None, None      # (every exchange ends with fresh activations)
+        exp_rows = list(self._exp_rows) if (exposure != "none" and self._exp is not None) else []
+        used = []
         for k in range(n_it):
-            for j in range(per):
-                arr[nw + j] = pool[picks[k * per + j]]
-            nat.check(self.lib.sgr_map_step(C.byref(views_st), stream), "sgr_map_step")
-            views_st.scaling, views_st.rotation, views_st.opacity = None, None, None
-            self._all_reduce_sum(self._acc["flat"])
+            used = list(window_cams) + [pool_cams[picks[k * per + j]] for j in range(per)]
+            for slot, i in enumerate(pos):
+                arr[slot] = self._map_view(used[i], False, images=False)
+            if exp_rows:
+                self._exp.grad[: max(exp_rows) + 1].zero_()                 # rows of cameras other ranks render stay 0 here
+            if pos:
+                nat.check(self.lib.sgr_map_step(C.byref(views_st), stream), "sgr_map_step")
             pl.groups[0].lr = lrs[k]
             for g in range(5):
                 pl.groups[g].step += 1
-            nat.check(self.lib.sgr_map_step(C.byref(adam_st), stream), "sgr_map_step")
+            self._exchange_and_adam(pl, iso_weight)
+            if exp_rows:
+                self._exposure_exchange(exp_rows)
+                self._exp.step_mask(self.lib, exp_rows, stream)
         for g, stt in pl.states:
             stt["step"] += n_it
         pl.frest_state["step"] += n_it
         self._acc_clean = True
-        self._mark_clean(list(window_cams) + [pool_cams[k] for k in set(picks)])
+        self._mark_clean([used[i] for i in pos])
 
     def _step(self, cams, iso_weight=0.0, adam=True, skip=(), initialization=False, stats=True, forward_only=False,
               exposure="none", activate=True):
         """ONE host call: activate -> batched views (forward / loss / backward) -> Adam -> exposure Adam."""
         pl = self._plan()
+        par = self._parallel() and not forward_only
+        all_cams = cams
+        if par:
+            cams = self._local(cams)
+            if self._exp is not None and self._exp_rows and len(all_cams):
+                self._exp.grad[: max(self._exp_rows) + 1].zero_()        # rows of cameras other ranks render stay 0 here
         arr = self._views_array(cams, initialization)
         if adam and not forward_only and "scaling" not in skip and self._stale_iso:
             iso_weight, self._stale_iso = iso_weight + self._stale_iso, 0.0     # the prune pass's share rides in this step
@@ -530,20 +652,19 @@ class FusedMappingLoop(MappingLoop):
             sc, st.scaling = st.scaling, None
             ro, st.rotation = st.rotation, None
             op, st.opacity = st.opacity, None
-        if self.world > 1 and st.adam_groups and len(cams) and not forward_only:
-            # multi-GPU: (1) this rank's views, (2) sum the flat gradient buffer over ranks with ONE RCCL all-reduce,
-            # (3) the identical Adam step on every rank (the isotropy term is added locally, once)
-            exp_rows = int(st.exp_rows)     # (reading a POINTER field aliases the struct memory: re-assign pl.groups below)
+        if par:
+            # multi-GPU: (1) this rank's views into the flat sinks, (2) the exchange + the identical Adam step everywhere
+            # (see _run_span_ranks); a call without an optimiser step just leaves the local sums in the sinks
+            do_adam = bool(st.adam_groups)
+            iso = st.iso_weight if do_adam else 0.0
             st.adam_groups, st.exp_rows = None, 0
-            rc = self.lib.sgr_map_step(C.byref(st), self._stream())
-            if rc == 0:
-                self._all_reduce_sum(self._acc["flat"])
-                st.adam_groups, st.exp_rows, st.num_views = pl.groups, exp_rows, 0
-                s2, st.scaling = st.scaling, None
-                r2, st.rotation = st.rotation, None
-                o2, st.opacity = st.opacity, None
-                rc = self.lib.sgr_map_step(C.byref(st), self._stream())
-                st.scaling, st.rotation, st.opacity = s2, r2, o2
+            if do_adam and self.fuse_tail:
+                st.grads_clean = -2
+            rc = self.lib.sgr_map_step(C.byref(st), self._stream()) if (len(cams) or activate) else 0
+            if rc == 0 and do_adam:
+                self._exchange_and_adam(pl, iso, skip)
+                if exposure != "none" and len(all_cams):
+                    self._exposure_step(all_cams, only_rendered=isinstance(exposure, list))
         else:
             rc = self.lib.sgr_map_step(C.byref(st), self._stream())
         if not activate:
@@ -626,10 +747,12 @@ class FusedMappingLoop(MappingLoop):
             if stale_only:
                 self._exp.grad[torch.tensor(stale_only, dtype=torch.long, device=self.device)] = 0
             self._exp.add_stale(self._exp_rows)
+            self._exposure_exchange(self._exp_rows)
             for row in sorted(set(rendered) | set(stale_only)):
                 self._exp.step_rows(self.lib, row, 1, self._stream())
         else:
             self._exp.add_stale(self._exp_rows)
+            self._exposure_exchange(self._exp_rows)
             self._exp.step_mask(self.lib, self._exp_rows, self._stream())
         if self.keyframe_optimizers is not None:
             for cam in cams:
@@ -663,6 +786,16 @@ class FusedMappingLoop(MappingLoop):
 
     # ------------------------------------------------------------------------------------------------ loops
     def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
+        """mapper.py:303-398.  One view per iteration: with several ranks every rank runs the identical iterations
+        (deterministic kernels keep the replicas bit-identical; there is nothing to exchange)."""
+        self._sync_moments()
+        self._replicated += 1
+        try:
+            return self._initialize_map(cur_frame_idx, viewpoint, iters)
+        finally:
+            self._replicated -= 1
+
+    def _initialize_map(self, cur_frame_idx, viewpoint, iters=None):
         vb, nt = None, None
         total = self.init_itr_num if iters is None else iters
         mapping_iteration = 0
@@ -671,7 +804,7 @@ class FusedMappingLoop(MappingLoop):
             # during initialisation, mapper.py:303-353)
             n = 0
             # (the last iteration goes through _step: its rendered images are the return value, mapper.py:355-398)
-            while (self.world == 1 and self.span_calls and mapping_iteration + n < total - 1
+            while (self.span_calls and mapping_iteration + n < total - 1
                    and (mapping_iteration + n) % self.init_gaussian_update != 0
                    and self.iteration_count + n + 1 != self.init_gaussian_reset
                    and self.iteration_count + n + 1 != self.opt_params.densify_from_iter):
@@ -743,15 +876,15 @@ class FusedMappingLoop(MappingLoop):
                 for _ in range(n):               # the reference's draws, in its order (mapper.py:470)
                     picks += torch.randperm(len(random_viewpoint_stack))[:2].tolist()
                 lrs = [float(self._xyz_group()["lr"])] + [self.gaussians.lr_at(c0 + k) for k in range(1, n)]
-                (self._run_span if self.world == 1 else self._run_span_ranks)(viewpoint_stack, random_viewpoint_stack, picks,
-                                                                              lrs, 10.0, "window")
+                (self._run_span_ranks if self._parallel() else self._run_span)(viewpoint_stack, random_viewpoint_stack, picks,
+                                                                               lrs, 10.0, "window")
                 self.iteration_count = c0 + n
                 self.gaussians.update_learning_rate(self.iteration_count)
                 self.last_used = list(viewpoint_stack) + [random_viewpoint_stack[k] for k in picks[len(picks) - per:]]
                 it += n - 1
                 if it == iters - 1:
-                    self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
-                                                 for kf, c in zip(current_window, viewpoint_stack)}
+                    self.occ_aware_visibility = self._window_visibility(current_window, viewpoint_stack)
+                    self._sync_moments()
                 self._since_check += n
                 if self._since_check >= self.check_every:
                     self.check_overflow()
@@ -768,8 +901,7 @@ class FusedMappingLoop(MappingLoop):
                 self._stale_iso += 10.0
                 if self._exp is not None:
                     self._exp.keep_stale([r for r in (self._exp.row_of(c) for c in used) if r is not None])
-                self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
-                                             for kf, c in zip(current_window, viewpoint_stack)}
+                self.occ_aware_visibility = self._window_visibility(current_window, viewpoint_stack)
                 self.last_used = used
                 return False
             update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
@@ -786,21 +918,22 @@ class FusedMappingLoop(MappingLoop):
                     if it == iters - 1 or update_gaussian:
                         # the reference rebuilds this dict every iteration (mapper.py:494-498); only the value that
                         # survives the call (or a change of N) is observable
-                        self.occ_aware_visibility = {kf: (self._views[c.uid].n_touched > 0).long()
-                                                     for kf, c in zip(current_window, viewpoint_stack)}
+                        self.occ_aware_visibility = self._window_visibility(current_window, viewpoint_stack)
+                    if special or it == iters - 1:
+                        self._sync_moments()
                     if update_gaussian:
-                        if self.world > 1:     # densification statistics are per rank: combine, then every rank
-                            import torch.distributed as dist        # takes the identical (same-seed) decision
+                        if self._parallel():   # densification statistics are per rank: combine, then every rank takes
+                            import torch.distributed as dist        # the identical (same-seed) decision
                             gm = self.gaussians
-                            dist.all_reduce(gm.xyz_gradient_accum, op=dist.ReduceOp.SUM, group=self.dist_group)
-                            dist.all_reduce(gm.denom, op=dist.ReduceOp.SUM, group=self.dist_group)
-                            dist.all_reduce(gm.max_radii2D, op=dist.ReduceOp.MAX, group=self.dist_group)
+                            self.comm.all_reduce(gm.xyz_gradient_accum)
+                            self.comm.all_reduce(gm.denom)
+                            self.comm.all_reduce(gm.max_radii2D, op=dist.ReduceOp.MAX)
                         self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
                                                          self.gaussian_extent, self.size_threshold)
                         gaussian_split = True
                         self._acc_key = None
                     if reset:
-                        self.gaussians.reset_opacity_nonvisible([self._views[c.uid].radii > 0 for c in used])
+                        self.gaussians.reset_opacity_nonvisible(self._seen_by_any(used))
                         gaussian_split = True
                         self._step([], iso_weight=10.0, adam=True, skip=("opacity",), activate=False)
                     if special or pose_opt:
@@ -814,6 +947,32 @@ class FusedMappingLoop(MappingLoop):
             self.last_used = used
             self._tick()
         return gaussian_split
+
+    def _window_visibility(self, current_window, viewpoint_stack):
+        """occ_aware_visibility of mapper.py:494-498 from the last render of every window keyframe; with split views each
+        keyframe was rendered by one rank: the masks are combined (max) so that every rank sees all of them."""
+        if not (self._parallel() and self.split_views):
+            return {kf: (self._views[c.uid].n_touched > 0).long() for kf, c in zip(current_window, viewpoint_stack)}
+        import torch.distributed as dist
+        n = self.gaussians._xyz.shape[0]
+        m = torch.zeros((len(viewpoint_stack), n), dtype=torch.int32, device=self.device)
+        for i, c in enumerate(viewpoint_stack):
+            if i % self.world == self.rank:
+                m[i] = (self._views[c.uid].n_touched > 0).int()
+        self.comm.all_reduce(m, op=dist.ReduceOp.MAX)
+        return {kf: m[i].long() for i, kf in enumerate(current_window)}
+
+    def _seen_by_any(self, used):
+        """[radii > 0 of every view of the iteration] for reset_opacity_nonvisible (mapper.py:550-555); with split views the
+        union over ALL ranks' views as one mask (the reference only uses the union)."""
+        if not (self._parallel() and self.split_views):
+            return [self._views[c.uid].radii > 0 for c in used]
+        import torch.distributed as dist
+        seen = torch.zeros(self.gaussians._xyz.shape[0], dtype=torch.int32, device=self.device)
+        for c in self._local(used):
+            seen |= (self._views[c.uid].radii > 0).int()
+        self.comm.all_reduce(seen, op=dist.ReduceOp.MAX)
+        return [seen.bool()]
 
     def _has_stale(self):
         """A prune pass left gradients behind that the next optimiser step must include (see the module docstring)."""
@@ -834,6 +993,16 @@ class FusedMappingLoop(MappingLoop):
                 return g
 
     def final_refine(self, iters=26000):
+        """mapper.py:656-708: ONE random view per optimiser step -- running several views per step would change the
+        optimisation, so with several ranks every rank runs the identical iterations."""
+        self._sync_moments()
+        self._replicated += 1
+        try:
+            return self._final_refine(iters)
+        finally:
+            self._replicated -= 1
+
+    def _final_refine(self, iters=26000):
         stack = list(self.viewpoints.values())
         done = 0
         while done < iters and self._has_stale():        # what the last prune pass left behind goes into this step
@@ -846,7 +1015,7 @@ class FusedMappingLoop(MappingLoop):
             self.last_used = [cam]
             self._tick()
             done += 1
-        while self.world == 1 and self.span_calls and done < iters:
+        while self.span_calls and done < iters:
             n = min(iters - done, 512)           # (the overflow check runs between chunks)
             self._ensure_state()
             c0 = self.iteration_count

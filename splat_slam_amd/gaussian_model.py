@@ -94,15 +94,38 @@ class GaussianModel:
         self.spatial_lr_scale = 1.0
         self._knn_fn = knn_fn
         self.use_hip_compaction = True   # CUDA models prune through sgr_keep_list / sgr_gather_rows (bit-identical to torch)
+        # The <= 12 renders of one mapping iteration (mapper.py:426-485) see the same parameters: on the GPU the activated
+        # tensors (and their autograd nodes) are shared between them instead of being recomputed -- and differentiated --
+        # per view (8 + 10 small kernels per render).  Same values; the views' gradients are summed before instead of after
+        # the activation's chain rule.  Off on the CPU, where the loops replay the reference bit for bit.
+        self.share_activations = self.device.type == "cuda"
+        self._act = {}
 
     # ---- activations (gaussian_model.py:53-61,76-101)
+    def _activated(self, name, fn, *params):
+        if not self.share_activations or not torch.is_grad_enabled():
+            return fn(*params)
+        key = tuple((id(p), p._version) for p in params)
+        hit = self._act.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        out = fn(*params)
+        if out.requires_grad:
+            # a backward frees this node's graph: whatever is rendered afterwards needs a fresh one
+            def drop(grad, n=name, k=key):
+                if self._act.get(n, (None,))[0] == k:
+                    del self._act[n]
+            out.register_hook(drop)
+            self._act[name] = (key, out)
+        return out
+
     @property
     def get_scaling(self):
-        return torch.exp(self._scaling)
+        return self._activated("scaling", torch.exp, self._scaling)
 
     @property
     def get_rotation(self):
-        return torch.nn.functional.normalize(self._rotation)
+        return self._activated("rotation", torch.nn.functional.normalize, self._rotation)
 
     @property
     def get_xyz(self):
@@ -110,11 +133,11 @@ class GaussianModel:
 
     @property
     def get_features(self):
-        return torch.cat((self._features_dc, self._features_rest), dim=1)
+        return self._activated("features", lambda a, b: torch.cat((a, b), dim=1), self._features_dc, self._features_rest)
 
     @property
     def get_opacity(self):
-        return torch.sigmoid(self._opacity)
+        return self._activated("opacity", torch.sigmoid, self._opacity)
 
     def _knn(self, pts):
         if self._knn_fn is not None:

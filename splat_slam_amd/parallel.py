@@ -128,3 +128,85 @@ class ShardedAdamSync:
         bc2 = 1 - b2 ** self.step_count
         denom = (v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
         p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Layout + collectives of the fused loop's multi-GPU iteration (splat_slam_amd/fused.py).  Device agnostic: the gloo tests
+# drive it with CPU tensors and a torch stand-in for the HIP Adam kernel.
+# ----------------------------------------------------------------------------------------------------------------------
+WIDTHS = (("xyz", 3), ("f_dc", 3), ("opacity", 1), ("scaling", 3), ("rotation", 4))     # floats per Gaussian, sink order
+
+
+class Comm:
+    """The three collectives of an iteration.  `staged=True` moves every message through host memory (gloo): that is how
+    two ranks that share ONE GPU exchange data in the tests; on a real node the tensors go to RCCL as they are."""
+
+    def __init__(self, group=None, staged=False):
+        self.group, self.staged = group, staged
+
+    def all_reduce(self, t, op=None):
+        op = dist.ReduceOp.SUM if op is None else op
+        if not self.staged:
+            dist.all_reduce(t, op=op, group=self.group)
+            return
+        c = t.detach().cpu()
+        dist.all_reduce(c, op=op, group=self.group)
+        t.copy_(c.to(t.device))
+
+    def reduce_scatter(self, out, inp):
+        if not self.staged:
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.reduce_scatter_tensor(o, inp.detach().cpu(), op=dist.ReduceOp.SUM, group=self.group)
+        out.copy_(o.to(out.device))
+
+    def all_gather(self, full, shard):
+        """full[r*S:(r+1)*S] <- rank r's shard; `shard` may be this rank's own slot of `full` (in place on RCCL)."""
+        if not self.staged:
+            dist.all_gather_into_tensor(full, shard, group=self.group)
+            return
+        f = torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(f, shard.detach().cpu().clone(), group=self.group)
+        full.copy_(f.to(full.device))
+
+
+class Zero1Plan:
+    """Which rows of which parameter group a rank owns when ONE flat buffer is reduce-scattered (ZeRO-1).
+
+    The flat buffer is group-major: group k (width w_k floats per Gaussian) occupies [off_k, off_k + n_pad * w_k) with
+    off_k = n_pad * (w_0 + ... + w_{k-1}).  n_pad = N rounded up to a multiple of 12 * world: then every boundary
+    r * S of the equal shards S = 14 * n_pad / world falls on a row boundary of whatever group it lands in (12 = lcm of
+    the widths; 14 * 12 = 168 is divisible by 3 and 4), so a shard is at most a few whole-row segments: ONE
+    reduce-scatter and ONE all-gather per iteration, no packing pass."""
+
+    def __init__(self, n, world, rank):
+        self.n, self.world, self.rank = n, world, rank
+        q = 12 * world
+        self.n_pad = (max(n, 1) + q - 1) // q * q
+        self.total = 14 * self.n_pad
+        self.shard = self.total // world
+        self.offsets, off = {}, 0
+        for name, w in WIDTHS:
+            self.offsets[name] = off
+            off += self.n_pad * w
+        self.lo, self.hi = rank * self.shard, (rank + 1) * self.shard
+        self.rows = {}            # name -> (row0, row1) owned by this rank, clipped to the real N
+        for name, w in WIDTHS:
+            a, b = max(self.lo, self.offsets[name]), min(self.hi, self.offsets[name] + self.n_pad * w)
+            if a >= b:
+                self.rows[name] = (0, 0)
+                continue
+            assert (a - self.offsets[name]) % w == 0 and (b - self.offsets[name]) % w == 0
+            r0, r1 = (a - self.offsets[name]) // w, (b - self.offsets[name]) // w
+            self.rows[name] = (min(r0, n), min(r1, n))
+
+    def view(self, flat, name, shape):
+        """The [N, ...] tensor of group `name` inside a flat buffer of this layout."""
+        w = dict(WIDTHS)[name]
+        return flat[self.offsets[name]: self.offsets[name] + self.n * w].view(shape)
+
+    def grad_base_offset(self, name):
+        """Element offset (may be negative) from the start of the rank's gradient shard to the VIRTUAL row 0 of group `name`:
+        shard[grad_base_offset + w * i] is the reduced gradient of Gaussian i for every i in rows[name]."""
+        return self.offsets[name] - self.lo

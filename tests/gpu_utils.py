@@ -57,14 +57,14 @@ def run_hip(inp, s, wc=None, wd=None, dev="cuda:0", want_depth_keys=False):
     return (res, grads, keys) if want_depth_keys else (res, grads)
 
 
-def run_oracle(inp, s, wc=None, wd=None, dtype=torch.float64, depth_sort_key=None):
+def run_oracle(inp, s, wc=None, wd=None, dtype=torch.float64, depth_sort_key=None, knife=None):
     x = {k: v.detach().to(dtype).requires_grad_(wc is not None) for k, v in inp.items()}
     s2 = s._replace(bg=s.bg.to(dtype), viewmatrix=s.viewmatrix.to(dtype), projmatrix=s.projmatrix.to(dtype),
                     projmatrix_raw=s.projmatrix_raw.to(dtype), campos=s.campos.to(dtype))
     out = O.rasterize(x["means3D"], x["means2D"], x["opacities"], shs=x.get("shs"),
                       colors_precomp=x.get("colors_precomp"), scales=x.get("scales"), rotations=x.get("rotations"),
                       cov3D_precomp=x.get("cov3D_precomp"), theta=x.get("theta"), rho=x.get("rho"), settings=s2,
-                      depth_sort_key=depth_sort_key)
+                      depth_sort_key=depth_sort_key, knife=knife)
     grads = None
     if wc is not None:
         loss = (out[0] * wc.to(dtype)).sum() + (out[2] * wd.to(dtype)).sum()
@@ -94,3 +94,29 @@ def outlier_report(a, b, rel):
     m = b.abs().max().clamp_min(1e-30)
     e = (a - b).abs()
     return int((e > rel * m).sum()), e.max().item(), m.item()
+
+
+def knife_ids(knife, n):
+    """Boolean [n]: Gaussians the oracle saw within KNIFE_BAND of a cut-off at some pixel (raster_oracle.knife_edge_gaussians)."""
+    m = torch.zeros(n, dtype=torch.bool)
+    for ids in knife.get("gaussians", []):
+        m[ids] = True
+    return m
+
+
+def move_off_knife_edges(inp, s, max_rounds=10):
+    """Nudges the (activated) opacities of Gaussians that sit on a cut-off by 0.2-2 % until no composite / skip decision
+    of the view is within KNIFE_BAND of its threshold; returns the number of rounds.  The scene stays what it was for every
+    practical purpose, but fp32 and fp64 can no longer disagree about WHICH pairs contribute."""
+    g = torch.Generator().manual_seed(17)
+    for rnd in range(max_rounds):
+        k = O.knife_edge_gaussians(inp["means3D"], inp["opacities"], shs=inp.get("shs"), colors_precomp=inp.get("colors_precomp"),
+                                   scales=inp.get("scales"), rotations=inp.get("rotations"), cov3D_precomp=inp.get("cov3D_precomp"),
+                                   settings=s)
+        if k.numel() == 0:
+            return rnd
+        f = 1.0 + (0.002 + 0.018 * torch.rand(k.numel(), generator=g, dtype=torch.float64))
+        o = inp["opacities"].clone()
+        o[k, 0] = torch.where(o[k, 0] * f < 0.9985, o[k, 0] * f, o[k, 0] / f)
+        inp["opacities"] = o.float().double()          # stays fp32-exact
+    raise AssertionError("scene still has knife-edge pairs after %d rounds" % max_rounds)

@@ -392,3 +392,43 @@ def test_initialize_map_with_run_calls_equals_iteration_by_iteration():
     assert out[0][0].shape == out[1][0].shape and out[0][0].shape[0] != 1800          # densification did change N
     for a, b in zip(*out):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("scene", ["light", "long_lists", "huge_lists"])
+def test_fused_tile_kernel_equals_the_two_separate_kernels_bitwise(scene):
+    """SGR_OPT_FUSED_BLEND: forward + loss + backward of a tile in one wave (pixel state in registers, splats still staged
+    in LDS) must give bit for bit what blend_fwd -> code bytes -> blend_bwd<true> give: same gradients, losses, exposure
+    gradients, n_touched, densification statistics."""
+    from splat_slam_amd import _native as nat
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    lib = nat.lib()
+    n, cam, add, op = {"light": (4000, "tiny", 1.2, 0.0), "long_lists": (60000, "tiny", 1.0, -1.0),
+                       "huge_lists": (300000, "tiny", 0.0, -2.0)}[scene]
+    intr = syn.INTRINSICS[cam]
+    params = syn.room_parameters(n, seed=3, device=DEV)
+    params["scaling"] = params["scaling"] + add
+    params["opacity"] = params["opacity"] + op
+    cams = syn.make_views(params, 5, intr, DEV, seed=3)
+    res = []
+    try:
+        for fused in (1, 0):
+            lib.sgr_set_option(nat.SGR_OPT_FUSED_BLEND, fused)
+            assert lib.sgr_get_option(nat.SGR_OPT_FUSED_BLEND) == fused
+            f = _loop(FusedMappingLoop, syn, params, cams, range(5))
+            for k, c in enumerate(cams):
+                c.exposure_a.data.fill_(0.02 * k)
+            f._ensure_state()
+            f._activate()
+            f._run_views(cams, stats=True)
+            torch.cuda.synchronize()
+            gm = f.gaussians
+            res.append(dict(flat=f._acc["flat"].clone(), loss=torch.cat([f._views[c.uid].loss for c in cams]).clone(),
+                            exp=f._exp.grad[:8].clone(), nt=torch.stack([f._views[c.uid].n_touched for c in cams]).clone(),
+                            accum=gm.xyz_gradient_accum.clone(), denom=gm.denom.clone(), maxr=gm.max_radii2D.clone()))
+    finally:
+        lib.sgr_set_option(nat.SGR_OPT_FUSED_BLEND, 1)
+    a, b = res
+    assert a["flat"].abs().max() > 0
+    for k in a:
+        assert torch.equal(a[k], b[k]), (scene, k, (a[k].float() - b[k].float()).abs().max().item())
