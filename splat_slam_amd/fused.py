@@ -335,7 +335,7 @@ class FusedMappingLoop(MappingLoop):
 
     def _exposure_exchange(self, rows):
         """Exposure gradients of the window rows: every camera was rendered by ONE rank, every rank steps every row."""
-        if self._parallel() and self._exp is not None and rows:
+        if self._parallel() and self.split_views and self._exp is not None and rows:     # (own views per rank: own exposures)
             n = max(rows) + 1
             self.comm.all_reduce(self._exp.grad[:n])
 

@@ -138,59 +138,110 @@ def test_fused_loop_tracks_autograd_loop():
         assert (a.occ_aware_visibility[kf] != f.occ_aware_visibility[kf]).float().mean().item() < 0.01
 
 
-def _mg_worker(rank, world, port, out, span=True):
+def _mg_state(f):
+    gm = f.gaussians
+    st = {g["name"]: gm.optimizer.state[g["params"][0]] for g in gm.optimizer.param_groups}
+    out = {k: getattr(gm, k).detach().cpu().clone() for k in ["_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"]}
+    out.update({"m_" + k: st[k]["exp_avg"].detach().cpu().clone() for k in ["xyz", "f_dc", "opacity", "scaling", "rotation"]})
+    out.update({"v_" + k: st[k]["exp_avg_sq"].detach().cpu().clone() for k in ["xyz", "scaling"]})
+    out["exposure"] = f._exp.param[:8].detach().cpu().clone()
+    out["occ"] = torch.stack([v for _, v in sorted(f.occ_aware_visibility.items())]).cpu()
+    out["accum"] = gm.xyz_gradient_accum.detach().cpu().clone()
+    return out
+
+
+def _mg_worker(rank, world, port, out, sync, split, span, reset_at):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from splat_slam_amd.fused import FusedMappingLoop
+    from splat_slam_amd.parallel import Comm
     syn, params, cams = _scene(n=2000, views=6, seed=21)
-    mine = cams[rank * 3: rank * 3 + 3]            # each rank maps its own three views of the replicated map
-    f = _loop(FusedMappingLoop, syn, params, mine, [c.uid for c in mine])
-    f.world = world
+    if split:            # strong scaling: every rank holds all keyframes and renders its share of each iteration
+        f = _loop(FusedMappingLoop, syn, params, cams, [0, 1, 2, 3])
+    else:                # weak scaling: each rank maps its own three views of the replicated map
+        mine = cams[rank * 3: rank * 3 + 3]
+        f = _loop(FusedMappingLoop, syn, params, mine, [c.uid for c in mine])
+    # one 1-GPU box: both ranks share cuda:0, so the collectives are staged through gloo / host memory
+    f.set_parallel(world, rank, split_views=split, sync=sync, comm=Comm(staged=True))
     f.span_calls = span
-
-    def staged_all_reduce(t):                      # one 1-GPU box: both ranks share cuda:0, so exchange through gloo/CPU
-        c = t.detach().cpu()
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        t.copy_(c.to(t.device))
-
-    f._all_reduce_sum = staged_all_reduce
+    f.iteration_count = 50
+    if reset_at:
+        f.gaussian_reset = reset_at          # an opacity-reset iteration inside the run (mapper.py:550-555)
     torch.manual_seed(3)
-    f.map(f.current_window, iters=3)
+    f.map(f.current_window, iters=4)
+    f.map(f.current_window, iters=2)
     torch.cuda.synchronize()
-    out[rank] = {k: getattr(f.gaussians, k).detach().cpu() for k in ["_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"]}
+    out[rank] = _mg_state(f)
     dist.destroy_process_group()
 
 
-def test_view_parallel_ranks_stay_bitwise_identical_and_match_single_process():
+def _spawn2(*args):
     import socket
     import torch.multiprocessing as mp
-    from splat_slam_amd.fused import FusedMappingLoop
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = mp.Manager().dict()
-    mp.spawn(_mg_worker, args=(2, port, out), nprocs=2, join=True)
-    for k in out[0]:
-        assert torch.equal(out[0][k], out[1][k]), k          # replicas never drift
-    # the lean per-iteration host loop of a run (_run_span_ranks) is the same computation as one _step per iteration
-    s2 = socket.socket(); s2.bind(("127.0.0.1", 0)); port2 = s2.getsockname()[1]; s2.close()
-    out2 = mp.Manager().dict()
-    mp.spawn(_mg_worker, args=(2, port2, out2, False), nprocs=2, join=True)
-    for k in out[0]:
-        assert torch.equal(out[0][k], out2[0][k]), k
-    # single process, all six views in one window: same gradient sum up to fp32 summation order
+    mp.spawn(_mg_worker, args=(2, port, out) + args, nprocs=2, join=True)
+    return out[0], out[1]
+
+
+def _single_process_reference(reset_at, window):
+    from splat_slam_amd.fused import FusedMappingLoop
     syn, params, cams = _scene(n=2000, views=6, seed=21)
-    f = _loop(FusedMappingLoop, syn, params, cams, [c.uid for c in cams])
+    f = _loop(FusedMappingLoop, syn, params, cams, window)
+    f.iteration_count = 50
+    if reset_at:
+        f.gaussian_reset = reset_at
     torch.manual_seed(3)
-    f.map(f.current_window, iters=3)
+    f.map(f.current_window, iters=4)
+    f.map(f.current_window, iters=2)
     torch.cuda.synchronize()
+    return _mg_state(f)
+
+
+def _close_to_single(multi, single):
+    lr = {"_xyz": 9.6e-4, "_features_dc": 2.5e-3, "_opacity": 0.05, "_scaling": 6e-3, "_rotation": 1e-3}
+    for k, step in lr.items():        # same gradient sum up to fp32 summation order: a bounded few rounding-noise flips
+        d = (multi[k] - single[k]).abs()
+        assert (d > 0.02 * step).float().mean().item() < 0.01, k
+    assert (multi["exposure"] - single["exposure"]).abs().max().item() < 2e-3
+    assert (multi["occ"] != single["occ"]).float().mean().item() < 0.01
+
+
+@pytest.mark.parametrize("reset_at", [0, 53])
+def test_strong_scaling_zero1_ranks_agree_bitwise_and_match_single_process(reset_at):
+    """The reference's iteration split over two ranks (views dealt round-robin), gradients reduce-scattered, Adam on each
+    rank's rows (sgr_gaussian_adam_shard), parameters all-gathered: replicas never drift (parameters, Adam moments after the
+    moment all-gather, exposures, visibility), ZeRO-1 equals the all-reduce + replicated Adam variant bit for bit, the span
+    form equals one call per iteration, and the result is the single-process loop's up to summation order -- also across an
+    opacity-reset iteration (the optimiser-only step after the reset must see the REDUCED gradients)."""
+    z0, z1 = _spawn2("zero1", True, True, reset_at)
+    for k in z0:
+        assert torch.equal(z0[k], z1[k]), ("ranks differ", k)
+    a0, a1 = _spawn2("allreduce", True, True, reset_at)
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), ("ranks differ (allreduce)", k)
+        assert torch.equal(z0[k], a0[k]), ("zero1 != allreduce", k)
+    s0, _ = _spawn2("zero1", True, False, reset_at)
+    for k in z0:
+        assert torch.equal(z0[k], s0[k]), ("span != per-iteration", k)
+    _close_to_single(z0, _single_process_reference(reset_at, [0, 1, 2, 3]))
+
+
+def test_weak_scaling_ranks_with_their_own_views_stay_bitwise_identical():
+    w0, w1 = _spawn2("zero1", False, True, 0)
+    for k in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation", "m_xyz", "v_scaling"):
+        assert torch.equal(w0[k], w1[k]), k
+    # single process, all six views in one window: same gradient sum up to fp32 summation order
+    single = _single_process_reference(0, [0, 1, 2, 3, 4, 5])
     lr = {"_xyz": 9.6e-4, "_features_dc": 2.5e-3, "_opacity": 0.05, "_scaling": 6e-3, "_rotation": 1e-3}
     for k, step in lr.items():
-        d = (out[0][k] - getattr(f.gaussians, k).detach().cpu()).abs()
+        d = (w0[k] - single[k]).abs()
         assert (d > 0.02 * step).float().mean().item() < 0.01, k
 
 

@@ -73,3 +73,91 @@ def test_gradient_exchange_world_size_2(n):
     for name in l0:
         assert torch.equal(p0[name], p1[name]), name                       # ranks agree bit-for-bit after all-gather
         assert torch.allclose(p0[name], getattr(ref, name).detach(), atol=1e-6, rtol=1e-5), name
+
+
+# ---- the fused loop's ZeRO-1 exchange (parallel.Zero1Plan + Comm) with a torch stand-in for sgr_gaussian_adam_shard
+def _torch_group_step(name, p, g_act, m, v, lr, step, iso_coef, b1=0.9, b2=0.999, eps=1e-15):
+    """Rows of ONE group: chain rule from the gradient wrt the ACTIVATED input to the raw parameter, then Adam (what
+    gaussian_adam_one does per Gaussian, csrc/sgr_aux.hip)."""
+    if name == "opacity":
+        sg = torch.sigmoid(p)
+        g = g_act * sg * (1 - sg)
+    elif name == "scaling":
+        s = torch.exp(p)
+        d = s - s.mean(dim=1, keepdim=True)
+        sgn = torch.sign(d)
+        g = (g_act + iso_coef * (sgn - sgn.sum(dim=1, keepdim=True) / 3.0)) * s
+    elif name == "rotation":
+        nrm = p.norm(dim=1, keepdim=True)
+        y = p / nrm
+        g = (g_act - y * (y * g_act).sum(dim=1, keepdim=True)) / nrm
+    else:
+        g = g_act
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.sub_((lr / (1 - b1 ** step)) * m / (v.sqrt() / (1 - b2 ** step) ** 0.5 + eps))
+
+
+def _zero1_worker(rank, world, port, n, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from splat_slam_amd.parallel import WIDTHS, Comm, Zero1Plan
+    plan, comm = Zero1Plan(n, world, rank), Comm()
+    shapes = {"xyz": (n, 3), "f_dc": (n, 3), "opacity": (n, 1), "scaling": (n, 3), "rotation": (n, 4)}
+    lrs = {"xyz": 1e-3, "f_dc": 2.5e-3, "opacity": 0.05, "scaling": 6e-3, "rotation": 1e-3}
+    g0 = torch.Generator().manual_seed(1)
+    flat_p, flat_m, flat_v = torch.zeros(plan.total), torch.zeros(plan.total), torch.zeros(plan.total)
+    for name, _ in WIDTHS:
+        plan.view(flat_p, name, shapes[name]).copy_(torch.randn(shapes[name], generator=g0))       # identical replicas
+    start = flat_p.clone()
+    shard = torch.zeros(plan.shard)
+    locals_ = []
+    for step in (1, 2, 3):
+        gl = torch.Generator().manual_seed(100 * step + rank)          # this rank's views -> its own gradient sums
+        flat_g = torch.zeros(plan.total)
+        for name, _ in WIDTHS:
+            plan.view(flat_g, name, shapes[name]).copy_(torch.randn(shapes[name], generator=gl))
+        locals_.append(flat_g.clone())
+        comm.reduce_scatter(shard, flat_g)
+        for name, w in WIDTHS:
+            r0, r1 = plan.rows[name]
+            if r1 <= r0:
+                continue
+            base = plan.grad_base_offset(name)
+            g_rows = shard[base + w * r0: base + w * r1].view(r1 - r0, w)      # the pointer arithmetic the HIP call is handed
+            sl = lambda buf: plan.view(buf, name, shapes[name])[r0:r1]
+            _torch_group_step(name, sl(flat_p), g_rows, sl(flat_m), sl(flat_v), lrs[name], step, 10.0 / (3.0 * n))
+        comm.all_gather(flat_p, flat_p[plan.lo:plan.hi].clone())
+    comm.all_gather(flat_m, flat_m[plan.lo:plan.hi].clone())              # _sync_moments
+    out[rank] = (start, locals_, flat_p.clone(), flat_m.clone(), {k: v for k, v in plan.rows.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 50, 1001])
+def test_zero1_plan_exchange_world_size_2_equals_replicated_adam(n):
+    from splat_slam_amd.parallel import WIDTHS, Zero1Plan
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_zero1_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    (start, l0, p0, m0, rows0), (_, l1, p1, m1, rows1) = out[0], out[1]
+    assert torch.equal(p0, p1) and torch.equal(m0, m1)                     # bitwise-equal replicas after the all-gathers
+    for name, _ in WIDTHS:                                                 # the two ranks' rows tile [0, n) exactly
+        (a0, b0), (a1, b1) = rows0[name], rows1[name]
+        assert (b0 - a0) + (b1 - a1) == n and (a1 == b0 or b0 == a0 or b1 == a1)
+    # single process: the summed gradient, the same per-group step on ALL rows
+    plan = Zero1Plan(n, 1, 0)
+    ref = Zero1Plan(n, world, 0)
+    shapes = {"xyz": (n, 3), "f_dc": (n, 3), "opacity": (n, 1), "scaling": (n, 3), "rotation": (n, 4)}
+    lrs = {"xyz": 1e-3, "f_dc": 2.5e-3, "opacity": 0.05, "scaling": 6e-3, "rotation": 1e-3}
+    P = {name: ref.view(start.clone(), name, shapes[name]).clone() for name, _ in WIDTHS}
+    M = {name: torch.zeros(shapes[name]) for name, _ in WIDTHS}
+    V = {name: torch.zeros(shapes[name]) for name, _ in WIDTHS}
+    for step in (1, 2, 3):
+        for name, _ in WIDTHS:
+            g = ref.view(l0[step - 1], name, shapes[name]) + ref.view(l1[step - 1], name, shapes[name])
+            _torch_group_step(name, P[name], g, M[name], V[name], lrs[name], step, 10.0 / (3.0 * n))
+    for name, _ in WIDTHS:
+        assert torch.equal(ref.view(p0, name, shapes[name]), P[name]), name
+        assert torch.equal(ref.view(m0, name, shapes[name]), M[name]), name
+    assert plan.rows["xyz"] == (0, n)
