@@ -190,9 +190,17 @@ int sgr_query_list_histogram(const SgrWorkspace* ws, int32_t num_gaussians, int3
 /* Run-time options of the library (process-wide; no reference counterpart).
  *   SGR_OPT_FUSED_BLEND (default 1): sgr_map_views / sgr_map_step / sgr_map_run composite a tile, evaluate the mapping loss
  *     and run the tile's backward in ONE kernel (the same wave, pixel state in registers).  0: the two halves run as the
- *     separate kernels sgr_forward / sgr_backward use (bitwise identical results) -- for timing the halves on their own. */
+ *     separate kernels sgr_forward / sgr_backward use (bitwise identical results) -- for timing the halves on their own.
+ *   SGR_OPT_UPSTREAM_POSE_JACOBIAN (default 0): how the projected-mean path enters the camera-pose gradient dL/dtau.
+ *     0: the exact derivative of the projection (x_ndc = (P00 X + P02 Z) / Z ...), what autograd through the reference's
+ *        own SE3_exp / update_pose convention gives (thirdparty/monogs/utils/pose_utils.py:66-98);
+ *     1: the form the pinned CUDA rasterizer is believed to use: five scalars of projmatrix_raw
+ *        (P00, P11, P22, P23, P32), d x_ndc / d p_cam = (P00 / w, 0, -x_hom / w^2) -- i.e. WITHOUT the principal-point terms
+ *        P02 / w, P12 / w.  Identical when cx = W/2 and cy = H/2; differs by O(|P02|) otherwise (8e-4 on Replica).  Only
+ *        dL/dtau changes; every other gradient is the same.  The oracle has the same switch (UPSTREAM_POSE_JACOBIAN). */
 #define SGR_OPT_FUSED_BLEND 0
-#define SGR_OPT_COUNT 1
+#define SGR_OPT_UPSTREAM_POSE_JACOBIAN 1
+#define SGR_OPT_COUNT 2
 int sgr_set_option(int32_t option, int32_t value);
 int sgr_get_option(int32_t option);
 

@@ -27,6 +27,12 @@ switch so it can be flipped if the real CUDA build is ever available:
   CLAMP_STRAIGHT_THROUGH  alpha = min(0.99, o*G) is treated as identity in the backward
   FRUSTUM_CLAMP_CONST     the +-1.3*tanfov clamp of t.x/t.y yields a constant (no d/dt.z)
   CAMPOS_CONST            camera centre used for SH view directions carries no pose grad
+
+A fourth switch is OFF by default: UPSTREAM_POSE_JACOBIAN.  Upstream's 2D-mean -> pose term is believed to
+read five scalars of projmatrix_raw (P00, P11, P22, P23, P32) and to use d x_ndc / d p_cam = (P00/w, 0, -x_hom/w^2), which
+drops the principal-point terms P02/w, P12/w: exact for cx = W/2, cy = H/2, off by O(|P02|) otherwise (8e-4 on Replica;
+irrelevant for default runs, mapping.BA False).  Default = the exact derivative; the HIP library has the same switch
+(SGR_OPT_UPSTREAM_POSE_JACOBIAN) and tests/ check both settings on both sides.
 """
 from __future__ import annotations
 
@@ -45,6 +51,7 @@ N_TOUCHED_T = 0.5           # n_touched counts pixels composited while T' > 0.5
 CLAMP_STRAIGHT_THROUGH = True
 FRUSTUM_CLAMP_CONST = True
 CAMPOS_CONST = True
+UPSTREAM_POSE_JACOBIAN = False   # True: pose path of the projected mean without the principal-point terms (see the docstring)
 
 SH_C0 = 0.28209479177387814
 SH_C1 = 0.4886025119029199
@@ -154,7 +161,12 @@ def preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotatio
         rh = rho.to(dt).reshape(3) if rho is not None and rho.numel() == 3 else torch.zeros(3, dtype=dt)
         E = se3_exp_small(rh - rh.detach(), th - th.detach())
         view_eff = E @ view
-        pv = P @ view_eff
+        P_pose = P
+        if UPSTREAM_POSE_JACOBIAN:            # the pose path does not see the principal-point column entries
+            P_pose = P.clone()
+            P_pose[0, 2] = 0.0
+            P_pose[1, 2] = 0.0
+        pv = P_pose @ view_eff
         proj_eff = proj_given + (pv - pv.detach())
 
     p = means3D

@@ -23,7 +23,7 @@ void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, const Loss
 void launch_blend_fused(const ViewTab&, int, const LOff&, const float*, const LossTab&, const LossCoef&, hipStream_t);
 
 // run-time options (sgr_set_option)
-static int g_opt[SGR_OPT_COUNT] = {1};
+static int g_opt[SGR_OPT_COUNT] = {1, 0};
 
 static thread_local char g_err[512] = "";
 int set_error(int code, const char* fmt, ...) {
@@ -147,6 +147,7 @@ static Common make_common(const SgrSettings* s) {
   Common c;
   c.deg = s->sh_degree; c.M = s->sh_coeffs; c.tanfovx = s->tanfovx; c.tanfovy = s->tanfovy; c.mod = s->scale_modifier;
   c.bg = s->bg; c.projraw = s->projmatrix_raw;
+  c.upstream_pose_jac = g_opt[SGR_OPT_UPSTREAM_POSE_JACOBIAN];
   return c;
 }
 

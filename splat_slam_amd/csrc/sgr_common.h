@@ -84,6 +84,7 @@ struct LOff {
 // shared (view independent) scalars of a batch
 struct Common {
   int deg, M;
+  int upstream_pose_jac;   // SGR_OPT_UPSTREAM_POSE_JACOBIAN
   float tanfovx, tanfovy, mod;
   const float* bg;
   const float* projraw;

@@ -491,7 +491,7 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     uint32_t slot0, uint32_t touched_cnt, unsigned clamped_bits,
     const float4* __restrict__ partials, int64_t cap, float* __restrict__ dshs, int sh_accumulate, GaussGrad& acc,
-    float tau[6]) {
+    float tau[6], int upstream_pose_jac) {
   float g_m2[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_rgb[3] = {0.f, 0.f, 0.f}, g_dep = 0.f;
   float g_p[3] = {0.f, 0.f, 0.f};
   float g_S6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -595,9 +595,13 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
 #pragma unroll
     for (int k = 0; k < 3; ++k) g_p[k] = vm[k * 4 + 0] * v[0] + vm[k * 4 + 1] * v[1] + vm[k * 4 + 2] * v[2];
 
-    // camera pose, left perturbation W2C <- exp(tau) W2C, tau = (rho, theta)  (pose_utils.py:66-98)
-    tau[0] = v[0]; tau[1] = v[1]; tau[2] = v[2];
-    V3 pc = cross(V3{pv[0], pv[1], pv[2]}, V3{v[0], v[1], v[2]});
+    // camera pose, left perturbation W2C <- exp(tau) W2C, tau = (rho, theta)  (pose_utils.py:66-98).
+    // SGR_OPT_UPSTREAM_POSE_JACOBIAN: the pose path sees the projected mean without the principal-point terms P02, P12
+    // (P[r][c] = pr[c*4+r]); the world-space mean gradient above keeps the exact projection either way.
+    float vz = v[2];
+    if (upstream_pose_jac) vz -= dph[0] * pr[2 * 4 + 0] + dph[1] * pr[2 * 4 + 1];
+    tau[0] = v[0]; tau[1] = v[1]; tau[2] = vz;
+    V3 pc = cross(V3{pv[0], pv[1], pv[2]}, V3{v[0], v[1], vz});
     tau[3] = pc.x; tau[4] = pc.y; tau[5] = pc.z;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {   // columns of W
@@ -735,7 +739,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                           cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
                           abs_offset(saved, L, (uint32_t)i, q3.y), q3.x, q3.w,
                           (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
-                          dshs, accumulate, acc, tau);
+                          dshs, accumulate, acc, tau, cm.upstream_pose_jac);
   // the record sits at the GAUSSIAN's index (one full 64-byte sector): the gather pass then needs no list-slot lookup
   float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)i * 4;
   rec[0] = make_float4(acc.p[0], acc.p[1], acc.p[2], acc.rgb_or_sh0[0]);

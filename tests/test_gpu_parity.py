@@ -121,3 +121,30 @@ def test_forward_only_then_drop_graph_and_cpu_tensor_raises():
     with pytest.raises(RuntimeError):
         rast(means3D=inp["means3D"].float(), means2D=inp["means2D"].float(), shs=inp["shs"].float(),
              opacities=inp["opacities"].float(), scales=inp["scales"].float(), rotations=inp["rotations"].float())
+
+
+def test_upstream_pose_jacobian_switch_on_both_sides():
+    """SGR_OPT_UPSTREAM_POSE_JACOBIAN / oracle UPSTREAM_POSE_JACOBIAN: with an off-centre principal point
+    the pose gradient changes -- identically on both sides --, every other gradient is bit-identical to the default."""
+    from oracle import raster_oracle as O
+    from splat_slam_amd import _native as nat
+    lib = nat.lib()
+    inp, s = random_scene(300, seed=11, W=50, H=37, fx=44.0, fy=41.0, cx=19.3, cy=23.9)       # |P02|, |P12| ~ 0.2-0.3
+    inp, s = to_fp32_inputs(inp, s)
+    wc, wd = _weights(5, 37, 50)
+    _, g_off = run_hip(inp, s, wc, wd)
+    try:
+        lib.sgr_set_option(nat.SGR_OPT_UPSTREAM_POSE_JACOBIAN, 1)
+        O.UPSTREAM_POSE_JACOBIAN = True
+        _, g_on = run_hip(inp, s, wc, wd)
+        _, ref_on = run_oracle(inp, s, wc, wd)
+    finally:
+        lib.sgr_set_option(nat.SGR_OPT_UPSTREAM_POSE_JACOBIAN, 0)
+        O.UPSTREAM_POSE_JACOBIAN = False
+    _, ref_off = run_oracle(inp, s, wc, wd)
+    for k in GRAD_KEYS:
+        if k in ("theta", "rho"):
+            assert rel_linf(g_on[k], ref_on[k]) <= REL and rel_linf(g_off[k], ref_off[k]) <= REL, k
+        else:
+            assert torch.equal(g_on[k], g_off[k]), k
+    assert rel_linf(g_on["rho"], g_off["rho"]) > 1e-3            # the switch really does something on this camera

@@ -96,3 +96,43 @@ def test_means2d_grad_is_ndc_scaled_pixel_gradient():
     assert torch.allclose(x["means2D"].grad[:, 0], torch.full((10,), 3.0 * 16.0, dtype=torch.float64))
     assert torch.allclose(x["means2D"].grad[:, 1], torch.full((10,), 5.0 * 16.0, dtype=torch.float64))
     assert torch.all(x["means2D"].grad[:, 2] == 0)
+
+
+def test_upstream_pose_jacobian_switch_drops_exactly_the_principal_point_terms():
+    """UPSTREAM_POSE_JACOBIAN: only (grad_theta, grad_rho) change, by the contraction of dL/d(ndc) with the
+    dropped terms -P02/w, -P12/w; with a centred principal point the two forms coincide."""
+    from helpers import random_scene
+    from oracle import raster_oracle as O
+
+    def grads(inp, s, flag):
+        old = O.UPSTREAM_POSE_JACOBIAN
+        O.UPSTREAM_POSE_JACOBIAN = flag
+        try:
+            x = {k: v.detach().clone().requires_grad_(True) for k, v in inp.items()}
+            out = O.rasterize(x["means3D"], x["means2D"], x["opacities"], shs=x["shs"], scales=x["scales"], rotations=x["rotations"],
+                              theta=x["theta"], rho=x["rho"], settings=s)
+            g = torch.Generator().manual_seed(9)
+            (out[0] * torch.randn(out[0].shape, generator=g, dtype=out[0].dtype)).sum().backward()
+            return {k: v.grad.detach().clone() for k, v in x.items()}
+        finally:
+            O.UPSTREAM_POSE_JACOBIAN = old
+
+    W, H = 64, 48
+    inp, s = random_scene(60, seed=5, W=W, H=H, cx=W / 2, cy=H / 2)          # P02 = P12 = 0
+    a, b = grads(inp, s, False), grads(inp, s, True)
+    for k in a:
+        assert torch.allclose(a[k], b[k], rtol=0, atol=1e-12 * max(1.0, a[k].abs().max().item())), k
+    inp, s = random_scene(60, seed=5, W=W, H=H, cx=26.3, cy=29.9)              # off-centre principal point
+    a, b = grads(inp, s, False), grads(inp, s, True)
+    for k in a:
+        if k not in ("theta", "rho"):
+            assert torch.equal(a[k], b[k]), k
+    P = s.projmatrix_raw.t()
+    W2C = s.viewmatrix.t()
+    pc = inp["means3D"] @ W2C[:3, :3].t() + W2C[:3, 3]
+    g_ndc = a["means2D"][:, :2]
+    dvz = -(g_ndc[:, 0] * P[0, 2] + g_ndc[:, 1] * P[1, 2]) / (pc[:, 2] + 1e-7)
+    dv = torch.stack([torch.zeros_like(dvz), torch.zeros_like(dvz), dvz], dim=1)
+    assert (b["rho"] - a["rho"] - dv.sum(0)).abs().max() < 1e-9 * max(1.0, a["rho"].abs().max().item())
+    assert (b["theta"] - a["theta"] - torch.linalg.cross(pc, dv).sum(0)).abs().max() < 1e-9 * max(1.0, a["theta"].abs().max().item())
+    assert (b["rho"] - a["rho"]).abs().max() > 1e-6 * a["rho"].abs().max()
