@@ -237,3 +237,31 @@ def test_densify_and_prune_with_hip_row_selection_equals_torch():
         assert torch.equal(getattr(a, name).detach(), getattr(b, name).detach()), name
     for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
         assert torch.equal(a.optimizer.state[ga["params"][0]]["exp_avg"], b.optimizer.state[gb["params"][0]]["exp_avg"])
+
+
+def test_config1_session_script_smoke(tmp_path, monkeypatch, capsys):
+    """scripts/run_session_config1.py (the configs[1] session: default hyper-parameters, densification on, deformation of
+    moved keyframes, final refinement, PSNR of the HIP map rendered by HIP and by the oracle) at smoke size."""
+    import importlib.util
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_session_config1", os.path.join(root, "scripts", "run_session_config1.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "s.json"
+    monkeypatch.setattr(sys, "argv", ["x", "--keyframes", "9", "--camera", "tiny", "--refine", "60", "--oracle-views", "2",
+                                      "--world", "30000", "--moved-every", "3", "--out", str(out)])
+    from splat_slam_amd.gaussian_model import GaussianModel
+    saved = {n: getattr(GaussianModel, n) for n in ("densify_and_prune", "extend_from_pcd_seq", "reset_opacity", "reset_opacity_nonvisible")}
+    try:
+        mod.main()
+    finally:
+        for n, f in saved.items():
+            setattr(GaussianModel, n, f)
+    d = json.load(open(out))
+    assert d["keyframes_mapped"] >= 3 and d["gaussians_final"] > 300 and d["overflow_events"] == 0
+    assert d["psnr_all_keyframes_mean"] > 15.0
+    for row in d["psnr_hip_vs_oracle_render_of_the_same_map"]:
+        assert abs(row["psnr_hip_map_hip_render"] - row["psnr_hip_map_oracle_render"]) < 0.05, row
