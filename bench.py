@@ -342,21 +342,25 @@ def main():
             torch.cuda.synchronize()
             out["refine_iterations_per_s"] = round(args.refine_iters / (time.perf_counter() - a), 1)
         trace("render/refine done")
-        if not args.no_extras:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(loop, cams[0], intr, views_per_step)
+        if not args.no_extras:          # (a failing extra must never cost the headline line)
             del loop
             torch.cuda.empty_cache()
-            drop, dloop, dcams = B.dropin_leg()
-            out["dropin_keyframes_per_s"] = drop.pop("dropin_keyframes_per_s")
-            out["dropin"] = drop
+            try:
+                drop, dloop, dcams = B.dropin_leg()
+                out["dropin_keyframes_per_s"] = drop.pop("dropin_keyframes_per_s")
+                out["dropin"] = drop
+                del dloop, dcams
+            except Exception as e:      # noqa: BLE001
+                out["dropin"] = {"error": repr(e)}
             trace("dropin done")
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(dloop, dcams[0], intr, views_per_step)
-            del dloop, dcams
             torch.cuda.empty_cache()
-            out["extra"] = {"opaque_scene": B.scene_leg(args.scale_add + 1.6)}
+            try:
+                out["extra"] = {"opaque_scene": B.scene_leg(args.scale_add + 1.6)}
+            except Exception as e:      # noqa: BLE001
+                out["extra"] = {"opaque_scene": {"error": repr(e)}}
             trace("opaque done")
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(loop, cams[0], intr, views_per_step)
 
     if rank == 0:
         print(json.dumps(out))

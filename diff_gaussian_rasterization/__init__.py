@@ -42,14 +42,20 @@ class GaussianRasterizationSettings(NamedTuple):
 #             leased from a per-shape pool and handed back when autograd drops the graph node -- a block that went through
 #             a forward has clean per-tile counters, so the library skips its zeroing launch
 #   scratch : one growing block per device, shared by all calls on the stream
-#   capacity: number of (8x8 tile, Gaussian) pairs the blocks are sized for = 2x the largest pair count seen so far.
+#   capacity: number of (8x8 tile, Gaussian) pairs the blocks are sized for = max(1 Mi, 4x the largest pair count seen so
+#             far): 288 GB of HBM make that head-room free (4 B + 56 B of scratch per pair), and the pair count of a map
+#             drifts by per cents between calls while different cameras of one map differ by small factors.
 # No host synchronisation in the steady state: the pair count R of a forward comes back through a 64-byte asynchronous copy
-# of the saved block's header into a pinned ring, read at the start of a LATER forward.  Only the first forward of a new map
-# size (N changed: a densification) waits for its R.  SPLAT_RASTER_SYNC=1 makes every forward wait (upstream's behaviour).
+# of the saved block's header into a pinned ring, read at the start of a LATER forward.  Only the first forward of a new MAP
+# (another `means3D` storage or another N: a densification, a different model) waits for its R.  A forward that still finds
+# the capacity too small drops pairs and the next call raises.  SPLAT_RASTER_SYNC=1 makes every forward wait (upstream's
+# behaviour: never drops anything).
 # ----------------------------------------------------------------------------------------------------------------
 SYNC = os.environ.get("SPLAT_RASTER_SYNC", "0") == "1"
 _RING = 64
 _SENTINEL = 0xFFFFFFFF
+_CAP_FLOOR = 1 << 20
+_CAP_FACTOR = 4
 
 
 class _Lease:
@@ -68,10 +74,10 @@ class _DeviceState:
     def __init__(self, dev):
         self.dev = dev
         self.scratch = None
-        self.capacity = 1 << 18
+        self.capacity = _CAP_FLOOR
         self.sizes = {}
         self.pools = {}
-        self.last_n = -1
+        self.last_map = None
         self.ring = torch.empty((_RING, 16), dtype=torch.int32, pin_memory=True)   # headers of recent forwards
         self.ring_np = self.ring.numpy().view("uint32")
         self.ring_ptr = self.ring.data_ptr()
@@ -111,8 +117,8 @@ class _DeviceState:
                     break
                 torch.cuda.current_stream(self.dev).synchronize()
             R = int(self.ring_np[slot, 0])
-            if 2 * R > self.capacity:
-                self.capacity = 2 * R
+            if _CAP_FACTOR * R > self.capacity:
+                self.capacity = _CAP_FACTOR * R
             if R > cap:
                 bad += 1
             self.pending.pop(0)
@@ -215,7 +221,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         inp = nat.SgrInputs(nat.ptr(means3D), nat.ptr(opacities), nat.ptr(sh), nat.ptr(colors_precomp), nat.ptr(scales),
                             nat.ptr(rotations), nat.ptr(cov3Ds_precomp))
         out = nat.SgrOutputs(color.data_ptr(), depth.data_ptr(), opac.data_ptr(), radii.data_ptr(), n_touched.data_ptr())
-        wait = SYNC or N != st.last_n            # a new map size: learn its pair count before trusting the capacity
+        this_map = (N, means3D.data_ptr())
+        wait = SYNC or this_map != st.last_map   # a new map: learn its pair count before trusting the capacity
         R = C.c_int64(0)
         while True:
             cap = st.capacity
@@ -227,15 +234,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             ws = nat.SgrWorkspace(saved.data_ptr(), saved_bytes, st.scratch.data_ptr(), st.scratch.numel(), cap, clean, 0)
             rc = lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(R) if wait else None, stream)
             if rc == nat.SGR_ERR_CAPACITY:
-                st.capacity = int(R.value * 2) + 1024
+                st.capacity = int(R.value) * _CAP_FACTOR
                 lease.pool = []                   # (layout changes with the capacity: do not hand this block back)
                 continue
             nat.check(rc, "sgr_forward")
             break
         if wait:
-            st.last_n = N
-            if R.value * 2 > st.capacity:
-                st.capacity = int(R.value * 2)      # head-room so that growth rarely forces a retry
+            st.last_map = this_map
+            if R.value * _CAP_FACTOR > st.capacity:
+                st.capacity = int(R.value) * _CAP_FACTOR
         else:
             st.post(saved.data_ptr(), cap, stream)
         ctx.raster_settings = rs

@@ -92,6 +92,7 @@ struct Common {
 
 // SGR_DEBUG environment variable -- stage-cost experiments only (scripts/stage_times.py), results are wrong when set:
 //   bit 0: preprocess_fwd stops after the cull / compact phase     bit 1: ... and skips the visibility test's arithmetic
+//   bit 2: preprocess_fwd does NOT use the whole-segment test (results stay correct: A/B timing of that test)
 int debug_flags();
 
 // Everything later stages gather BY GAUSSIAN for one view, as ONE 64-byte record (= one HBM sector pair, one L2 line

@@ -275,6 +275,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint32_t vbase_t[kMaxViews + 1], vbase_v[kMaxViews + 1];
   __shared__ uint32_t red[4];
   __shared__ uint32_t vis_bits[kSeg];            // per Gaussian of the segment: bit v = view v of the batch sees it
+  __shared__ float seg_box[4][8];                // per wave: min xyz, max xyz, max trS of its 64 Gaussians
+  __shared__ uint32_t seg_views;                 // bit v = some Gaussian of this segment MAY be visible in view v
   const int N = L.N;
   const int seg = blockIdx.x, seg0 = seg * kSeg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -316,6 +318,86 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         }
       }
     }
+    // Whole-segment test first.  A map that grows keyframe by keyframe (extend_from_pcd_seq appends each keyframe's points) is
+    // spatially coherent: most 256-Gaussian segments lie entirely outside most views.  The segment's bounding box + the
+    // largest tr(Sigma) give, per view, an interval bound of exactly the quantities maybe_visible() tests (view-space
+    // depth, projected centre, radius bound): if even those intervals miss the image the per-Gaussian tests of that view are
+    // skipped.  Conservative by construction (every bound is widened, 0.1 % + 1 px); a randomly ordered map just pays
+    // the ~100 instructions of the reduction.
+    {
+      const bool in = ia < N && isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]) && isfinite(trS);
+      const bool bad = ia < N && !in;                       // non-finite input: let the exact path deal with it
+      float lo[3], hi[3], ts = in ? trS : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { lo[k] = in ? p[k] : 3.0e38f; hi[k] = in ? p[k] : -3.0e38f; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+        ts = fmaxf(ts, __shfl_xor(ts, off));
+      }
+      const unsigned long long anybad = __ballot(bad);
+      if (lane == 0) {
+        seg_box[wv][0] = lo[0]; seg_box[wv][1] = lo[1]; seg_box[wv][2] = lo[2];
+        seg_box[wv][3] = hi[0]; seg_box[wv][4] = hi[1]; seg_box[wv][5] = hi[2];
+        seg_box[wv][6] = ts; seg_box[wv][7] = anybad ? 1.f : 0.f;
+      }
+      if (tid == 0) seg_views = 0u;
+      __syncthreads();
+      if (tid < nviews) {
+        float b0[3], b1[3], tsm = 0.f, anyb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { b0[k] = 3.0e38f; b1[k] = -3.0e38f; }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { b0[k] = fminf(b0[k], seg_box[w][k]); b1[k] = fmaxf(b1[k], seg_box[w][3 + k]); }
+          tsm = fmaxf(tsm, seg_box[w][6]); anyb = fmaxf(anyb, seg_box[w][7]);
+        }
+        bool maybe = true;
+        if (anyb == 0.f && b0[0] <= b1[0] && !(L.dbg & 4)) {
+          const float* vm = mats[tid];
+          // view-space box of the 8 corners (W2C[r][c] = vm[c*4+r])
+          float v0[3], v1[3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            float a = vm[12 + r], bsum = vm[12 + r];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float m = vm[c * 4 + r];
+              a += fminf(m * b0[c], m * b1[c]);
+              bsum += fmaxf(m * b0[c], m * b1[c]);
+            }
+            const float pad = 1e-3f * (fabsf(a) + fabsf(bsum)) + 1e-4f;
+            v0[r] = a - pad; v1[r] = bsum + pad;
+          }
+          if (v1[2] <= kNearPlane) {
+            maybe = false;                                   // the whole box is behind the near plane
+          } else if (v0[2] > kNearPlane) {
+            const float fx = L.W / (2.f * cm.tanfovx), fy = L.H / (2.f * cm.tanfovy);
+            const float iz0 = 1.f / v0[2], iz1 = 1.f / v1[2];
+            // x / z and y / z over the box (z > 0): extremes at the corners
+            const float xz0 = fminf(fminf(v0[0] * iz0, v0[0] * iz1), fminf(v1[0] * iz0, v1[0] * iz1));
+            const float xz1 = fmaxf(fmaxf(v0[0] * iz0, v0[0] * iz1), fmaxf(v1[0] * iz0, v1[0] * iz1));
+            const float yz0 = fminf(fminf(v0[1] * iz0, v0[1] * iz1), fminf(v1[1] * iz0, v1[1] * iz1));
+            const float yz1 = fmaxf(fmaxf(v0[1] * iz0, v0[1] * iz1), fmaxf(v1[1] * iz0, v1[1] * iz1));
+            // pixel centre px = fx * x/z + (W/2)(P02 + 1) - 0.5 (P[r][c] = projraw[c*4+r]); radius bound of maybe_visible with
+            // |T|_F^2 = (fx/z)^2 (1 + cx^2) + (fy/z)^2 (1 + cy^2),  |cx| <= 1.3 tanfovx, |cy| <= 1.3 tanfovy
+            const float limx = 1.3f * cm.tanfovx, limy = 1.3f * cm.tanfovy;
+            const float tn = (fx * fx * (1.f + limx * limx) + fy * fy * (1.f + limy * limy)) * iz0 * iz0;
+            const float rad = ceilf(3.f * sqrtf(tn * tsm * 1.01f + 1.0f)) + 3.f;
+            const float ox = 0.5f * L.W * (cm.projraw[8] + 1.f) - 0.5f, oy = 0.5f * L.H * (cm.projraw[9] + 1.f) - 0.5f;
+            const float px0 = fx * xz0 + ox - rad - 1.f, px1 = fx * xz1 + ox + rad + (kRefTile - 1) + 1.f;
+            const float py0 = fy * yz0 + oy - rad - 1.f, py1 = fy * yz1 + oy + rad + (kRefTile - 1) + 1.f;
+            if (isfinite(px0) && isfinite(px1) && isfinite(py0) && isfinite(py1) && isfinite(rad))
+              maybe = !(px1 < 0.f || py1 < 0.f || px0 >= (float)(L.sgx * kRefTile) || py0 >= (float)(L.sgy * kRefTile));
+          }
+        }
+        if (maybe) atomicOr(&seg_views, 1u << tid);
+      }
+      __syncthreads();
+    }
+    const uint32_t segv = seg_views;
 #pragma unroll 2
     for (int v = 0; v < nviews; ++v) {
       bool pass = false;
@@ -323,7 +405,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         p_radii[v][ia] = 0;                // outputs of the culled majority; phase B overwrites the visible ones
         if (p_ntouched[v]) p_ntouched[v][ia] = 0;
         if (L.dbg & 2) pass = (p[0] + trS == 12345.678f);
-        else pass = maybe_visible(p, trS, L.H, L.W, cm.tanfovx, cm.tanfovy, mats[v], mats[v] + 16, L.sgx, L.sgy);
+        else if (segv & (1u << v)) pass = maybe_visible(p, trS, L.H, L.W, cm.tanfovx, cm.tanfovy, mats[v], mats[v] + 16, L.sgx, L.sgy);
       }
       const unsigned long long m = __ballot(pass);
       if (lane == 0) wtot[v][wv] = (uint32_t)__popcll(m);

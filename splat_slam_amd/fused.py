@@ -248,10 +248,6 @@ class FusedMappingLoop(MappingLoop):
         for name, shape in shapes.items():
             self._acc[name] = plan.view(flat, name, shape)
         self._zero = None
-        if self.world > 1 and self.sync == "zero1":
-            self._zero = {"plan": plan, "param": z(plan.total), "m": z(plan.total), "v": z(plan.total), "shard": z(plan.shard),
-                          "shapes": shapes}
-            self._rehome(range(5))
         self._acc_key, self._acc_ids = key, ids
         self._acc_clean = True     # the gradient sinks are all-zero (every Adam step leaves them so)
         self._stale_iso = 0.0      # (every tensor is new: nothing a prune pass left behind survives)
@@ -265,6 +261,10 @@ class FusedMappingLoop(MappingLoop):
             if st is None or len(st) == 0:
                 gm.optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(p),
                                          "exp_avg_sq": torch.zeros_like(p)}
+        if self.world > 1 and self.sync == "zero1":
+            self._zero = {"plan": plan, "param": z(plan.total), "m": z(plan.total), "v": z(plan.total), "shard": z(plan.shard),
+                          "shapes": shapes}
+            self._rehome(range(5))
 
     def _rehome(self, which):
         """ZeRO-1: parameters and Adam moments of the given groups become views of the flat buffers the collectives work on

@@ -2,8 +2,9 @@
 
   configs[0] shape  room, 20 000 Gaussians, 640x320 (Replica intrinsics after datasets.py:94-104)
   configs[1] shape  room, 300 000 Gaussians, 640x480 (the metric's resolution), bench camera
-  opaque            the same map with log-scale + 1.6 (a converged, surface-covering map): per-tile lists beyond 64 / 256
-                    entries, LDS / in-HBM sorts, the multi-chunk 64-lane backward
+  opaque            a map with log-scale + 1.6 (a converged, surface-covering map; 150 k Gaussians so that the fp64 oracle
+                    stays within a minute per view): per-tile lists beyond 64 / 256 entries, LDS / in-HBM sorts, the
+                    multi-chunk 64-lane backward
 
 Two code paths are pinned against the fp64 oracle (oracle/raster_oracle.py):
 
@@ -123,7 +124,7 @@ WIDTH = {"means3D": 3, "means2D": 3, "opacities": 1, "shs": 3, "scales": 3, "rot
 
 
 @pytest.mark.parametrize("case", [("configs0", 20000, "replica", 0.0, True), ("configs1", 300000, "metric", 0.0, True),
-                                  ("configs1_opaque", 300000, "metric", 1.6, False)], ids=lambda c: c[0])
+                                  ("configs1_opaque", 150000, "metric", 1.6, False)], ids=lambda c: c[0])
 def test_autograd_api_matches_oracle_at_config_size(case):
     name, n, camera, scale_add, deknife = case
     syn, intr, params, cams = _room(n, camera, 1, scale_add=scale_add)
@@ -312,15 +313,15 @@ def test_batched_mapping_path_matches_oracle_configs1():
 
 
 def test_batched_mapping_path_matches_oracle_configs0():
-    _run_batched_case(20000, "replica", 5)
+    _run_batched_case(20000, "replica", 3)
 
 
 def test_batched_mapping_path_matches_oracle_opaque_scene():
     # a converged, surface-covering map: lists beyond 64 entries (LDS sort, multi-chunk backward) at 640x480
-    _run_batched_case(300000, "metric", 3, scale_add=1.6, min_long_tiles=50)
+    _run_batched_case(150000, "metric", 2, scale_add=1.6, min_long_tiles=50)
 
 
 def test_batched_mapping_path_matches_oracle_very_long_lists():
     # the whole 300 k map seen through a 96x64 camera with faint splats: hundreds of centres per 8x8 tile and nothing
     # terminates early, so the walked lists run past 256 entries (4096-key LDS sort build, multi-chunk backward with carries)
-    _run_batched_case(300000, "tiny", 4, opacity_add=-2.0, min_long_tiles=40, min_huge_tiles=10)
+    _run_batched_case(300000, "tiny", 4, opacity_add=-4.5, min_long_tiles=40, min_huge_tiles=10)
