@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--sync", default="zero1", choices=["zero1", "allreduce"],
                     help="multi-GPU gradient exchange: reduce-scatter + sliced Adam + all-gather, or one all-reduce + replicated Adam")
     ap.add_argument("--scale-add", type=float, default=0.0, help="added to every log-scale of the room (1.6 = opaque surfaces)")
+    ap.add_argument("--order", default="random", choices=["random", "keyframe"],
+                    help="order of the Gaussians in memory: random (worst case for the forward's per-segment view test) or the "
+                         "order a SLAM session produces (keyframe after keyframe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the drop-in and opaque-scene legs")
     ap.add_argument("--refine-iters", type=int, default=200, help="final_refine iterations timed for refine it/s (0 = skip)")
@@ -89,7 +92,7 @@ class Bench:
         self.intr = syn.INTRINSICS[args.camera]
 
     # ------------------------------------------------------------------------------------------------ scene + loop
-    def build(self, loop_kind, scale_add, seed_shift=0):
+    def build(self, loop_kind, scale_add, seed_shift=0, order=None):
         """The room at `scale_add`, `views` keyframes around it, and a mapping loop in the state right after a densification
         point (149 iterations without map surgery follow: the metric is quoted AT 300k Gaussians)."""
         import numpy as np
@@ -101,6 +104,9 @@ class Bench:
         params = syn.room_parameters(args.gaussians, seed=43, device=dev)
         if scale_add:
             params["scaling"] = params["scaling"] + scale_add
+        if (order or args.order) == "keyframe":
+            perm = syn.keyframe_order(params["xyz"]).to(dev)
+            params = {k: v[perm].contiguous() for k, v in params.items()}
         # strong scaling: every rank holds the SAME views (it renders its share of them); weak: its own set
         seed = 43 + (self.rank if (self.world > 1 and args.scaling == "weak") else 0) + seed_shift
         cams = syn.make_views(params, args.views, self.intr, dev, seed=seed)
@@ -233,6 +239,20 @@ class Bench:
                 "ms_per_view_fwd_loss_bwd_incl_adam_share": round(ms_it / views, 4),
                 "host_enqueue_ms_per_iteration": round(1e3 * host / steps, 3), "views_per_iteration": views}, loop, cams
 
+    def order_leg(self, steps=30):
+        """preprocess_fwd (K1) on the SAME room stored in keyframe order, with and without the per-segment view test."""
+        loop, cams = self.build("fused", self.args.scale_add, order="keyframe")
+        self.run_steps(loop, 10)
+        el, _ = self.timed(loop, steps)
+        res = {"ms_per_step": round(1e3 * el / steps, 4)}
+        for name, on in (("preprocess_fwd_ms_with_segment_test", 1), ("preprocess_fwd_ms_without_segment_test", 0)):
+            self.lib.sgr_set_option(self.nat.SGR_OPT_SEGMENT_TEST, on)
+            try:
+                res[name] = round(self.profiled(loop, 20, 1 << 0, fused_blend=True)[0][0], 5)
+            finally:
+                self.lib.sgr_set_option(self.nat.SGR_OPT_SEGMENT_TEST, 1)
+        return res
+
     def scene_leg(self, scale_add, steps=40):
         loop, cams = self.build("fused", scale_add)
         self.run_steps(loop, 10)
@@ -356,11 +376,14 @@ def main():
                 out["dropin"] = {"error": repr(e)}
             trace("dropin done")
             torch.cuda.empty_cache()
-            try:
-                out["extra"] = {"opaque_scene": B.scene_leg(args.scale_add + 1.6)}
-            except Exception as e:      # noqa: BLE001
-                out["extra"] = {"opaque_scene": {"error": repr(e)}}
-            trace("opaque done")
+            out["extra"] = {}
+            for name, leg in (("opaque_scene", lambda: B.scene_leg(args.scale_add + 1.6)), ("keyframe_ordered_map", B.order_leg)):
+                try:
+                    out["extra"][name] = leg()
+                except Exception as e:      # noqa: BLE001
+                    out["extra"][name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+                trace(name + " done")
 
     if rank == 0:
         print(json.dumps(out))

@@ -197,10 +197,14 @@ int sgr_query_list_histogram(const SgrWorkspace* ws, int32_t num_gaussians, int3
  *     1: the form the pinned CUDA rasterizer is believed to use: five scalars of projmatrix_raw
  *        (P00, P11, P22, P23, P32), d x_ndc / d p_cam = (P00 / w, 0, -x_hom / w^2) -- i.e. WITHOUT the principal-point terms
  *        P02 / w, P12 / w.  Identical when cx = W/2 and cy = H/2; differs by O(|P02|) otherwise (8e-4 on Replica).  Only
- *        dL/dtau changes; every other gradient is the same.  The oracle has the same switch (UPSTREAM_POSE_JACOBIAN). */
+ *        dL/dtau changes; every other gradient is the same.  The oracle has the same switch (UPSTREAM_POSE_JACOBIAN).
+ *   SGR_OPT_SEGMENT_TEST (default 1): the forward tests every 256-Gaussian segment's bounding box against each view before
+ *     testing its Gaussians one by one (a map that grows keyframe by keyframe is spatially coherent: most segments miss
+ *     most views).  Conservative: results are identical with 0, which exists for A/B timing. */
 #define SGR_OPT_FUSED_BLEND 0
 #define SGR_OPT_UPSTREAM_POSE_JACOBIAN 1
-#define SGR_OPT_COUNT 2
+#define SGR_OPT_SEGMENT_TEST 2
+#define SGR_OPT_COUNT 3
 int sgr_set_option(int32_t option, int32_t value);
 int sgr_get_option(int32_t option);
 

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsplat_hip.so")
 
 SGR_OPT_FUSED_BLEND = 0
 SGR_OPT_UPSTREAM_POSE_JACOBIAN = 1
+SGR_OPT_SEGMENT_TEST = 2
 SGR_OK, SGR_ERR_INVALID, SGR_ERR_WORKSPACE, SGR_ERR_CAPACITY, SGR_ERR_HIP = 0, -1, -2, -3, -4
 
 _fp = C.c_void_p

@@ -23,7 +23,7 @@ void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, const Loss
 void launch_blend_fused(const ViewTab&, int, const LOff&, const float*, const LossTab&, const LossCoef&, hipStream_t);
 
 // run-time options (sgr_set_option)
-static int g_opt[SGR_OPT_COUNT] = {1, 0};
+static int g_opt[SGR_OPT_COUNT] = {1, 0, 1};
 
 static thread_local char g_err[512] = "";
 int set_error(int code, const char* fmt, ...) {
@@ -42,7 +42,7 @@ int set_error(int code, const char* fmt, ...) {
 int debug_flags() {
   static int f = -1;
   if (f < 0) { const char* e = getenv("SGR_DEBUG"); f = e ? atoi(e) : 0; }
-  return f;
+  return f | (g_opt[SGR_OPT_SEGMENT_TEST] ? 0 : 4);
 }
 
 static Layout make_layout(int N, int H, int W, int64_t cap) { return Layout(N, H, W, cap); }

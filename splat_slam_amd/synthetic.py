@@ -74,6 +74,33 @@ def room_parameters(n, seed=43, knn_fn=None, device="cpu"):
                 f_dc=f_dc.contiguous().to(device))
 
 
+def keyframe_order(xyz, K=160, hfov_deg=77.0, seed=43):
+    """Permutation that orders the room the way a SLAM map grows (extend_from_pcd_seq appends a random subsample of each new
+    keyframe's pixels, /root/reference/src/mapper.py:959-962): for keyframe k = 0..K-1 of the orbit, ~N/K not yet taken
+    points inside its horizontal field of view, then whatever is left.  A 256-Gaussian segment then spans ONE keyframe's
+    frustum instead of the whole room."""
+    g = torch.Generator().manual_seed(seed)
+    p = xyz.detach().cpu().double()
+    n = p.shape[0]
+    taken = torch.zeros(n, dtype=torch.bool)
+    order = []
+    per = max(1, n // K)
+    half = math.radians(hfov_deg) * 0.5
+    for k in range(K):
+        phi = 2.0 * math.pi * k / K
+        eye = torch.tensor([math.cos(phi), 0.0, math.sin(phi)], dtype=torch.float64)
+        d = p - eye
+        ang = torch.atan2(d[:, 2], d[:, 0]) - phi
+        ang = torch.atan2(torch.sin(ang), torch.cos(ang)).abs()
+        cand = torch.nonzero((ang < half) & ~taken).flatten()
+        if cand.numel() > per:
+            cand = cand[torch.randperm(cand.numel(), generator=g)[:per]]
+        taken[cand] = True
+        order.append(cand)
+    order.append(torch.nonzero(~taken).flatten())
+    return torch.cat(order)
+
+
 def orbit_w2c(k, K, radius=1.0):
     """Camera k of K on a circle of radius 1 m at mid height, looking outward, yaw sweeping 360 degrees."""
     phi = 2.0 * math.pi * k / K

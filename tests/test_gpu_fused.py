@@ -483,3 +483,37 @@ def test_fused_tile_kernel_equals_the_two_separate_kernels_bitwise(scene):
     assert a["flat"].abs().max() > 0
     for k in a:
         assert torch.equal(a[k], b[k]), (scene, k, (a[k].float() - b[k].float()).abs().max().item())
+
+
+def test_segment_view_test_is_conservative_bitwise_same_results():
+    """SGR_OPT_SEGMENT_TEST: skipping whole 256-Gaussian segments whose bounding box misses a view never changes a result --
+    on a keyframe-ordered map (where it skips most segment / view pairs) and on a randomly ordered one."""
+    from splat_slam_amd import _native as nat
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    lib = nat.lib()
+    intr = syn.INTRINSICS["tiny"]
+    for order in ("keyframe", "random"):
+        params = syn.room_parameters(40000, seed=9, device=DEV)
+        params["scaling"] = params["scaling"] + 0.8
+        if order == "keyframe":
+            perm = syn.keyframe_order(params["xyz"], K=40).to(DEV)
+            params = {k: v[perm].contiguous() for k, v in params.items()}
+        cams = syn.make_views(params, 6, intr, DEV, seed=9)
+        res = []
+        try:
+            for on in (1, 0):
+                lib.sgr_set_option(nat.SGR_OPT_SEGMENT_TEST, on)
+                f = _loop(FusedMappingLoop, syn, params, cams, range(6))
+                f._ensure_state()
+                f._activate()
+                f._run_views(cams, stats=True)
+                torch.cuda.synchronize()
+                res.append(dict(flat=f._acc["flat"].clone(), radii=torch.stack([f._views[c.uid].radii for c in cams]).clone(),
+                                nt=torch.stack([f._views[c.uid].n_touched for c in cams]).clone(),
+                                loss=torch.cat([f._views[c.uid].loss for c in cams]).clone()))
+        finally:
+            lib.sgr_set_option(nat.SGR_OPT_SEGMENT_TEST, 1)
+        for k in res[0]:
+            assert torch.equal(res[0][k], res[1][k]), (order, k)
+        assert int((res[0]["radii"] > 0).sum()) > 1000
