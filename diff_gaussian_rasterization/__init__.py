@@ -78,6 +78,7 @@ class _DeviceState:
         self.sizes = {}
         self.pools = {}
         self.last_map = None
+        self.last_pairs = 0               # pair count of the most recent forward whose header has arrived
         self.ring = torch.empty((_RING, 16), dtype=torch.int32, pin_memory=True)   # headers of recent forwards
         self.ring_np = self.ring.numpy().view("uint32")
         self.ring_ptr = self.ring.data_ptr()
@@ -117,6 +118,7 @@ class _DeviceState:
                     break
                 torch.cuda.current_stream(self.dev).synchronize()
             R = int(self.ring_np[slot, 0])
+            self.last_pairs = R
             if _CAP_FACTOR * R > self.capacity:
                 self.capacity = _CAP_FACTOR * R
             if R > cap:
@@ -231,7 +233,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 st.scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
             lease, clean = st.lease(N, H, W, cap, saved_bytes)
             saved = lease.block
-            ws = nat.SgrWorkspace(saved.data_ptr(), saved_bytes, st.scratch.data_ptr(), st.scratch.numel(), cap, clean, 0)
+            ntiles = ((H + 7) // 8) * ((W + 7) // 8)
+            ws = nat.SgrWorkspace(saved.data_ptr(), saved_bytes, st.scratch.data_ptr(), st.scratch.numel(), cap, clean,
+                                  max(1, st.last_pairs // ntiles))
             rc = lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(R) if wait else None, stream)
             if rc == nat.SGR_ERR_CAPACITY:
                 st.capacity = int(R.value) * _CAP_FACTOR
@@ -241,6 +245,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             break
         if wait:
             st.last_map = this_map
+            st.last_pairs = int(R.value)
             if R.value * _CAP_FACTOR > st.capacity:
                 st.capacity = int(R.value) * _CAP_FACTOR
         else:

@@ -112,7 +112,9 @@ typedef struct SgrWorkspace {
   int32_t counters_clean;      /* != 0: the per-tile pair counters inside `saved` are zero -- every completed forward
                                   (same N, H, W, capacity) leaves them so; 0 for a fresh / foreign block: the library
                                   then spends one extra launch zeroing them */
-  int32_t reserved;
+  int32_t mean_list_hint;      /* > 0: the caller's estimate of the mean number of pairs per 8x8 tile (e.g. the last pair count
+                                  it saw / tiles): picks the in-LDS sort build of the compositing kernels.  0: derived from
+                                  `capacity` (right when the capacity is ~2x the expected pair count) */
 } SgrWorkspace;
 
 typedef struct SgrGradOutputs {

@@ -12,7 +12,10 @@ tag = sys.argv[1]
 out = os.path.join(ROOT, "gpurun_out", tag)
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "6", "--no-cpu-baseline", "--refine-iters", "0"]
+# the profiled command: the headline loop (fused tile kernel) + bench.py's own un-fused / fused roofline legs, so that the trace
+# holds blend_bwd_kernel<true> launches (the kernel `roofline` is quoted for) next to the fused kernel's
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "6", "--no-cpu-baseline", "--refine-iters", "0",
+         "--no-extras"]
 
 
 def short(name):
@@ -27,6 +30,14 @@ def run(args, d):
         print("FAILED", " ".join(cmd), r.stderr[-800:])
     return " ".join(cmd[:len(args) + 1]) + " -- python bench.py " + " ".join(BENCH[2:])
 
+
+# ---- 0. the plain bench line (defaults), for tests/test_bench_contract.py and BASELINE.md
+r0 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], cwd=ROOT, env=env, capture_output=True, text=True)
+line = [l for l in r0.stdout.splitlines() if l.startswith("{")]
+if line:
+    open(os.path.join(out, tag + "_bench_line.json"), "w").write(line[-1] + "\n")
+else:
+    print("bench.py failed", r0.stderr[-1500:])
 
 # ---- 1. kernel trace + stats
 cmd = run(["--kernel-trace", "--stats"], "/tmp/prof_kt")

@@ -35,7 +35,7 @@ class SgrOutputs(C.Structure):
 
 class SgrWorkspace(C.Structure):
     _fields_ = [("saved", _fp), ("saved_bytes", C.c_size_t), ("scratch", _fp), ("scratch_bytes", C.c_size_t),
-                ("capacity", C.c_int64), ("counters_clean", C.c_int32), ("reserved", C.c_int32)]
+                ("capacity", C.c_int64), ("counters_clean", C.c_int32), ("mean_list_hint", C.c_int32)]
 
 
 class SgrGradOutputs(C.Structure):

@@ -21,6 +21,7 @@ void launch_zero_heads(const ViewTab&, int, const LOff&, size_t, hipStream_t);
 void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
 void launch_blend_bwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
 void launch_blend_fused(const ViewTab&, int, const LOff&, const float*, const LossTab&, const LossCoef&, hipStream_t);
+bool blend_can_fuse(const LOff&);
 
 // run-time options (sgr_set_option)
 static int g_opt[SGR_OPT_COUNT] = {1, 0, 1};
@@ -197,7 +198,7 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
   ViewTab tab = {};
   tab_set_view(tab, 0, s, out, ws);
   Common cm = make_common(s);
-  if (int rc = forward_batch(tab, 1, L, cm, *in, st)) return rc;
+  if (int rc = forward_batch(tab, 1, L, cm, *in, st, ws->counters_clean != 0)) return rc;
   if (num_rendered_host) {
     uint32_t R = 0;
     HIP_TRY(hipMemcpyAsync(&R, &((SavedHeader*)((char*)ws->saved + L.o_hdr))->num_rendered, 4, hipMemcpyDeviceToHost, st));
@@ -205,7 +206,9 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
     *num_rendered_host = R;
     if ((int64_t)R > L.cap) return set_error(SGR_ERR_CAPACITY, "%u (tile, Gaussian) pairs exceed capacity %lld", R, (long long)L.cap);
   }
-  launch_blend_fwd(tab, 1, L.dev(), s->bg, nullptr, nullptr, st);          // K4: per-tile sort + compositing
+  LOff d1 = L.dev();
+  d1.mean_hint = ws->mean_list_hint;
+  launch_blend_fwd(tab, 1, d1, s->bg, nullptr, nullptr, st);          // K4: per-tile sort + compositing
   HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
@@ -288,6 +291,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
   }
   Layout L = make_layout(f.settings.num_gaussians, f.settings.image_height, f.settings.image_width, f.ws.capacity);
   LOff d = L.dev();
+  d.mean_hint = f.ws.mean_list_hint;
   Common cm = make_common(&f.settings);
   const int HW = f.settings.image_height * f.settings.image_width;
   for (int base = 0; base < num_views; base += kMaxViews) {
@@ -326,7 +330,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
     LossCoef lc = {alpha / (3.f * (float)HW), (1.f - alpha) / (float)HW, rgb_boundary_threshold};
     // forward, loss and backward of a tile run in the same wave (one launch) unless the option is off (profiling the two
     // halves separately, bitwise A/B tests)
-    const bool fused_blend = g_opt[SGR_OPT_FUSED_BLEND] != 0;
+    const bool fused_blend = g_opt[SGR_OPT_FUSED_BLEND] != 0 && blend_can_fuse(d);
     if (fused_blend) launch_blend_fused(tab, nv, d, f.settings.bg, lt, lc, st);
     else launch_blend_fwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
     const bool fuse = fused && num_views <= kMaxViews;

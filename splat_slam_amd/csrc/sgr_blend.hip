@@ -26,9 +26,9 @@
 
 namespace sgr {
 
-// keys sorted inside the wave's LDS slice: two builds of the forward kernel, picked per launch from the expected
-// list length (capacity / tiles): "light" keeps 8 workgroups per CU resident, "heavy" trades occupancy for LDS.
-constexpr int kSortLight = 256, kSortHeavy = 4096;
+// keys sorted inside the wave's LDS slice: three builds of the forward kernel, picked per launch from the expected
+// list length (capacity / tiles): "light" keeps 8 workgroups per CU resident, "mid" 3, "heavy" 1 (LDS for occupancy).
+constexpr int kSortLight = 256, kSortMid = 1024, kSortHeavy = 4096;
 
 // workgroup -> 16x16 super tile with an XCD-aware remap: hardware places block b on XCD b%8, we hand every XCD a
 // contiguous run of super tiles so neighbouring tiles (which share Gaussians) hit the same 4 MiB L2.
@@ -748,6 +748,15 @@ static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, co
   hipLaunchKernelGGL((blend_fwd_kernel<SORT_MAX, FUSED>), dim3(grid, nviews), dim3(256), lds, st, tab, L, bg, lt, lc);
 }
 
+// 0 light / 1 mid / 2 heavy, from the expected mean list length: SgrWorkspace.mean_list_hint (x 2 for safety) when the caller
+// gives one, else capacity / tiles / 2 (the fused loop sizes `capacity` at 2x the pair count it has seen).  Tiles beyond the
+// build's key count fall back to the in-HBM sort, which is correct but slow, so a build is chosen when the estimated mean
+// is a factor ~4 below its key count.
+static int blend_build(const LOff& L) {
+  const int64_t mean_len = L.mean_hint > 0 ? 2 * (int64_t)L.mean_hint : L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
+  return mean_len > 256 ? 2 : (mean_len > 64 ? 1 : 0);
+}
+
 // lt: per-view loss pointers (gt_image[v] == NULL -> plain render).  With a loss, every 8x8 tile also leaves one
 // LossPart in lt.parts[v][tile]; launch_mapping_loss_final adds them up in fixed order.
 void launch_blend_fwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab* lt, const LossCoef* lc,
@@ -757,19 +766,22 @@ void launch_blend_fwd(const ViewTab& tab, int nviews, const LOff& L, const float
   LossCoef nocoef = {0.f, 0.f, 0.f};
   const LossTab& t = lt ? *lt : none;
   const LossCoef& c = lc ? *lc : nocoef;
-  // the caller sizes `capacity` at ~2x the pair count it has seen: capacity / tiles / 2 estimates the mean list length
-  const int64_t mean_len = L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
-  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy, false>(tab, nviews, L, bg, t, c, st);
+  const int build = blend_build(L);
+  if (build == 2) launch_blend_fwd_t<kSortHeavy, false>(tab, nviews, L, bg, t, c, st);
+  else if (build == 1) launch_blend_fwd_t<kSortMid, false>(tab, nviews, L, bg, t, c, st);
   else launch_blend_fwd_t<kSortLight, false>(tab, nviews, L, bg, t, c, st);
 }
+
+// The fused tile kernel exists in the light build only: with thousands of keys per wave in LDS one or three workgroups fit a
+// CU, and a backward that runs at that occupancy is slower than blend_bwd_kernel on its own (measured on the opaque room,
+// mean list 93: fused heavy 2.80 ms vs 1.33 + 0.70 ms for the pair) -- long-list maps run the two kernels.
+bool blend_can_fuse(const LOff& L) { return blend_build(L) == 0; }
 
 // forward + mapping loss + backward of every tile in ONE launch (needs lt / lc: the loss is what links the two halves)
 void launch_blend_fused(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab& lt, const LossCoef& lc,
                         hipStream_t st) {
   ProfScope prof(PK_BLEND_FUSED, st);
-  const int64_t mean_len = L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
-  if (mean_len > 48) launch_blend_fwd_t<kSortHeavy, true>(tab, nviews, L, bg, lt, lc, st);
-  else launch_blend_fwd_t<kSortLight, true>(tab, nviews, L, bg, lt, lc, st);
+  launch_blend_fwd_t<kSortLight, true>(tab, nviews, L, bg, lt, lc, st);
 }
 
 // lt / lc given: the pixel gradients are the code bytes blend_fwd's loss epilogue wrote for these views

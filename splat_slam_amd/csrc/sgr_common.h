@@ -75,7 +75,7 @@ struct ViewTab {
 };
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {
-  int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg;
+  int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg, mean_hint;
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
@@ -173,7 +173,7 @@ struct Layout {
   }
   __host__ LOff dev() const {
     LOff d;
-    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags();
+    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags(); d.mean_hint = 0;
     d.cap = cap;
     d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_grec = o_grec;
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;

@@ -508,5 +508,8 @@ class GaussianModel:
         self.prune_points(doomed)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        """accum[visible] += |dL/d(mean2D)|, denom[visible] += 1 (gaussian_model.py:738-742), mask-free (no nonzero() sync)."""
+        seen = update_filter.unsqueeze(-1)
+        norm = torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1, keepdim=True)
+        self.xyz_gradient_accum += torch.where(seen, norm, torch.zeros_like(norm))
+        self.denom += seen.to(self.denom.dtype)

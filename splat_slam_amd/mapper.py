@@ -95,6 +95,15 @@ class MappingLoop:
             opt_params.append({"params": [viewpoint.exposure_b], "lr": 0.01, "name": "exposure_b_{}".format(viewpoint.uid)})
         self.keyframe_optimizers = torch.optim.Adam(opt_params) if opt_params else None
 
+    def _visible_stats(self, viewspace_points, vis, radii):
+        """max_radii2D[vis] = max(max_radii2D[vis], radii[vis]) and add_densification_stats (mapper.py:332-335,523-529,
+        gaussian_model.py:738-742) written without boolean-mask indexing: the same values element for element, but a mask
+        index is a nonzero() -- a host synchronisation and three extra kernels -- per statement, 36 of them per 12-view
+        iteration on the GPU."""
+        gm = self.gaussians
+        gm.max_radii2D = torch.where(vis, torch.max(gm.max_radii2D, radii), gm.max_radii2D)
+        gm.add_densification_stats(viewspace_points, vis)
+
     # ---------------------------------------------------------------------------------- mapper.py:303-353
     def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
         n_touched = None
@@ -107,8 +116,7 @@ class MappingLoop:
             loss_init = self.loss_fn(self.config["mapping"], image, depth, viewpoint, opacity, initialization=True)
             loss_init.backward()
             with torch.no_grad():
-                self.gaussians.max_radii2D[vis] = torch.max(self.gaussians.max_radii2D[vis], radii[vis])
-                self.gaussians.add_densification_stats(vsp, vis)
+                self._visible_stats(vsp, vis, radii)
                 if mapping_iteration % self.init_gaussian_update == 0:
                     self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.init_gaussian_th,
                                                      self.init_gaussian_extent, None)
@@ -164,9 +172,7 @@ class MappingLoop:
                     # refreshes occ_aware_visibility and returns before optimizer.step()/zero_grad()
                     return False
                 for idx in range(len(vsp_acm)):
-                    self.gaussians.max_radii2D[vis_acm[idx]] = torch.max(self.gaussians.max_radii2D[vis_acm[idx]],
-                                                                         radii_acm[idx][vis_acm[idx]])
-                    self.gaussians.add_densification_stats(vsp_acm[idx], vis_acm[idx])
+                    self._visible_stats(vsp_acm[idx], vis_acm[idx], radii_acm[idx])
                 update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
                 if update_gaussian:
                     self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,

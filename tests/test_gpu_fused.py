@@ -146,8 +146,7 @@ def _mg_state(f):
     out.update({"v_" + k: st[k]["exp_avg_sq"].detach().cpu().clone() for k in ["xyz", "scaling"]})
     out["exposure"] = f._exp.param[:8].detach().cpu().clone()
     out["occ"] = torch.stack([v for _, v in sorted(f.occ_aware_visibility.items())]).cpu()
-    out["accum"] = gm.xyz_gradient_accum.detach().cpu().clone()
-    return out
+    return out        # (the densification statistics are per rank until the all-reduce in front of a densification)
 
 
 def _mg_worker(rank, world, port, out, sync, split, span, reset_at):
