@@ -284,6 +284,7 @@ def build_tile_lists(pp: Preprocessed, H: int, W: int, depth_sort_key=None):
 
 
 KNIFE_BAND = 5e-4          # relative half-width of "fp32 rounding may decide this cut-off" for alpha (see knife_edge_gaussians)
+KNIFE_PIXEL_ERR = 4e-4     # ... or, if larger, what this much error (in pixels) of the projected centre does to alpha
 KNIFE_BAND_T = 1e-4        # ... and for the transmittance thresholds (products of a few (1 - alpha): far better conditioned)
 
 
@@ -340,7 +341,12 @@ def blend(pp: Preprocessed, tile_ids, gauss_ids, s: OracleSettings, dt, knife=No
             # (pixel, splat) pairs that sit within KNIFE_BAND of a cut-off: alpha vs 1/255 (pixel centres carry ~1e-4 px of
             # fp32 error, which the exponent turns into up to ~1e-4 relative in alpha), T' vs 1e-4, T' vs 0.5 (n_touched)
             rawd, Td = raw.detach(), T_after.detach()
-            near = (power.detach() <= 0) & ((rawd * 255.0 - 1.0).abs() < KNIFE_BAND)
+            # d(ln alpha) = |grad power| * d(centre): steep sub-pixel splats (conic ~ 1/0.3) far from the image origin turn
+            # a few fp32 ulps of the projected centre (~1e-4 px at coordinate 500) into > 5e-4 relative in alpha
+            gx = (con[:, 0] * dx + con[:, 1] * dy).detach()
+            gy = (con[:, 1] * dx + con[:, 2] * dy).detach()
+            band = torch.clamp_min(torch.sqrt(gx * gx + gy * gy) * KNIFE_PIXEL_ERR, KNIFE_BAND)
+            near = (power.detach() <= 0) & ((rawd * 255.0 - 1.0).abs() < band)
             near |= keep & (T_before.detach() >= T_EPS) & (((Td / T_EPS - 1.0).abs() < KNIFE_BAND_T) | ((Td / N_TOUCHED_T - 1.0).abs() < KNIFE_BAND_T))
             if bool(near.any()):
                 # ... and every splat composited at a pixel that has such a pair: a flip there changes their T / "colour

@@ -55,17 +55,18 @@ class _FusedMappingLoss(torch.autograd.Function):
         dev = image.device
         _, H, W = image.shape
         image, depth = image.contiguous(), depth.contiguous()
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        d_img = torch.empty_like(image)
-        d_dep = torch.empty_like(depth)
-        d_a = torch.empty(1, dtype=torch.float32, device=dev)
-        d_b = torch.empty(1, dtype=torch.float32, device=dev)
-        scratch = torch.empty(1024 * 16, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            nat.check(lib.sgr_mapping_loss(H, W, image.data_ptr(), depth.data_ptr(), gt_image.data_ptr(), gt_depth.data_ptr(),
-                                           nat.ptr(exp_a), nat.ptr(exp_b), alpha, thr, 1.0, loss.data_ptr(), d_img.data_ptr(),
-                                           d_dep.data_ptr(), d_a.data_ptr(), d_b.data_ptr(), scratch.data_ptr(), scratch.numel(),
-                                           torch.cuda.current_stream(dev).cuda_stream), "sgr_mapping_loss")
+        # one arena per call: dL/dimage | dL/ddepth | loss, d/da, d/db | 16 KiB of reduction scratch
+        hw = H * W
+        arena = torch.empty(4 * hw + 4 + 4096, dtype=torch.float32, device=dev)
+        d_img, d_dep = arena[:3 * hw].view(3, H, W), arena[3 * hw:4 * hw].view(depth.shape)
+        loss, d_a, d_b = arena[4 * hw:4 * hw + 1], arena[4 * hw + 1:4 * hw + 2], arena[4 * hw + 2:4 * hw + 3]
+        scratch = arena[4 * hw + 4:]
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        nat.check(lib.sgr_mapping_loss(H, W, image.data_ptr(), depth.data_ptr(), gt_image.data_ptr(), gt_depth.data_ptr(),
+                                       nat.ptr(exp_a), nat.ptr(exp_b), alpha, thr, 1.0, loss.data_ptr(), d_img.data_ptr(),
+                                       d_dep.data_ptr(), d_a.data_ptr(), d_b.data_ptr(), scratch.data_ptr(), 4 * scratch.numel(),
+                                       torch.cuda.current_stream().cuda_stream), "sgr_mapping_loss")
         ctx.save_for_backward(d_img, d_dep, d_a, d_b)
         ctx.has_exp = exp_a is not None
         return loss[0]

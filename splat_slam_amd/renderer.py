@@ -11,11 +11,10 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, mask=None):
     if pc.get_xyz.shape[0] == 0:
         return None
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # the dummy whose .grad receives dL/d(mean2D) (:43-52).  The reference builds `zeros_like(...) + 0` and retains the grad of
+    # that non-leaf; a leaf of zeros is the same tensor with the same .grad and one kernel instead of two
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device, requires_grad=True)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(
