@@ -343,9 +343,9 @@ def blend(pp: Preprocessed, tile_ids, gauss_ids, s: OracleSettings, dt, knife=No
             rawd, Td = raw.detach(), T_after.detach()
             # d(ln alpha) = |grad power| * d(centre): steep sub-pixel splats (conic ~ 1/0.3) far from the image origin turn
             # a few fp32 ulps of the projected centre (~1e-4 px at coordinate 500) into > 5e-4 relative in alpha
-            gx = (con[:, 0] * dx + con[:, 1] * dy).detach()
-            gy = (con[:, 1] * dx + con[:, 2] * dy).detach()
-            band = torch.clamp_min(torch.sqrt(gx * gx + gy * gy) * KNIFE_PIXEL_ERR, KNIFE_BAND)
+            dpx = (con[:, 0] * dx + con[:, 1] * dy).detach()
+            dpy = (con[:, 1] * dx + con[:, 2] * dy).detach()
+            band = torch.clamp_min(torch.sqrt(dpx * dpx + dpy * dpy) * KNIFE_PIXEL_ERR, KNIFE_BAND)
             near = (power.detach() <= 0) & ((rawd * 255.0 - 1.0).abs() < band)
             near |= keep & (T_before.detach() >= T_EPS) & (((Td / T_EPS - 1.0).abs() < KNIFE_BAND_T) | ((Td / N_TOUCHED_T - 1.0).abs() < KNIFE_BAND_T))
             if bool(near.any()):

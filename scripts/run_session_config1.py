@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--oracle-views", type=int, default=3)
     ap.add_argument("--world", type=int, default=400000, help="Gaussians of the ground-truth room the keyframes observe")
     ap.add_argument("--moved-every", type=int, default=10, help="every k-th past keyframe gets a refined pose / depth (0 = none)")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--max-gaussians", type=int, default=4000000)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     from splat_slam_amd import synthetic as syn
@@ -91,6 +93,12 @@ def main():
         torch.cuda.synchronize()
         t_kf.append(time.perf_counter() - t1)
         n_hist.append(int(loop.gaussians.get_xyz.shape[0]))
+        if a.verbose:
+            worst = max((vb.pairs for vb in loop._views.values()), default=0)
+            print("[kf %3d] %-7s N %8d  pairs(max over cameras) %9d  capacity %9d  %.2f s  mem %.1f GB" % (
+                f[0], status[-1], n_hist[-1], worst, loop._cap, t_kf[-1], torch.cuda.memory_allocated() / 2 ** 30), file=sys.stderr, flush=True)
+        if n_hist[-1] > a.max_gaussians:
+            raise RuntimeError("map grew to %d Gaussians (> --max-gaussians): the synthetic feed does not converge" % n_hist[-1])
     t_map = time.perf_counter() - t0
     mapped = status.count("mapped")
     t1 = time.perf_counter()
