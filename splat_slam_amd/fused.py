@@ -182,6 +182,7 @@ class FusedMappingLoop(MappingLoop):
         self._replicated = 0         # > 0: every rank runs the identical iteration, no exchange (initialize_map, final_refine)
         self._acc_ids = None        # id() of the five parameter tensors the sinks belong to
         self._stale_iso = 0.0       # isotropy weight whose gradient a prune pass left on the current `_scaling` tensor
+        self.max_pairs = 1 << 28    # a view with more (tile, Gaussian) pairs than this is a degenerate map: fail loudly, not by OOM
 
     def reset(self):
         super().reset()
@@ -405,6 +406,12 @@ class FusedMappingLoop(MappingLoop):
             break
         vb.pairs = int(R.value)
         vb.clean = True
+        if vb.pairs > self.max_pairs:
+            gm = self.gaussians
+            with torch.no_grad():
+                big = float(gm.get_scaling.max())
+            raise RuntimeError(f"camera {cam.uid}: {vb.pairs} (tile, Gaussian) pairs for {N} Gaussians -- more than max_pairs = "
+                               f"{self.max_pairs}; the map has degenerated (largest scale {big:.3g} m)")
 
     def _mark_clean(self, cams):
         """A completed forward leaves the per-tile counters of a saved block zero: later calls skip the zeroing launch."""
