@@ -775,12 +775,15 @@ class FusedMappingLoop(MappingLoop):
         self._since_check = 0
         worst = 0
         for uid, vb in self._views.items():
-            if vb.saved is None or not vb.mv:
+            if vb.saved is None or not vb.mv or not vb.clean:      # (a block no forward has run on yet holds no header)
                 continue
             R, ov = C.c_int64(0), C.c_int32(0)
             nat.check(self.lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), self._stream()), "sgr_query")
             self.overflow_events += int(bool(ov.value))
             vb.pairs = int(R.value)
+            if vb.pairs > self.max_pairs:
+                raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
+                                   "the map has degenerated")
             worst = max(worst, vb.pairs)
         if worst * 1.5 > self._cap:
             self._cap = max(1 << 16, 2 * worst)
