@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--world", type=int, default=400000, help="Gaussians of the ground-truth room the keyframes observe")
     ap.add_argument("--moved-every", type=int, default=10, help="every k-th past keyframe gets a refined pose / depth (0 = none)")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="HIP-event time of every kernel kind over the mapping phase (adds overhead)")
     ap.add_argument("--max-gaussians", type=int, default=4000000)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -85,6 +86,8 @@ def main():
             return r
         setattr(gm_cls, name, timed)
     status, n_hist, t_kf = [], [], []
+    if a.profile:
+        loop.lib.sgr_profile_enable(0x1ff)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for f in frames:
@@ -101,6 +104,24 @@ def main():
             raise RuntimeError("map grew to %d Gaussians (> --max-gaussians): the synthetic feed does not converge" % n_hist[-1])
     t_map = time.perf_counter() - t0
     mapped = status.count("mapped")
+    kernel_ms = None
+    if a.profile:
+        import ctypes as C
+        ms, cnt = (C.c_float * 9)(), (C.c_int64 * 9)()
+        loop.lib.sgr_profile_read(ms, cnt)
+        loop.lib.sgr_profile_enable(0)
+        names = ["preprocess_fwd", "tile_scan", "scatter", "blend_fused", "-", "blend_fwd", "-", "blend_bwd", "preprocess_bwd"]
+        kernel_ms = {n: {"total_s": round(float(ms[i]) / 1e3, 3), "launches": int(cnt[i]), "avg_ms": round(float(ms[i]) / max(1, int(cnt[i])), 4)}
+                     for i, n in enumerate(names) if int(cnt[i])}
+        from splat_slam_amd import _native as nat
+        cam = loop.last_used[0]
+        vb = loop._views[cam.uid]
+        ws = nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), loop._cap)
+        hist = (C.c_int64 * 8)()
+        nat.check(loop.lib.sgr_query_list_histogram(C.byref(ws), int(loop.gaussians.get_xyz.shape[0]), intr["H"], intr["W"], hist,
+                                                    torch.cuda.current_stream().cuda_stream), "hist")
+        kernel_ms["tiles_by_walked_list_length_last_view"] = dict(zip(["0", "1-4", "5-8", "9-16", "17-32", "33-64", "65-256", ">256"],
+                                                                      [int(x) for x in hist]))
     t1 = time.perf_counter()
     scores = sess.finish(refine_iters=a.refine)
     torch.cuda.synchronize()
@@ -147,7 +168,7 @@ def main():
         "map_surgery_ms_per_keyframe": round(1e3 * surgery_s[0] / max(1, mapped + 1), 3),
         "final_refine": {"iters": a.refine, "wall_s": round(t_refine, 3), "it_per_s": round(a.refine / t_refine, 1) if a.refine else None},
         "feed_s_rendering_ground_truth": round(t_feed, 2), "moved_keyframes_deformed": len(moved),
-        "overflow_events": loop.overflow_events,
+        "overflow_events": loop.overflow_events, "kernel_times_mapping_phase": kernel_ms,
         "psnr_all_keyframes_mean": round(float(np.mean(scores)), 3), "psnr_min": round(float(np.min(scores)), 3),
         "psnr_hip_vs_oracle_render_of_the_same_map": cmp_rows, "oracle_threads": ncores,
     }
