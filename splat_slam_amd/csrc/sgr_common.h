@@ -49,8 +49,10 @@ struct SavedHeader {
   uint32_t overflow;       // != 0 when R > capacity (pairs were dropped)
   uint32_t sorted_count;   // number of pairs actually binned = min(R, capacity)
   uint32_t num_visible;    // V: Gaussians with radii > 0
-  uint32_t num_overfull;   // tiles with more than kBucket pairs (scatter_kernel re-bins only those)
-  uint32_t pad[11];
+  uint32_t num_overfull;   // tiles with more than kBucket pairs (scatter_kernel completes only those)
+  uint32_t ovf_cursor;     // K1's append cursor into the overflow list (pairs whose rank in their tile is >= kBucket); K2 resets it
+  uint32_t ovf_count;      // ... its final value for this forward (written by K2, read by K3)
+  uint32_t pad[9];
 };
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -79,8 +81,11 @@ struct LOff {
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
-      o_seg_list, o_vismask, o_entries, o_bucket, o_partials, o_tau_part, o_gradrec, o_taurec;
+      o_seg_list, o_vismask, o_entries, o_bucket, o_ovf, o_partials, o_tau_part, o_gradrec, o_taurec;
 };
+// one pair that did not fit its tile's bucket: K1 knows its tile and its rank inside the tile (the counting atomic returned it)
+// but not yet where the tile's run starts -- K3 files it at start(tile) + rank once K2 has scanned the counts
+struct __attribute__((aligned(16))) OvfEntry { uint32_t tile, rank; uint64_t key; };
 // shared (view independent) scalars of a batch
 struct Common {
   int deg, M;
@@ -123,7 +128,7 @@ struct Layout {
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
       o_seg_list, o_vismask, saved_bytes, zero_bytes;
   // scratch (forward)
-  size_t o_entries, o_bucket;
+  size_t o_entries, o_bucket, o_ovf;
   // scratch (backward)
   size_t o_partials, o_tau_part, o_gradrec, o_taurec, scratch_bytes;
   int pre_blocks, nseg;
@@ -163,6 +168,7 @@ struct Layout {
     o = 0;
     o_entries = take(c * 8);
     o_bucket = take((size_t)ntiles * kBucket * 8);
+    o_ovf = take(c * sizeof(OvfEntry));
     // (the backward arrays FOLLOW the forward ones: in the fused tile kernel one tile's wave writes its partials while the
     // waves of other tiles still read their buckets / runs)
     o_partials = take(c * 48);
@@ -179,7 +185,7 @@ struct Layout {
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;
     d.o_n_contrib = o_n_contrib; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
     d.o_block_base_t = o_block_base_t; d.o_block_base_v = o_block_base_v; d.o_vis_list = o_vis_list;
-    d.o_seg_list = o_seg_list; d.o_vismask = o_vismask; d.o_entries = o_entries; d.o_bucket = o_bucket; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
+    d.o_seg_list = o_seg_list; d.o_vismask = o_vismask; d.o_entries = o_entries; d.o_bucket = o_bucket; d.o_ovf = o_ovf; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
     d.o_gradrec = o_gradrec; d.o_taurec = o_taurec;
     return d;
   }
@@ -320,6 +326,12 @@ __device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
   v += dpp_u<DPP_ROW_SHR8>(v);
   v += dpp_u<DPP_ROW_BCAST15, 0xa>(v);
   v += dpp_u<DPP_ROW_BCAST31, 0xc>(v);
+  return v;
+}
+// maximum of a non-negative int over the wave (in every lane)
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
   return v;
 }
 // exclusive prefix of `v` inside a 256-thread block (4 waves) + block total; `red` = 4 uints of LDS

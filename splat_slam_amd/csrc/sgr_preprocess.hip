@@ -503,11 +503,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       if (pair) return atomicAdd((unsigned long long*)c, 0x100000001ull);
       return (unsigned long long)atomicAdd(c, 1u);
     };
-    auto consume = [&](unsigned long long old, int tx, int ty, bool pair) {
+    SavedHeader* hdr = (SavedHeader*)(saved + L.o_hdr);
+    OvfEntry* ovf = (OvfEntry*)(p_scratch[v] + L.o_ovf);
+    // a pair whose tile's bucket is full joins the view's overflow list (K3 files it once the tile starts are known); the
+    // lanes of a wave that overflow in the same step share ONE atomic on the list cursor
+    auto spill = [&](bool want, uint32_t tile, uint32_t rank) {
+      const unsigned long long m = __ballot(want);
+      if (m == 0ull) return;
+      const int leader = __ffsll((long long)m) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&hdr->ovf_cursor, (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+      if (want) {
+        const uint64_t pos = (uint64_t)base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if ((int64_t)pos < L.cap) ovf[pos] = OvfEntry{tile, rank, key};
+      }
+    };
+    auto consume = [&](unsigned long long old, int tx, int ty, bool pair, bool on) {
       const uint32_t t0 = (uint32_t)(ty * L.gx + tx);
       const uint32_t r0 = (uint32_t)old, r1 = (uint32_t)(old >> 32);
-      if (r0 < (uint32_t)kBucket) bucket[(size_t)t0 * kBucket + r0] = key;
-      if (pair && r1 < (uint32_t)kBucket) bucket[(size_t)(t0 + 1) * kBucket + r1] = key;
+      if (on && r0 < (uint32_t)kBucket) bucket[(size_t)t0 * kBucket + r0] = key;
+      if (on && pair && r1 < (uint32_t)kBucket) bucket[(size_t)(t0 + 1) * kBucket + r1] = key;
+      spill(on && r0 >= (uint32_t)kBucket, t0, r0);
+      spill(on && pair && r1 >= (uint32_t)kBucket, t0 + 1, r1);
     };
     unsigned long long old4[4] = {0ull, 0ull, 0ull, 0ull};
     int tx4[4] = {0, 0, 0, 0}, ty4[4] = {0, 0, 0, 0};
@@ -525,18 +543,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         if (u > v && vstart[u] == f + 1) { vbase_t[u] = ex_t + cnt; vbase_v[u] = ex_v + vis; }
     }
     __syncthreads();
-    if (o.visible) {
+    // (consume() votes across the wave: every lane walks the longest rectangle of its wave, idle lanes with on = false)
+    {
+      const int wave_nops = __builtin_amdgcn_readfirstlane((int)wave_max_i32(nops));
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
-        if (jj < nops) consume(old4[jj], tx4[jj], ty4[jj], pr4[jj]);
-      for (int k0 = 4; k0 < nops; k0 += 4) {
+        if (jj < wave_nops) consume(old4[jj], tx4[jj], ty4[jj], pr4[jj], jj < nops);
+      for (int k0 = 4; k0 < wave_nops; k0 += 4) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
           if (k0 + jj < nops) old4[jj] = issue(k0 + jj, tx4[jj], ty4[jj], pr4[jj]);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-          if (k0 + jj < nops) consume(old4[jj], tx4[jj], ty4[jj], pr4[jj]);
+          if (k0 + jj < wave_nops) consume(old4[jj], tx4[jj], ty4[jj], pr4[jj], k0 + jj < nops);
       }
+    }
+    if (o.visible) {
       const uint32_t k = ex_v - vbase_v[v];
       // touched, in-segment prefix (abs_offset() adds the segment base), list slot (relative; scatter_kernel makes it
       // absolute), SH clamp bits
