@@ -508,15 +508,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     // a pair whose tile's bucket is full joins the view's overflow list (K3 files it once the tile starts are known); the
     // lanes of a wave that overflow in the same step share ONE atomic on the list cursor
     auto spill = [&](bool want, uint32_t tile, uint32_t rank) {
-      const unsigned long long m = __ballot(want);
-      if (m == 0ull) return;
-      const int leader = __ffsll((long long)m) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&hdr->ovf_cursor, (uint32_t)__popcll(m));
-      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-      if (want) {
-        const uint64_t pos = (uint64_t)base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if ((int64_t)pos < L.cap) ovf[pos] = OvfEntry{tile, rank, key};
+      unsigned long long m = __ballot(want);
+      while (m != 0ull) {           // (the lanes of a wave may belong to different views: one atomic per view present)
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+        const int lv = __builtin_amdgcn_readlane(v, leader);
+        const unsigned long long same = __ballot(want && v == lv);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&hdr->ovf_cursor, (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (want && v == lv) {
+          const uint64_t pos = (uint64_t)base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+          if ((int64_t)pos < L.cap) ovf[pos] = OvfEntry{tile, rank, key};
+        }
+        m &= ~same;
       }
     };
     auto consume = [&](unsigned long long old, int tx, int ty, bool pair, bool on) {
