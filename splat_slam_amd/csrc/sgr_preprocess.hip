@@ -275,6 +275,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint32_t vbase_t[kMaxViews + 1], vbase_v[kMaxViews + 1];
   __shared__ uint32_t red[4];
   __shared__ uint32_t vis_bits[kSeg];            // per Gaussian of the segment: bit v = view v of the batch sees it
+  __shared__ uint32_t op_ex[kSeg];               // load-balanced counting atomics: per owner thread, prefix of its remaining operations,
+  __shared__ uint4 op_rect[kSeg];                // ... its rectangle (x0 | y0 << 16, x1 | opr << 16, lead | view << 8, Gaussian)
+  __shared__ uint32_t op_depth[kSeg];            // ... and the depth half of its key
   __shared__ float seg_box[4][8];                // per wave: min xyz, max xyz, max trS of its 64 Gaussians
   __shared__ uint32_t seg_views;                 // bit v = some Gaussian of this segment MAY be visible in view v
   const int N = L.N;
@@ -484,59 +487,59 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       rec[2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     }
     // Count the pairs per tile; the returning atomic is the pair's rank in its tile: while the tile's bucket has room the
-    // key is binned right here.  The kernel's time follows the NUMBER of atomics, so a splat that covers the two tiles of
+    // key is binned right here, beyond that the pair joins the view's overflow list (K3 files it at start(tile) + rank once
+    // the tile starts are known).  The kernel's time follows the NUMBER of atomics, so a splat that covers the two tiles of
     // a counter word (x even, x+1) takes both ranks with ONE 64-bit atomic; a row of the rectangle is a leading single
-    // tile (odd x0), pairs, and a trailing single tile.  The first 4 operations (most splats need <= 4) are issued now
-    // and consumed after the block scans below, which hide their round trip.
-    uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
-    uint64_t* bucket = (uint64_t*)(p_scratch[v] + L.o_bucket);
+    // tile (odd x0), pairs, and a trailing single tile.  The first 4 operations of every splat (most splats of a fresh map
+    // need <= 4) are issued now and consumed after the block scans below, which hide their round trip; the remaining ones
+    // -- a converged map has splats that cover tens to hundreds of tiles -- are dealt out evenly over the block.
     const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
     const int lead = o.x0 & 1, wrect = o.x1 - o.x0;
     const int opr = lead + ((wrect - lead + 1) >> 1);                  // operations per row
     const int nops = cnt > 0u ? opr * (o.y1 - o.y0) : 0;
-    auto issue = [&](int k, int& tx, int& ty, bool& pair) -> unsigned long long {
-      const int row = k / opr, j = k % opr;
-      ty = o.y0 + row;
-      tx = (lead && j == 0) ? o.x0 : o.x0 + lead + 2 * (j - lead);
-      pair = !(tx & 1) && (tx + 1 < o.x1);
-      uint32_t* c = &tile_count[tile_counter_index(tx, ty, L.gxp)];
+    // operation k of the rectangle (x0, y0, x1, lead, opr) of a splat of view `view`: tile(s) + the counting atomic
+    auto issue = [&](int view, int x0, int y0, int x1, int ld, int per_row, int k, int& tx, int& ty, bool& pair) -> unsigned long long {
+      const int row = k / per_row, j = k % per_row;
+      ty = y0 + row;
+      tx = (ld && j == 0) ? x0 : x0 + ld + 2 * (j - ld);
+      pair = !(tx & 1) && (tx + 1 < x1);
+      uint32_t* c = (uint32_t*)(p_saved[view] + L.o_tile_count) + tile_counter_index(tx, ty, L.gxp);
       if (pair) return atomicAdd((unsigned long long*)c, 0x100000001ull);
       return (unsigned long long)atomicAdd(c, 1u);
     };
-    SavedHeader* hdr = (SavedHeader*)(saved + L.o_hdr);
-    OvfEntry* ovf = (OvfEntry*)(p_scratch[v] + L.o_ovf);
-    // a pair whose tile's bucket is full joins the view's overflow list (K3 files it once the tile starts are known); the
-    // lanes of a wave that overflow in the same step share ONE atomic on the list cursor
-    auto spill = [&](bool want, uint32_t tile, uint32_t rank) {
+    // a pair whose tile's bucket is full joins its view's overflow list; the lanes of a wave that overflow in the same step
+    // share ONE atomic on the list cursor per view present in the wave.  Called by the whole wave (`want` selects lanes).
+    auto spill = [&](bool want, int view, uint32_t tile, uint32_t rank, uint64_t kk) {
       unsigned long long m = __ballot(want);
-      while (m != 0ull) {           // (the lanes of a wave may belong to different views: one atomic per view present)
+      while (m != 0ull) {
         const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-        const int lv = __builtin_amdgcn_readlane(v, leader);
-        const unsigned long long same = __ballot(want && v == lv);
+        const int lv = __builtin_amdgcn_readlane(view, leader);
+        const unsigned long long same = __ballot(want && view == lv);
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&hdr->ovf_cursor, (uint32_t)__popcll(same));
+        if (lane == leader) base = atomicAdd(&((SavedHeader*)(p_saved[lv] + L.o_hdr))->ovf_cursor, (uint32_t)__popcll(same));
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if (want && v == lv) {
+        if (want && view == lv) {
           const uint64_t pos = (uint64_t)base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-          if ((int64_t)pos < L.cap) ovf[pos] = OvfEntry{tile, rank, key};
+          if ((int64_t)pos < L.cap) ((OvfEntry*)(p_scratch[lv] + L.o_ovf))[pos] = OvfEntry{tile, rank, kk};
         }
         m &= ~same;
       }
     };
-    auto consume = [&](unsigned long long old, int tx, int ty, bool pair, bool on) {
+    auto consume = [&](bool on, int view, unsigned long long old, int tx, int ty, bool pair, uint64_t kk) {
       const uint32_t t0 = (uint32_t)(ty * L.gx + tx);
       const uint32_t r0 = (uint32_t)old, r1 = (uint32_t)(old >> 32);
-      if (on && r0 < (uint32_t)kBucket) bucket[(size_t)t0 * kBucket + r0] = key;
-      if (on && pair && r1 < (uint32_t)kBucket) bucket[(size_t)(t0 + 1) * kBucket + r1] = key;
-      spill(on && r0 >= (uint32_t)kBucket, t0, r0);
-      spill(on && pair && r1 >= (uint32_t)kBucket, t0 + 1, r1);
+      uint64_t* bucket = (uint64_t*)(p_scratch[view] + L.o_bucket);
+      if (on && r0 < (uint32_t)kBucket) bucket[(size_t)t0 * kBucket + r0] = kk;
+      if (on && pair && r1 < (uint32_t)kBucket) bucket[(size_t)(t0 + 1) * kBucket + r1] = kk;
+      spill(on && r0 >= (uint32_t)kBucket, view, t0, r0, kk);
+      spill(on && pair && r1 >= (uint32_t)kBucket, view, t0 + 1, r1, kk);
     };
     unsigned long long old4[4] = {0ull, 0ull, 0ull, 0ull};
     int tx4[4] = {0, 0, 0, 0}, ty4[4] = {0, 0, 0, 0};
     bool pr4[4] = {false, false, false, false};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (jj < nops) old4[jj] = issue(jj, tx4[jj], ty4[jj], pr4[jj]);
+      if (jj < nops) old4[jj] = issue(v, o.x0, o.y0, o.x1, lead, opr, jj, tx4[jj], ty4[jj], pr4[jj]);
     uint32_t tot_t, tot_v;
     const uint32_t ex_t = carry_t + block256_exclusive_scan(cnt, red, tot_t);
     const uint32_t ex_v = carry_v + block256_exclusive_scan(vis, red, tot_v);
@@ -547,20 +550,42 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         if (u > v && vstart[u] == f + 1) { vbase_t[u] = ex_t + cnt; vbase_v[u] = ex_v + vis; }
     }
     __syncthreads();
-    // (consume() votes across the wave: every lane walks the longest rectangle of its wave, idle lanes with on = false)
-    {
-      const int wave_nops = __builtin_amdgcn_readfirstlane((int)wave_max_i32(nops));
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-        if (jj < wave_nops) consume(old4[jj], tx4[jj], ty4[jj], pr4[jj], jj < nops);
-      for (int k0 = 4; k0 < wave_nops; k0 += 4) {
+    for (int jj = 0; jj < 4; ++jj) consume(jj < nops, v, old4[jj], tx4[jj], ty4[jj], pr4[jj], key);
+    // operations beyond the first four, dealt out evenly: item -> (owner thread, k) by a search in the owners' prefix sums
+    const int rem = nops > 4 ? nops - 4 : 0;
+    if (__syncthreads_or(rem > 0)) {
+      uint32_t tot_r;
+      const uint32_t ex_r = block256_exclusive_scan((uint32_t)rem, red, tot_r);
+      op_ex[tid] = ex_r;
+      op_rect[tid] = make_uint4((uint32_t)o.x0 | ((uint32_t)o.y0 << 16), (uint32_t)o.x1 | ((uint32_t)opr << 16),
+                                (uint32_t)lead | ((uint32_t)v << 8), (uint32_t)i);
+      op_depth[tid] = __float_as_uint(o.depth);
+      __syncthreads();
+#pragma unroll 1
+      for (uint32_t it0 = 0; it0 < tot_r; it0 += 4 * 256) {
+        int view4[4] = {0, 0, 0, 0};
+        uint64_t key4[4] = {0ull, 0ull, 0ull, 0ull};
+        bool on4[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          if (k0 + jj < nops) old4[jj] = issue(k0 + jj, tx4[jj], ty4[jj], pr4[jj]);
+        for (int jj = 0; jj < 4; ++jj) {
+          const uint32_t item = it0 + (uint32_t)jj * 256u + (uint32_t)tid;
+          on4[jj] = item < tot_r;
+          if (on4[jj]) {
+            int lo = 0, hi = 256;                    // owner = last thread whose prefix is <= item
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (op_ex[mid] <= item) lo = mid + 1; else hi = mid; }
+            const int owner = lo - 1;
+            const uint4 r = op_rect[owner];
+            view4[jj] = (int)(r.z >> 8);
+            key4[jj] = ((uint64_t)op_depth[owner] << 32) | r.w;
+            old4[jj] = issue(view4[jj], (int)(r.x & 0xffffu), (int)(r.x >> 16), (int)(r.y & 0xffffu), (int)(r.z & 0xffu),
+                             (int)(r.y >> 16), 4 + (int)(item - op_ex[owner]), tx4[jj], ty4[jj], pr4[jj]);
+          }
+        }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          if (k0 + jj < wave_nops) consume(old4[jj], tx4[jj], ty4[jj], pr4[jj], k0 + jj < nops);
+        for (int jj = 0; jj < 4; ++jj) consume(on4[jj], view4[jj], old4[jj], tx4[jj], ty4[jj], pr4[jj], key4[jj]);
       }
+      __syncthreads();                               // (the next chunk rewrites the owner tables)
     }
     if (o.visible) {
       const uint32_t k = ex_v - vbase_v[v];
@@ -597,10 +622,10 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
     const float* __restrict__ projmatrix, const float* __restrict__ projraw, const float* __restrict__ campos,
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-    uint32_t slot0, uint32_t touched_cnt, unsigned clamped_bits,
-    const float4* __restrict__ partials, int64_t cap, float* __restrict__ dshs, int sh_accumulate, GaussGrad& acc,
-    float tau[6], int upstream_pose_jac) {
-  float g_m2[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_rgb[3] = {0.f, 0.f, 0.f}, g_dep = 0.f;
+    const float gsum[10] /* the Gaussian's per-tile partials, summed */, unsigned clamped_bits,
+    float* __restrict__ dshs, int sh_accumulate, GaussGrad& acc, float tau[6], int upstream_pose_jac) {
+  float g_m2[2] = {gsum[0], gsum[1]}, g_con[3] = {gsum[2], gsum[3], gsum[4]}, g_op = gsum[5], g_rgb[3] = {gsum[6], gsum[7], gsum[8]},
+        g_dep = gsum[9];
   float g_p[3] = {0.f, 0.f, 0.f};
   float g_S6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float g_s[3] = {0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -608,17 +633,6 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
   const int accumulate = sh_accumulate;
   float* dcolors = nullptr;   // precomputed-colour gradient is returned through acc.rgb_or_sh0
   {
-    // fixed-order gather of this Gaussian's per-tile partials: deterministic, no atomics
-    uint32_t off = slot0, cnt = touched_cnt;
-    for (uint32_t k = 0; k < cnt; ++k) {
-      uint64_t e = (uint64_t)off + k;
-      if ((int64_t)e >= cap) break;
-      float4 p0 = partials[e * 3 + 0], p1 = partials[e * 3 + 1], p2 = partials[e * 3 + 2];
-      g_m2[0] += p0.x; g_m2[1] += p0.y; g_con[0] += p0.z; g_con[1] += p0.w;
-      g_con[2] += p1.x; g_op += p1.y; g_rgb[0] += p1.z; g_rgb[1] += p1.w;
-      g_rgb[2] += p2.x; g_dep += p2.y;
-    }
-
     float vm[16], pm[16], pr[16];
     load16(viewmatrix, vm);
     load16(projmatrix, pm);
@@ -831,10 +845,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   const int V = (int)((const SavedHeader*)(saved + L.o_hdr))->num_visible;
   if ((int)(blockIdx.x * blockDim.x) >= V) return;             // whole block beyond the list (uniform)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= V) return;
+  const bool have = t < V;
+  const int i = have ? (int)((const uint32_t*)(saved + L.o_vis_list))[t] : 0;
+  uint4 q3 = make_uint4(0u, 0u, 0u, 0u);
+  if (have) q3 = ((const uint4*)(grec_of(saved, L) + i))[3];
+  // Sum of this Gaussian's per-tile partials (48 B per covered tile, one contiguous run per Gaussian).  A converged map has
+  // splats that cover tens to hundreds of tiles: a lane walking its own run alone makes the wave wait for its longest run
+  // and fetches 48 scattered bytes per lane and step.  Instead every group of 8 lanes sums ONE run together (lane l takes
+  // slots l, l + 8, ...: 384 contiguous bytes per step), eight rounds cover the wave's 64 Gaussians; fixed order, no atomics.
+  float gsum[10];
+  {
+    const float4* __restrict__ partials = (const float4*)(tab.scratch[v] + L.o_partials);
+    const int lane = threadIdx.x & 63, grp = lane >> 3, sub = lane & 7;
+    const uint32_t my_off = have ? abs_offset(saved, L, (uint32_t)i, q3.y) : 0u, my_cnt = have ? q3.x : 0u;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) gsum[j] = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      const int src = r * 8 + grp;                    // the lane whose Gaussian this group sums in round r
+      const uint32_t o = (uint32_t)__shfl((int)my_off, src), c = (uint32_t)__shfl((int)my_cnt, src);
+      float part[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) part[j] = 0.f;
+      for (uint32_t k = (uint32_t)sub; k < c; k += 8u) {
+        const uint64_t e = (uint64_t)o + k;
+        if ((int64_t)e >= L.cap) break;
+        const float4 p0 = partials[e * 3 + 0], p1 = partials[e * 3 + 1], p2 = partials[e * 3 + 2];
+        part[0] += p0.x; part[1] += p0.y; part[2] += p0.z; part[3] += p0.w; part[4] += p1.x;
+        part[5] += p1.y; part[6] += p1.z; part[7] += p1.w; part[8] += p2.x; part[9] += p2.y;
+      }
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) part[j] += __shfl_xor(part[j], off);
+      // every lane of group g now holds the sum of lane (r * 8 + g)'s Gaussian: lane L of row r fetches its own from group L & 7
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const float got = __shfl(part[j], sub * 8);
+        if (grp == r) gsum[j] = got;
+      }
+    }
+  }
+  if (!have) return;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int i = (int)((const uint32_t*)(saved + L.o_vis_list))[t];
-  const uint4 q3 = ((const uint4*)(grec_of(saved, L) + i))[3];
   GaussGrad acc;
 #pragma unroll
   for (int j = 0; j < 3; ++j) { acc.p[j] = 0.f; acc.s[j] = 0.f; acc.rgb_or_sh0[j] = 0.f; }
@@ -845,9 +898,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   acc.op = 0.f; acc.m2[0] = 0.f; acc.m2[1] = 0.f;
   preprocess_bwd_one_view(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, tab.viewmatrix[v], tab.projmatrix[v],
                           cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                          abs_offset(saved, L, (uint32_t)i, q3.y), q3.x, q3.w,
-                          (const float4*)(tab.scratch[v] + L.o_partials), L.cap,
-                          dshs, accumulate, acc, tau, cm.upstream_pose_jac);
+                          gsum, q3.w, dshs, accumulate, acc, tau, cm.upstream_pose_jac);
   // the record sits at the GAUSSIAN's index (one full 64-byte sector): the gather pass then needs no list-slot lookup
   float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)i * 4;
   rec[0] = make_float4(acc.p[0], acc.p[1], acc.p[2], acc.rgb_or_sh0[0]);
