@@ -24,7 +24,7 @@ void launch_blend_fused(const ViewTab&, int, const LOff&, const float*, const Lo
 bool blend_can_fuse(const LOff&);
 
 // run-time options (sgr_set_option)
-static int g_opt[SGR_OPT_COUNT] = {1, 0, 1};
+static int g_opt[SGR_OPT_COUNT] = {1, 0, 0};
 
 static thread_local char g_err[512] = "";
 int set_error(int code, const char* fmt, ...) {

@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
   }
   if (tid <= kMaxViews) { vbase_t[tid] = 0u; vbase_v[tid] = 0u; }
+  if (tid == 0) seg_views = 0xffffffffu;         // (every view, unless the whole-segment test below says otherwise)
   vis_bits[tid] = 0u;
   __syncthreads();
 
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     // depth, projected centre, radius bound): if even those intervals miss the image the per-Gaussian tests of that view are
     // skipped.  Conservative by construction (every bound is widened, 0.1 % + 1 px); a randomly ordered map just pays
     // the ~100 instructions of the reduction.
-    {
+    if (!(L.dbg & 4)) {
       const bool in = ia < N && isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]) && isfinite(trS);
       const bool bad = ia < N && !in;                       // non-finite input: let the exact path deal with it
       float lo[3], hi[3], ts = in ? trS : 0.f;
@@ -345,6 +346,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         seg_box[wv][3] = hi[0]; seg_box[wv][4] = hi[1]; seg_box[wv][5] = hi[2];
         seg_box[wv][6] = ts; seg_box[wv][7] = anybad ? 1.f : 0.f;
       }
+      __syncthreads();
       if (tid == 0) seg_views = 0u;
       __syncthreads();
       if (tid < nviews) {
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
           tsm = fmaxf(tsm, seg_box[w][6]); anyb = fmaxf(anyb, seg_box[w][7]);
         }
         bool maybe = true;
-        if (anyb == 0.f && b0[0] <= b1[0] && !(L.dbg & 4)) {
+        if (anyb == 0.f && b0[0] <= b1[0]) {
           const float* vm = mats[tid];
           // view-space box of the 8 corners (W2C[r][c] = vm[c*4+r])
           float v0[3], v1[3];
@@ -860,6 +862,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const uint32_t my_off = have ? abs_offset(saved, L, (uint32_t)i, q3.y) : 0u, my_cnt = have ? q3.x : 0u;
 #pragma unroll
     for (int j = 0; j < 10; ++j) gsum[j] = 0.f;
+    const int longest = __builtin_amdgcn_readfirstlane(wave_max_i32((int)my_cnt));
+    if (longest <= 6) {              // a fresh map (splats of a few tiles): every lane sums its own short run
+      for (uint32_t k = 0; k < my_cnt; ++k) {
+        const uint64_t e = (uint64_t)my_off + k;
+        if ((int64_t)e >= L.cap) break;
+        const float4 p0 = partials[e * 3 + 0], p1 = partials[e * 3 + 1], p2 = partials[e * 3 + 2];
+        gsum[0] += p0.x; gsum[1] += p0.y; gsum[2] += p0.z; gsum[3] += p0.w; gsum[4] += p1.x;
+        gsum[5] += p1.y; gsum[6] += p1.z; gsum[7] += p1.w; gsum[8] += p2.x; gsum[9] += p2.y;
+      }
+    } else
 #pragma unroll 1
     for (int r = 0; r < 8; ++r) {
       const int src = r * 8 + grp;                    // the lane whose Gaussian this group sums in round r
