@@ -285,7 +285,7 @@ def build_tile_lists(pp: Preprocessed, H: int, W: int, depth_sort_key=None):
 
 KNIFE_BAND = 5e-4          # relative half-width of "fp32 rounding may decide this cut-off" for alpha (see knife_edge_gaussians)
 KNIFE_PIXEL_ERR = 4e-4     # ... or, if larger, what this much error (in pixels) of the projected centre does to alpha
-KNIFE_CONIC_EPS = 1e-6     # ... or what ~8 fp32 ulps, amplified by the conic's condition number, do to the exponent
+KNIFE_CONIC_EPS = 1e-6     # ... or what ~8 fp32 ulps of the quadratic form's TERMS do to the exponent
 KNIFE_BAND_T = 1e-4        # ... and for the transmittance thresholds (products of a few (1 - alpha): far better conditioned)
 
 
@@ -347,11 +347,13 @@ def blend(pp: Preprocessed, tile_ids, gauss_ids, s: OracleSettings, dt, knife=No
             dpx = (con[:, 0] * dx + con[:, 1] * dy).detach()
             dpy = (con[:, 1] * dx + con[:, 2] * dy).detach()
             band = torch.clamp_min(torch.sqrt(dpx * dpx + dpy * dpy) * KNIFE_PIXEL_ERR, KNIFE_BAND)
-            # ... and an elongated splat's conic is ill-conditioned in fp32: det = a c - b^2 cancels, relative error ~ eps * kappa
-            # with kappa = a c / det = A C / (A C - B^2), which the exponent multiplies by |power|
-            kappa = (con[:, 0] * con[:, 2] / (con[:, 0] * con[:, 2] - con[:, 1] * con[:, 1]).clamp_min(1e-30)).detach()
-            band = torch.maximum(band, power.detach().abs() * kappa[None, :] * KNIFE_CONIC_EPS)
+            # ... and the quadratic form of a long thin splat cancels: its three terms can be 1e4 while their sum is ~0, so fp32
+            # (any fp32 implementation, upstream's included) carries an absolute error of ~8 ulps of the TERMS in `power`
+            pw_err = ((con[:, 0] * dx * dx + con[:, 2] * dy * dy).abs() + 2.0 * (con[:, 1] * dx * dy).abs()).detach() * KNIFE_CONIC_EPS
+            band = torch.maximum(band, pw_err)
             near = (power.detach() <= 0) & ((rawd * 255.0 - 1.0).abs() < band)
+            # the `power > 0 -> skip` rule itself: exact power is never positive, a rounded one within pw_err of 0 may be
+            near |= (power.detach() > -pw_err) & (rawd * 255.0 >= 1.0 - band)
             near |= keep & (T_before.detach() >= T_EPS) & (((Td / T_EPS - 1.0).abs() < KNIFE_BAND_T) | ((Td / N_TOUCHED_T - 1.0).abs() < KNIFE_BAND_T))
             if bool(near.any()):
                 # ... and every splat composited at a pixel that has such a pair: a flip there changes their T / "colour
