@@ -254,6 +254,7 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
     stat_denom = torch.zeros(n, dtype=torch.float64)
     stat_maxr = torch.zeros(n, dtype=torch.float64)
     knife, seen = {}, torch.zeros(n, dtype=torch.bool)
+    flip_px = []
     for k, cam in enumerate(cams):
         vb = f._views[cam.uid]
         s = _oracle_settings(cam, intr)
@@ -282,6 +283,7 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
         sg_ref = torch.sign(r_all)
         firm = r_all.abs() >= KNIFE
         n_flip = int((sg_hip[firm] != sg_ref[firm]).sum())
+        flip_px.append(torch.nonzero(firm & (sg_hip != sg_ref)).tolist())
         soft.check(n_flip <= 4 + r_all.numel() // 200000, f"view {k}: {n_flip} loss-gradient signs differ away from the knife edge "
                    f"(largest |residual| among them {float(r_all[firm & (sg_hip != sg_ref)].abs().max()) if n_flip else 0.0:.2e})")
         soft.check(int((~firm & (r_all != 0)).sum()) < 0.002 * r_all.numel(), f"view {k}: {int((~firm & (r_all != 0)).sum())} knife-edge residuals")
@@ -319,6 +321,14 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
         worst = int(e.argmax())
         soft.check(strict <= REL, f"accumulated grad {mine}: rel err {strict:.3e} (Gaussians off the knife edges; worst: Gaussian {worst}, "
                                   f"hip {a[worst].tolist()} vs oracle {b[worst].tolist()})")
+        if strict > REL and mine == "xyz":          # what does that Gaussian look like in every view?
+            for k, cam in enumerate(cams):
+                pp = O.preprocess(inp["means3D"], None, inp["opacities"], inp["shs"], None, inp["scales"], inp["rotations"], None, None,
+                                  None, _oracle_settings(cam, intr))
+                soft.check(True, f"  view {k}: Gaussian {worst} radius {int(pp.radii[worst])} xy {pp.xy[worst].tolist()} depth {float(pp.depth[worst]):.5f} "
+                                 f"conic {pp.conic[worst].tolist()} opacity {float(pp.opacity[worst]):.6f} rect {pp.rect[worst].tolist()} hip radius "
+                                 f"{int(f._views[cam.uid].radii[worst])}; sign-flip pixels (c, y, x) of this view: {flip_px[k]}")
+            soft.check(True, f"  scales {inp['scales'][worst].tolist()} rot {inp['rotations'][worst].tolist()} xyz {inp['means3D'][worst].tolist()}")
         soft.check(loose <= 2e-2 and n_loose <= max(3, nvis // 100), f"accumulated grad {mine}: {n_loose} knife-edge Gaussians beyond {REL}, worst {loose:.3e}")
         top = torch.topk(e, 20).indices
         dbg[mine + "_idx"], dbg[mine + "_hip"], dbg[mine + "_ref"] = top.numpy(), a[top].numpy(), b[top].numpy()
