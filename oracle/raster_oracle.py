@@ -379,6 +379,8 @@ def rasterize(means3D, means2D, opacities, shs=None, colors_precomp=None, scales
                     cov3D_precomp, theta, rho, settings)
     tile_ids, gauss_ids = build_tile_lists(pp, int(settings.image_height), int(settings.image_width), depth_sort_key)
     color, depth, opac, n_touched = blend(pp, tile_ids, gauss_ids, settings, dt, knife=knife)   # knife: see knife_edge_gaussians
+    if knife is not None:
+        knife.setdefault("gaussians", []).append(_geometric_knife_edges(pp, int(settings.image_height), int(settings.image_width)))
     return color, pp.radii, depth, opac, n_touched
 
 
@@ -397,7 +399,35 @@ def knife_edge_gaussians(means3D, opacities, shs=None, colors_precomp=None, scal
     knife = {}
     blend(pp, tile_ids, gauss_ids, settings, means3D.dtype, knife=knife)
     found = knife.get("gaussians", [])
-    return torch.unique(torch.cat(found)) if found else torch.zeros(0, dtype=torch.int64)
+    found.append(_geometric_knife_edges(pp, int(settings.image_height), int(settings.image_width)))
+    return torch.unique(torch.cat(found))
+
+
+KNIFE_RADIUS_REL = 2e-4    # 3 sqrt(lambda_max) this close (relative) to an integer: ceil() may round the other way in fp32
+
+
+def _geometric_knife_edges(pp, H, W):
+    """The two integer decisions of preprocessCUDA (forward.cu:240-260 as restated in preprocess above) that fp32 rounding of the
+    projected centre can flip: the 16-pixel tile rectangle trunc((xy -+ r [+ 15]) / 16) when xy -+ r is within KNIFE_PIXEL_ERR
+    of a multiple of 16 (measured: centre x = 507.99997 in fp64, 508.0000x in fp32 -> one more column of tiles, whose pixels
+    at dx = 4 still carry alpha = 0.011 -> 12 % of that Gaussian's gradient), and the radius ceil(3 sqrt(lambda_max))."""
+    vis = pp.visible
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    r = pp.radii.to(pp.xy.dtype)
+    hit = torch.zeros_like(vis)
+    for axis, g in ((0, gx), (1, gy)):
+        for u in ((pp.xy[:, axis] - r) / TILE, (pp.xy[:, axis] + r + TILE - 1) / TILE):
+            u = u.detach()
+            hit |= ((u - torch.round(u)).abs() < KNIFE_PIXEL_ERR / TILE) & (u > -0.5) & (u < g + 0.5)
+    con = pp.conic.detach()
+    detc = con[:, 0] * con[:, 2] - con[:, 1] * con[:, 1]
+    detc = torch.where(detc != 0, detc, torch.ones_like(detc))
+    a, c_ = con[:, 2] / detc, con[:, 0] / detc
+    mid = 0.5 * (a + c_)
+    lam = mid + torch.clamp_min(mid * mid - 1.0 / detc, 0.1).sqrt()
+    ext = 3.0 * lam.clamp_min(0).sqrt()
+    hit |= (ext - torch.round(ext)).abs() < KNIFE_RADIUS_REL * ext
+    return torch.nonzero(hit & vis).flatten()
 
 
 # ----------------------------------------------------------------------------------------------

@@ -367,4 +367,4 @@ def test_batched_mapping_path_matches_oracle_very_long_lists():
     # the whole 300 k map seen through a 96x64 camera with enlarged, uniformly faint splats (opacity 0.03): hundreds of pairs
     # per 8x8 tile and nothing terminates early, so the walked lists run past 256 entries (1024- / 4096-key LDS sort builds,
     # multi-chunk backward with carries)
-    _run_batched_case(300000, "tiny", 4, scale_add=2.2, opacity_const=0.02, min_long_tiles=40, min_huge_tiles=10, by_l2=True)
+    _run_batched_case(300000, "tiny", 4, scale_add=3.2, opacity_const=0.02, min_long_tiles=40, min_huge_tiles=10, by_l2=True)
