@@ -427,7 +427,16 @@ def _geometric_knife_edges(pp, H, W):
     lam = mid + torch.clamp_min(mid * mid - 1.0 / detc, 0.1).sqrt()
     ext = 3.0 * lam.clamp_min(0).sqrt()
     hit |= (ext - torch.round(ext)).abs() < KNIFE_RADIUS_REL * ext
-    return torch.nonzero(hit & vis).flatten()
+    hit &= vis
+    # ... and whoever shares pixels with such a splat: its flip puts alpha up to ~0.01 in front of (or takes it away from)
+    # them at the pixels of the gained / lost tile row or column (measured: the neighbour 4 px away moved by 3e-4)
+    out = hit.clone()
+    vi = torch.nonzero(vis).flatten()
+    vx, vy, vr = pp.xy[vi, 0].detach(), pp.xy[vi, 1].detach(), r[vi]
+    for h in torch.nonzero(hit).flatten().tolist():
+        reach = vr + r[h] + 1.0
+        out[vi[((vx - pp.xy[h, 0].detach()).abs() <= reach) & ((vy - pp.xy[h, 1].detach()).abs() <= reach)]] = True
+    return torch.nonzero(out).flatten()
 
 
 # ----------------------------------------------------------------------------------------------

@@ -98,7 +98,8 @@ def _oracle_settings(cam, intr, dtype=torch.float64):
 
 def _check_radii(soft, hip, ref, what):
     d = (hip.long() - ref.long()).abs()
-    soft.check(int((d > 0).sum()) <= 3 and int(d.max()) <= 1,
+    big = d > 1          # ceil(3 sqrt(lambda)) of a splat a few mm from the camera plane: radius ~1e4 px, fp32 resolves it to ~1e-3 relative
+    soft.check(int((d > 0).sum()) <= 3 and bool((d[big].double() <= 2e-3 * ref[big].double()).all()),
                f"{what}: radii differ at {int((d > 0).sum())} of {int((ref > 0).sum())} visible Gaussians (max {int(d.max())})")
 
 
@@ -286,7 +287,7 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
         flip_px.append(torch.nonzero(firm & (sg_hip != sg_ref)).tolist())
         soft.check(n_flip <= 4 + r_all.numel() // 200000, f"view {k}: {n_flip} loss-gradient signs differ away from the knife edge "
                    f"(largest |residual| among them {float(r_all[firm & (sg_hip != sg_ref)].abs().max()) if n_flip else 0.0:.2e})")
-        soft.check(int((~firm & (r_all != 0)).sum()) < 0.002 * r_all.numel(), f"view {k}: {int((~firm & (r_all != 0)).sum())} knife-edge residuals")
+        soft.check(int((~firm & (r_all != 0)).sum()) < max(100, 0.002 * r_all.numel()), f"view {k}: {int((~firm & (r_all != 0)).sum())} knife-edge residuals")
         sg = torch.where(firm & (sg_hip == sg_ref), sg_ref, sg_hip)
         surrogate = (alpha * (sg[:3] * r_rgb).sum() / (3 * H * W) + (1 - alpha) * (sg[3:] * r_dep).sum() / (H * W))
         surrogate.backward()                                      # gradient of the L1 loss with those signs; accumulates over views
@@ -345,7 +346,7 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
         strict, loose, n_loose = _strict_rel(a, b, on_edge, 1)
         soft.check(strict <= REL and loose <= 2e-2, f"densification statistic: rel err {strict:.3e} / knife-edge {loose:.3e}")
     soft.check(int((gm.denom.cpu().reshape(-1).double() != stat_denom).sum()) <= 3, "denom differs")
-    soft.check(float((gm.max_radii2D.cpu().double() - stat_maxr).abs().max()) <= 1, "max_radii2D differs")
+    soft.check(bool(((gm.max_radii2D.cpu().double() - stat_maxr).abs() <= torch.clamp_min(2e-3 * stat_maxr, 1.0)).all()), "max_radii2D differs")
     soft.done()
     return list(hist)
 
