@@ -250,7 +250,7 @@ class Bench:
             try:
                 res[name] = round(self.profiled(loop, 20, 1 << 0, fused_blend=True)[0][0], 5)
             finally:
-                self.lib.sgr_set_option(self.nat.SGR_OPT_SEGMENT_TEST, 1)
+                self.lib.sgr_set_option(self.nat.SGR_OPT_SEGMENT_TEST, 0)
         return res
 
     def scene_leg(self, scale_add, steps=40):

@@ -333,7 +333,8 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
     const int v = blockIdx.x;
     loss_final_view((const LossPart*)fa.tail_parts[v], fa.tail_nparts, fa.tail_inv_rgb, fa.tail_inv_dep, fa.tail_alpha,
                     fa.tail_loss[v], fa.tail_da[v], fa.tail_db[v], red);
-    if (threadIdx.x == 0 && fa.exp_rows > 0 && fa.tail_da[v]) {
+    // (a view whose forward ran out of pair capacity rendered truncated lists: it takes no part in this step, see below)
+    if (threadIdx.x == 0 && fa.exp_rows > 0 && fa.tail_da[v] && ((const SavedHeader*)tab.saved[v])->overflow == 0u) {
       const ptrdiff_t d = fa.tail_da[v] - fa.exp_grad;
       if (d >= 0 && d < (ptrdiff_t)fa.exp_rows * fa.exp_width && d % fa.exp_width == 0) {
         const int r = (int)(d / fa.exp_width);
@@ -347,10 +348,20 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
   // per-view pointers into LDS: the gather below indexes them per LANE (a by-value kernarg table cannot be)
   __shared__ const char* s_scratch[kMaxViews];
   __shared__ const int32_t* s_radii[kMaxViews];
+  __shared__ uint32_t s_over[kMaxViews];
 #pragma unroll
   for (int u = 0; u < kMaxViews; ++u)
-    if ((int)threadIdx.x == u && u < nviews) { s_scratch[u] = tab.scratch[u]; s_radii[u] = tab.radii[u]; }
+    if ((int)threadIdx.x == u && u < nviews) {
+      s_scratch[u] = tab.scratch[u];
+      s_radii[u] = tab.radii[u];
+      s_over[u] = ((const SavedHeader*)tab.saved[u])->overflow;
+    }
   __syncthreads();
+  // Capacity overflow (R > cap): the view's lists were truncated and some of its partial slots were never written.  Such a
+  // view contributes NOTHING to this step -- no gradient, no densification statistics, no exposure update -- instead of
+  // feeding uninitialised sums into the Adam moments; the host sees header.overflow at its next check and grows the capacity.
+  uint32_t truncated = 0u;
+  for (int u = 0; u < nviews; ++u) truncated |= (s_over[u] != 0u ? 1u : 0u) << u;
   const int i = ((int)blockIdx.x - fa.tail_views) * blockDim.x + threadIdx.x;
   if (i >= L.N) return;
   float a[14];
@@ -360,7 +371,7 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
   // K1 left one word per Gaussian with the views of the batch that see it.  Every lane walks ITS OWN set bits in
   // ascending view order (the fixed summation order of grad_gather_kernel): a wave makes max-over-lanes(popcount) record
   // round trips -- about 3 for a SLAM batch -- instead of one per view of the batch.
-  uint32_t seen = ((const uint32_t*)(tab.saved[0] + L.o_vismask))[i];
+  uint32_t seen = ((const uint32_t*)(tab.saved[0] + L.o_vismask))[i] & ~truncated;
   const bool any = seen != 0u;
   while (seen) {
     const int v = __builtin_ctz(seen);

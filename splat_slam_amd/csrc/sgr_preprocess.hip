@@ -944,7 +944,10 @@ __global__ void __launch_bounds__(256) grad_gather_kernel(
   float m2x = 0.f, m2y = 0.f, st_norm = 0.f, st_cnt = 0.f, st_maxr = 0.f;
   bool any = false;
   for (int v = 0; v < nviews; ++v) {
-    const int r = in_range ? tab.radii[v][i] : 0;
+    // (a view whose forward overflowed the pair capacity has partial slots nobody wrote: it contributes zeros; the caller sees
+    //  header.overflow -- sgr_query / the drop-in's deferred check -- and redoes the work with a larger workspace)
+    const bool truncated = ((const SavedHeader*)tab.saved[v])->overflow != 0u;
+    const int r = in_range && !truncated ? tab.radii[v][i] : 0;
     uint32_t pos = 0;
     if (r > 0) {
       any = true;

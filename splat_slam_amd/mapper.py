@@ -161,9 +161,11 @@ class MappingLoop:
                 radii_acm.append(pkg["radii"])
             scaling = self.gaussians.get_scaling
             isotropic_loss = torch.abs(scaling - scaling.mean(dim=1).view(-1, 1))
-            loss_mapping += 10 * isotropic_loss.mean()
+            # multi-GPU (grad_sync set): the view losses are summed over the ranks, the isotropy term must enter that sum ONCE
+            iso_weight = 10.0 if self.grad_sync is None else 10.0 / self.grad_sync.world
+            loss_mapping += iso_weight * isotropic_loss.mean()
             loss_mapping.backward()
-            if self.grad_sync is not None:          # multi-GPU: sum the per-rank view gradients (parallel.py)
+            if self.grad_sync is not None and not prune:      # (the prune pass never steps: nothing to exchange)
                 self.grad_sync.reduce()
             with torch.no_grad():
                 self.occ_aware_visibility = {}

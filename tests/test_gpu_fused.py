@@ -516,3 +516,46 @@ def test_segment_view_test_is_conservative_bitwise_same_results():
         for k in res[0]:
             assert torch.equal(res[0][k], res[1][k]), (order, k)
         assert int((res[0]["radii"] > 0).sum()) > 1000
+
+
+def test_views_that_overflow_the_pair_capacity_take_no_part_in_the_step():
+    """Capacity overflow between two host checks (the forwards run asynchronously): the truncated views must contribute zeros --
+    not the partial slots nobody wrote -- so parameters and Adam moments stay finite and sane; the next check_overflow()
+    reports the event and grows the workspace, after which iterations are regular again."""
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    intr = syn.INTRINSICS["metric"]
+    params = syn.room_parameters(60000, seed=5, device=DEV)
+    params["scaling"] = params["scaling"] + 2.0
+    cams = syn.make_views(params, 4, intr, DEV, seed=5)
+    f = _loop(FusedMappingLoop, syn, params, cams, [0, 1, 2])
+    f.check_every = 1 << 30                         # no host check in between
+    f.map(f.current_window, iters=2)
+    torch.cuda.synchronize()
+    real = max(vb.pairs for vb in f._views.values())
+    assert real > (1 << 16), real                   # the scene really needs more than the floor capacity
+    gm = f.gaussians
+    for vb in f._views.values():                    # pretend the probes had seen a nearly empty map
+        vb.pairs = 1
+    f._cap = 1 << 16
+    f._views_dirty()
+    before = {n: getattr(gm, n).detach().clone() for n in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")}
+    f.map(f.current_window, iters=3)
+    torch.cuda.synchronize()
+    lr = {g["name"]: g["lr"] for g in gm.optimizer.param_groups}
+    name_of = {"_xyz": "xyz", "_features_dc": "f_dc", "_opacity": "opacity", "_scaling": "scaling", "_rotation": "rotation"}
+    for n, b in before.items():
+        p = getattr(gm, n).detach()
+        assert torch.isfinite(p).all(), n
+        assert float((p - b).abs().max()) <= 3 * 1.01 * lr[name_of[n]] + 1e-12, n       # |Adam step| <= lr (bias-corrected, 3 steps)
+        st = gm.optimizer.state[getattr(gm, n)]
+        assert torch.isfinite(st["exp_avg"]).all() and torch.isfinite(st["exp_avg_sq"]).all(), n
+    ev = f.overflow_events
+    f.check_overflow()
+    assert f.overflow_events > ev and f._cap >= 2 * real
+    f.map(f.current_window, iters=2)
+    f.check_overflow()
+    torch.cuda.synchronize()
+    assert all(vb.pairs <= f._cap for vb in f._views.values() if vb.clean)
+    for n in before:
+        assert torch.isfinite(getattr(gm, n)).all(), n
