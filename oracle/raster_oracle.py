@@ -386,7 +386,7 @@ def rasterize(means3D, means2D, opacities, shs=None, colors_precomp=None, scales
 
 @torch.no_grad()
 def knife_edge_gaussians(means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, *,
-                         settings: OracleSettings):
+                         settings: OracleSettings, detail=False):
     """Indices of the Gaussians that have, at some pixel, a composite / skip decision within KNIFE_BAND of its threshold.
 
     The rasterizer is piecewise continuous; exactly AT such a threshold two correct fp32 implementations (or fp32 and fp64)
@@ -399,6 +399,9 @@ def knife_edge_gaussians(means3D, opacities, shs=None, colors_precomp=None, scal
     knife = {}
     blend(pp, tile_ids, gauss_ids, settings, means3D.dtype, knife=knife)
     found = knife.get("gaussians", [])
+    if detail:        # what a test needs to move the scene off the edges: opacity decides the first kind, geometry the second
+        geo = _geometric_knife_edges(pp, int(settings.image_height), int(settings.image_width), sources_only=True)
+        return {"alpha": torch.unique(torch.cat(found)) if found else torch.zeros(0, dtype=torch.int64), "geometric": geo}
     found.append(_geometric_knife_edges(pp, int(settings.image_height), int(settings.image_width)))
     return torch.unique(torch.cat(found))
 
@@ -406,7 +409,7 @@ def knife_edge_gaussians(means3D, opacities, shs=None, colors_precomp=None, scal
 KNIFE_RADIUS_REL = 2e-4    # 3 sqrt(lambda_max) this close (relative) to an integer: ceil() may round the other way in fp32
 
 
-def _geometric_knife_edges(pp, H, W):
+def _geometric_knife_edges(pp, H, W, sources_only=False):
     """The two integer decisions of preprocessCUDA (forward.cu:240-260 as restated in preprocess above) that fp32 rounding of the
     projected centre can flip: the 16-pixel tile rectangle trunc((xy -+ r [+ 15]) / 16) when xy -+ r is within KNIFE_PIXEL_ERR
     of a multiple of 16 (measured: centre x = 507.99997 in fp64, 508.0000x in fp32 -> one more column of tiles, whose pixels
@@ -428,6 +431,8 @@ def _geometric_knife_edges(pp, H, W):
     ext = 3.0 * lam.clamp_min(0).sqrt()
     hit |= (ext - torch.round(ext)).abs() < KNIFE_RADIUS_REL * ext
     hit &= vis
+    if sources_only:
+        return torch.nonzero(hit).flatten()
     # ... and whoever shares pixels with such a splat: its flip puts alpha up to ~0.01 in front of (or takes it away from)
     # them at the pixels of the gained / lost tile row or column (measured: the neighbour 4 px away moved by 3e-4)
     out = hit.clone()

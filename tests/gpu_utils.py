@@ -104,19 +104,31 @@ def knife_ids(knife, n):
     return m
 
 
-def move_off_knife_edges(inp, s, max_rounds=10):
-    """Nudges the (activated) opacities of Gaussians that sit on a cut-off by 0.2-2 % until no composite / skip decision
-    of the view is within KNIFE_BAND of its threshold; returns the number of rounds.  The scene stays what it was for every
-    practical purpose, but fp32 and fp64 can no longer disagree about WHICH pairs contribute."""
+def move_off_knife_edges(inp, s, max_rounds=12):
+    """Nudges the Gaussians that sit on a cut-off until no decision of the view is within the oracle's knife bands of its
+    threshold: activated opacities by 0.2-2 % (alpha >= 1/255, T thresholds), and -- for the integer decisions of the
+    projection (16-pixel tile rectangle, ceil() of the radius) -- the centre by ~0.2 mm and the scales by <= 0.3 %.  Returns the
+    number of rounds.  The scene stays what it was for every practical purpose, but fp32 and fp64 can no longer disagree about
+    WHICH pairs contribute."""
     g = torch.Generator().manual_seed(17)
     for rnd in range(max_rounds):
-        k = O.knife_edge_gaussians(inp["means3D"], inp["opacities"], shs=inp.get("shs"), colors_precomp=inp.get("colors_precomp"),
+        d = O.knife_edge_gaussians(inp["means3D"], inp["opacities"], shs=inp.get("shs"), colors_precomp=inp.get("colors_precomp"),
                                    scales=inp.get("scales"), rotations=inp.get("rotations"), cov3D_precomp=inp.get("cov3D_precomp"),
-                                   settings=s)
-        if k.numel() == 0:
+                                   settings=s, detail=True)
+        k, kg = d["alpha"], d["geometric"]
+        if k.numel() == 0 and kg.numel() == 0:
             return rnd
-        f = 1.0 + (0.002 + 0.018 * torch.rand(k.numel(), generator=g, dtype=torch.float64))
-        o = inp["opacities"].clone()
-        o[k, 0] = torch.where(o[k, 0] * f < 0.9985, o[k, 0] * f, o[k, 0] / f)
-        inp["opacities"] = o.float().double()          # stays fp32-exact
+        if k.numel():
+            f = 1.0 + (0.002 + 0.018 * torch.rand(k.numel(), generator=g, dtype=torch.float64))
+            o = inp["opacities"].clone()
+            o[k, 0] = torch.where(o[k, 0] * f < 0.9985, o[k, 0] * f, o[k, 0] / f)
+            inp["opacities"] = o.float().double()          # stays fp32-exact
+        if kg.numel():
+            m = inp["means3D"].clone()
+            m[kg] += 2e-4 * torch.randn(kg.numel(), 3, generator=g, dtype=torch.float64)
+            inp["means3D"] = m.float().double()
+            if inp.get("scales") is not None:
+                sc = inp["scales"].clone()
+                sc[kg] *= 1.0 + 0.003 * torch.rand(kg.numel(), 1, generator=g, dtype=torch.float64)
+                inp["scales"] = sc.float().double()
     raise AssertionError("scene still has knife-edge pairs after %d rounds" % max_rounds)

@@ -137,7 +137,7 @@ def test_autograd_api_matches_oracle_at_config_size(case):
     soft = Soft()
     if deknife:        # the two headline configs are compared WITHOUT exceptions: first move the scene off its knife edges
         rounds = move_off_knife_edges(inp, s)
-        soft.check(True, f"{name}: {rounds} rounds of opacity nudging to clear the knife edges")
+        soft.check(True, f"{name}: {rounds} rounds of nudging (opacity; centre and scale for tile-rectangle or radius edges) to clear the knife edges")
     g = torch.Generator().manual_seed(5)
     wc = torch.randn(3, intr["H"], intr["W"], generator=g, dtype=torch.float64)
     wd = torch.randn(1, intr["H"], intr["W"], generator=g, dtype=torch.float64)

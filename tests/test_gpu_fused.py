@@ -552,7 +552,7 @@ def test_views_that_overflow_the_pair_capacity_take_no_part_in_the_step():
         assert torch.isfinite(st["exp_avg"]).all() and torch.isfinite(st["exp_avg_sq"]).all(), n
     ev = f.overflow_events
     f.check_overflow()
-    assert f.overflow_events > ev and f._cap >= 2 * real
+    assert f.overflow_events > ev and f._cap >= 1.5 * real
     f.map(f.current_window, iters=2)
     f.check_overflow()
     torch.cuda.synchronize()
