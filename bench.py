@@ -253,14 +253,15 @@ class Bench:
                 self.lib.sgr_set_option(self.nat.SGR_OPT_SEGMENT_TEST, 0)
         return res
 
-    def scene_leg(self, scale_add, steps=40):
-        loop, cams = self.build("fused", scale_add)
+    def scene_leg(self, scale_add, steps=40, order=None):
+        loop, cams = self.build("fused", scale_add, order=order)
         self.run_steps(loop, 10)
         el, _ = self.timed(loop, steps)
         per_view, hist = self.work_counters(loop)
         roof, roof_f = self.rooflines(loop, per_view, 20)
+        allk = self.profiled(loop, 20, (1 << len(KINDS)) - 1, fused_blend=True)      # (HIP events around every kernel: serialises them)
         nv = len(per_view)
-        return {"scale_add": scale_add, "ms_per_step": round(1e3 * el / steps, 4), "keyframes_per_s": round((steps / el) / 61.0, 3),
+        return {"scale_add": scale_add, "kernel_ms": {KINDS[i]: round(ms, 5) for i, (ms, n) in allk.items() if n}, "ms_per_step": round(1e3 * el / steps, 4), "keyframes_per_s": round((steps / el) / 61.0, 3),
                 "visible_gaussians": sum(p[0] for p in per_view) // nv, "tile_pairs_R": sum(p[1] for p in per_view) // nv,
                 "tile_pairs_walked_R_eff": sum(p[2] for p in per_view) // nv, "tiles_by_walked_list_length_last_view": hist,
                 "blend_bwd_frac": roof["frac"], "blend_bwd_avg_launch_ms": roof["avg_launch_ms"],
@@ -377,7 +378,8 @@ def main():
             trace("dropin done")
             torch.cuda.empty_cache()
             out["extra"] = {}
-            for name, leg in (("opaque_scene", lambda: B.scene_leg(args.scale_add + 1.6)), ("keyframe_ordered_map", B.order_leg)):
+            for name, leg in (("opaque_scene", lambda: B.scene_leg(args.scale_add + 1.6)), ("keyframe_ordered_map", B.order_leg),
+                              ("opaque_scene_keyframe_ordered", lambda: B.scene_leg(args.scale_add + 1.6, order="keyframe"))):
                 try:
                     out["extra"][name] = leg()
                 except Exception as e:      # noqa: BLE001
