@@ -118,6 +118,9 @@ class _DeviceState:
                     break
                 torch.cuda.current_stream(self.dev).synchronize()
             R = int(self.ring_np[slot, 0])
+            if int(self.ring_np[slot, 1]) == 2:                # header.overflow == 2: a 16-bit tile counter saturated
+                self.pending.pop(0)
+                raise RuntimeError("more than 65280 splats on one 8x8 tile: the map has degenerated")
             self.last_pairs = R
             if _CAP_FACTOR * R > self.capacity:
                 self.capacity = _CAP_FACTOR * R

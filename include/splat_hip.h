@@ -156,7 +156,11 @@ size_t sgr_scratch_bytes(int32_t num_gaussians, int32_t image_height, int32_t im
  *   non-NULL: the call synchronises once on `stream` to learn the pair count R, sorts exactly R pairs, stores R
  *             there, and fails with SGR_ERR_CAPACITY (outputs untouched) when R > ws->capacity;
  *   NULL    : fully asynchronous; pairs beyond ws->capacity are dropped and the overflow word of the saved
- *             block is raised -- poll it with sgr_query(). */
+ *             block is raised -- poll it with sgr_query().
+ * Overflow word: 0 = fine; 1 = R > capacity (grow the workspace and redo); 2 = more than 65280 splats fell on ONE 8x8 tile
+ * (the per-tile pair counters are 16-bit fields of a word shared by a 2x2 block of tiles; only a degenerate map gets there)
+ * -- the synchronous form fails with SGR_ERR_INVALID.  A view whose overflow word is non-zero contributes zeros to
+ * sgr_backward / sgr_map_* gradients instead of sums over truncated lists. */
 int sgr_forward(const SgrSettings* settings, const SgrInputs* in, const SgrOutputs* out,
                 const SgrWorkspace* ws, int64_t* num_rendered_host, void* stream);
 
@@ -168,7 +172,7 @@ int sgr_backward(const SgrSettings* settings, const SgrInputs* in, const int32_t
 int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_host, void* stream);
 
 /* Asynchronous variant: enqueues a 64-byte copy of the saved block's header (uint32 words: [0] pair count R, [1] overflow
- * flag, [2] pairs binned, [3] visible Gaussians, [4] over-full tiles, [5..15] zero) into PINNED host memory on `stream`.
+ * flag, [2] pairs binned, [3] visible Gaussians, [4] over-full tiles, [5..14] internal, [15] zero) into PINNED host memory on `stream`.
  * The caller pre-sets word 15 to a non-zero sentinel and knows the copy has landed when it reads 0 there: a later call can
  * then learn R without ever waiting (the drop-in package sizes its capacity this way). */
 int sgr_header_to_host(const void* saved, void* pinned_host64, void* stream);

@@ -200,10 +200,13 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
   Common cm = make_common(s);
   if (int rc = forward_batch(tab, 1, L, cm, *in, st, ws->counters_clean != 0)) return rc;
   if (num_rendered_host) {
-    uint32_t R = 0;
-    HIP_TRY(hipMemcpyAsync(&R, &((SavedHeader*)((char*)ws->saved + L.o_hdr))->num_rendered, 4, hipMemcpyDeviceToHost, st));
+    uint32_t h2[2] = {0u, 0u};        // num_rendered, overflow
+    HIP_TRY(hipMemcpyAsync(h2, (char*)ws->saved + L.o_hdr, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t R = h2[0];
     *num_rendered_host = R;
+    if (h2[1] == 2u)
+      return set_error(SGR_ERR_INVALID, "more than %u splats on one 8x8 tile: the map has degenerated (16-bit tile counters)", kTileCountLimit);
     if ((int64_t)R > L.cap) return set_error(SGR_ERR_CAPACITY, "%u (tile, Gaussian) pairs exceed capacity %lld", R, (long long)L.cap);
   }
   LOff d1 = L.dev();

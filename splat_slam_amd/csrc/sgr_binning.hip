@@ -47,21 +47,26 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
   if (blockIdx.x == 0) {
     uint32_t* tmp = (uint32_t*)(saved + L.o_tile_maxc);      // free until blend_fwd overwrites it
     uint2* ranges = (uint2*)(saved + L.o_ranges);
-    uint32_t* tile_count = (uint32_t*)(saved + L.o_tile_count);
-    auto cidx = [&](int t) { return tile_counter_index(t % L.gx, t / L.gx, L.gxp); };
-    uint32_t R = block1024_scan([&](int t) { return tile_count[cidx(t)]; }, tmp, L.ntiles, red);
+    unsigned long long* tile_count = (unsigned long long*)(saved + L.o_tile_count);
+    auto count_of = [&](int t) {
+      const int x = t % L.gx, y = t / L.gx;
+      return (uint32_t)(tile_count[tile_counter_word(x, y, L.gxp)] >> tile_counter_shift(x, y)) & 0xffffu;
+    };
+    uint32_t R = block1024_scan([&](int t) { return count_of(t); }, tmp, L.ntiles, red);
     __syncthreads();
-    uint32_t over = 0;
+    uint32_t over = 0, saturated = 0;
     for (int t = threadIdx.x; t < L.ntiles; t += 1024) {
-      const uint32_t s0 = tmp[t], c = tile_count[cidx(t)];
+      const uint32_t s0 = tmp[t], c = count_of(t);
+      saturated |= c >= kTileCountLimit ? 1u : 0u;
       // <= kBucket pairs: K1 already binned them in the tile's bucket, the run [s0, s0+c) only addresses point_list.
       // more: scatter_kernel fills the run; .y is its fill cursor and ends at s0 + c as well.
       ranges[(size_t)t * kRngStride] = make_uint2(c <= (uint32_t)kBucket ? s0 : (s0 | kOverfull), s0 + c);
       over += c > (uint32_t)kBucket ? 1u : 0u;
-      tile_count[cidx(t)] = 0u;       // consumed: leave the counters clean for the next forward
     }
     over = wave_scan_add_u32(over);
-    __syncthreads();
+    saturated = __syncthreads_or((int)saturated) ? 1u : 0u;
+    // consumed: leave the counters clean for the next forward
+    for (int w = threadIdx.x; w < ((L.gy + 1) / 2) * L.gxp; w += 1024) tile_count[(size_t)w * (kCntSlotWords / 2)] = 0ull;
     if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = over;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -71,7 +76,10 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
       hdr->ovf_count = hdr->ovf_cursor;          // K1 is done appending; leave the cursor clean for the next forward
       hdr->ovf_cursor = 0u;
       hdr->num_rendered = R;
-      hdr->overflow = (int64_t)R > L.cap ? 1u : 0u;
+      // 1: more pairs than the workspace holds (grow it); 2: > kTileCountLimit splats on ONE 8x8 tile (the map has degenerated:
+      // a 16-bit tile counter may have carried into its neighbour) -- either way the lists of this view are not to be used
+      hdr->overflow = (saturated || hdr->count_saturated) ? 2u : ((int64_t)R > L.cap ? 1u : 0u);
+      hdr->count_saturated = 0u;
       hdr->sorted_count = (uint32_t)((int64_t)R > L.cap ? L.cap : (int64_t)R);
     }
   } else if (blockIdx.x == 1) {

@@ -19,13 +19,15 @@ constexpr float kTouchedT = 0.5f;
 constexpr int kRefTile = 16;           // upstream tile edge: defines which pixels a splat may reach
 constexpr int kTile = 8;               // our binning tile = one wave64 = 8x8 pixels
 constexpr int kWave = 64;
-// per-tile atomic counters live on their own 64-byte line: ~200 atomics per line (16 counters x 12 hits) serialised the
-// binning kernels, one counter per line does not
-// per-tile pair counters: the counters of two horizontally adjacent tiles (x even, x+1) are the halves of ONE 64-bit word,
-// so a splat that covers both takes one atomic for the two ranks (binning is bound by the number of atomics); one such
-// word per 32 bytes keeps the per-line contention where the padded layout had it
-constexpr int kCntSlotWords = 8;       // uint32 units per tile-pair slot
-__host__ __device__ inline size_t tile_counter_index(int x, int y, int gxp) { return ((size_t)y * gxp + (x >> 1)) * kCntSlotWords + (x & 1); }
+// Per-tile pair counters.  Binning is bound by the NUMBER of counting atomics (they execute at the memory side: ~12 per ns
+// chip-wide, measured: 245 of the 357 us of K1 on a converged map), so ONE 64-bit word holds the four 16-bit counters of a
+// 2x2 block of tiles and a splat takes the ranks of every tile it covers in that block with one atomic.  A field that
+// reaches kTileCountLimit marks the view as degenerate (header.overflow = 2): beyond it a carry could reach the
+// neighbour's field.  One word per 32 bytes keeps the per-line contention low (one counter per line measured no better).
+constexpr int kCntSlotWords = 8;       // uint32 units per 2x2-block slot
+constexpr uint32_t kTileCountLimit = 0xff00u;
+__host__ __device__ inline size_t tile_counter_word(int x, int y, int gxp) { return ((size_t)(y >> 1) * gxp + (x >> 1)) * (kCntSlotWords / 2); }   // in uint64 units
+__host__ __device__ inline int tile_counter_shift(int x, int y) { return 16 * ((y & 1) * 2 + (x & 1)); }
 constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
 // Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the
 // key goes straight into the tile's fixed bucket -- no second pass.  Only tiles with more than kBucket pairs are re-scattered
@@ -46,13 +48,14 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 // ---- header at the start of the saved block
 struct SavedHeader {
   uint32_t num_rendered;   // R: total (tile, Gaussian) pairs demanded (may exceed capacity)
-  uint32_t overflow;       // != 0 when R > capacity (pairs were dropped)
+  uint32_t overflow;       // 1: R > capacity (pairs were dropped); 2: a 16-bit tile counter saturated (> kTileCountLimit splats on one tile)
   uint32_t sorted_count;   // number of pairs actually binned = min(R, capacity)
   uint32_t num_visible;    // V: Gaussians with radii > 0
   uint32_t num_overfull;   // tiles with more than kBucket pairs (scatter_kernel completes only those)
   uint32_t ovf_cursor;     // K1's append cursor into the overflow list (pairs whose rank in their tile is >= kBucket); K2 resets it
   uint32_t ovf_count;      // ... its final value for this forward (written by K2, read by K3)
-  uint32_t pad[9];
+  uint32_t count_saturated;  // K1: some pair drew a rank >= kTileCountLimit (sticky until K2 folds it into `overflow` and clears it)
+  uint32_t pad[8];
 };
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint32_t red[4];
   __shared__ uint32_t vis_bits[kSeg];            // per Gaussian of the segment: bit v = view v of the batch sees it
   __shared__ uint32_t op_ex[kSeg];               // load-balanced counting atomics: per owner thread, prefix of its remaining operations,
-  __shared__ uint4 op_rect[kSeg];                // ... its rectangle (x0 | y0 << 16, x1 | opr << 16, lead | view << 8, Gaussian)
+  __shared__ uint4 op_rect[kSeg];                // ... its rectangle (x0 | y0 << 16, x1 | y1 << 16, view, Gaussian)
   __shared__ uint32_t op_depth[kSeg];            // ... and the depth half of its key
   __shared__ float seg_box[4][8];                // per wave: min xyz, max xyz, max trS of its 64 Gaussians
   __shared__ uint32_t seg_views;                 // bit v = some Gaussian of this segment MAY be visible in view v
@@ -490,24 +490,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
     // Count the pairs per tile; the returning atomic is the pair's rank in its tile: while the tile's bucket has room the
     // key is binned right here, beyond that the pair joins the view's overflow list (K3 files it at start(tile) + rank once
-    // the tile starts are known).  The kernel's time follows the NUMBER of atomics, so a splat that covers the two tiles of
-    // a counter word (x even, x+1) takes both ranks with ONE 64-bit atomic; a row of the rectangle is a leading single
-    // tile (odd x0), pairs, and a trailing single tile.  The first 4 operations of every splat (most splats of a fresh map
-    // need <= 4) are issued now and consumed after the block scans below, which hide their round trip; the remaining ones
-    // -- a converged map has splats that cover tens to hundreds of tiles -- are dealt out evenly over the block.
+    // the tile starts are known).  The kernel's time follows the NUMBER of atomics (they execute at the memory side), so the
+    // four 16-bit counters of a 2x2 block of tiles share ONE 64-bit word and a splat takes all its ranks in that block with
+    // one atomic: an operation = one 2x2 block of the rectangle.  The first 4 operations of every splat (most splats of a
+    // fresh map need <= 4) are issued now and consumed after the block scans below, which hide their round trip; the
+    // remaining ones -- a converged map has splats that cover tens to hundreds of tiles -- are dealt out evenly over the block.
     const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
-    const int lead = o.x0 & 1, wrect = o.x1 - o.x0;
-    const int opr = lead + ((wrect - lead + 1) >> 1);                  // operations per row
-    const int nops = cnt > 0u ? opr * (o.y1 - o.y0) : 0;
-    // operation k of the rectangle (x0, y0, x1, lead, opr) of a splat of view `view`: tile(s) + the counting atomic
-    auto issue = [&](int view, int x0, int y0, int x1, int ld, int per_row, int k, int& tx, int& ty, bool& pair) -> unsigned long long {
-      const int row = k / per_row, j = k % per_row;
-      ty = y0 + row;
-      tx = (ld && j == 0) ? x0 : x0 + ld + 2 * (j - ld);
-      pair = !(tx & 1) && (tx + 1 < x1);
-      uint32_t* c = (uint32_t*)(p_saved[view] + L.o_tile_count) + tile_counter_index(tx, ty, L.gxp);
-      if (pair) return atomicAdd((unsigned long long*)c, 0x100000001ull);
-      return (unsigned long long)atomicAdd(c, 1u);
+    const int nbx = cnt > 0u ? ((o.x1 - 1) >> 1) - (o.x0 >> 1) + 1 : 0;              // 2x2 blocks per row of blocks
+    const int nops = cnt > 0u ? nbx * (((o.y1 - 1) >> 1) - (o.y0 >> 1) + 1) : 0;
+    // operation k of the rectangle [x0, x1) x [y0, y1) of a splat of view `view`: its 2x2 block (even bx, by = the block's
+    // first tile), which of the four tiles the rectangle covers (bit s = (y & 1) * 2 + (x & 1)), and the counting atomic
+    auto issue = [&](int view, int x0, int y0, int x1, int y1, int k, int& bx, int& by, uint32_t& cover) -> unsigned long long {
+      const int per_row = ((x1 - 1) >> 1) - (x0 >> 1) + 1;
+      bx = ((x0 >> 1) + k % per_row) * 2;
+      by = ((y0 >> 1) + k / per_row) * 2;
+      const bool c0 = bx >= x0, c1 = bx + 1 < x1, r0 = by >= y0, r1 = by + 1 < y1;
+      cover = (uint32_t)(r0 && c0) | ((uint32_t)(r0 && c1) << 1) | ((uint32_t)(r1 && c0) << 2) | ((uint32_t)(r1 && c1) << 3);
+      const unsigned long long inc = (unsigned long long)(cover & 1u) | ((unsigned long long)((cover >> 1) & 1u) << 16) |
+                                     ((unsigned long long)((cover >> 2) & 1u) << 32) | ((unsigned long long)((cover >> 3) & 1u) << 48);
+      unsigned long long* c = (unsigned long long*)(p_saved[view] + L.o_tile_count) + tile_counter_word(bx, by, L.gxp);
+      return atomicAdd(c, inc);
     };
     // a pair whose tile's bucket is full joins its view's overflow list; the lanes of a wave that overflow in the same step
     // share ONE atomic on the list cursor per view present in the wave.  Called by the whole wave (`want` selects lanes).
@@ -527,21 +529,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         m &= ~same;
       }
     };
-    auto consume = [&](bool on, int view, unsigned long long old, int tx, int ty, bool pair, uint64_t kk) {
-      const uint32_t t0 = (uint32_t)(ty * L.gx + tx);
-      const uint32_t r0 = (uint32_t)old, r1 = (uint32_t)(old >> 32);
+    auto consume = [&](bool on, int view, unsigned long long old, int bx, int by, uint32_t cover, uint64_t kk) {
       uint64_t* bucket = (uint64_t*)(p_scratch[view] + L.o_bucket);
-      if (on && r0 < (uint32_t)kBucket) bucket[(size_t)t0 * kBucket + r0] = kk;
-      if (on && pair && r1 < (uint32_t)kBucket) bucket[(size_t)(t0 + 1) * kBucket + r1] = kk;
-      spill(on && r0 >= (uint32_t)kBucket, view, t0, r0, kk);
-      spill(on && pair && r1 >= (uint32_t)kBucket, view, t0 + 1, r1, kk);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const bool mine = on && ((cover >> s4) & 1u);
+        const uint32_t t = (uint32_t)((by + (s4 >> 1)) * L.gx + bx + (s4 & 1));
+        const uint32_t r = (uint32_t)(old >> (16 * s4)) & 0xffffu;
+        if (mine && r < (uint32_t)kBucket) bucket[(size_t)t * kBucket + r] = kk;
+        if (mine && r >= kTileCountLimit) ((SavedHeader*)(p_saved[view] + L.o_hdr))->count_saturated = 1u;   // (before the field can wrap)
+        spill(mine && r >= (uint32_t)kBucket, view, t, r, kk);
+      }
     };
     unsigned long long old4[4] = {0ull, 0ull, 0ull, 0ull};
     int tx4[4] = {0, 0, 0, 0}, ty4[4] = {0, 0, 0, 0};
-    bool pr4[4] = {false, false, false, false};
+    uint32_t pr4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (jj < nops) old4[jj] = issue(v, o.x0, o.y0, o.x1, lead, opr, jj, tx4[jj], ty4[jj], pr4[jj]);
+      if (jj < nops) old4[jj] = issue(v, o.x0, o.y0, o.x1, o.y1, jj, tx4[jj], ty4[jj], pr4[jj]);
     uint32_t tot_t, tot_v;
     const uint32_t ex_t = carry_t + block256_exclusive_scan(cnt, red, tot_t);
     const uint32_t ex_v = carry_v + block256_exclusive_scan(vis, red, tot_v);
@@ -560,8 +565,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       uint32_t tot_r;
       const uint32_t ex_r = block256_exclusive_scan((uint32_t)rem, red, tot_r);
       op_ex[tid] = ex_r;
-      op_rect[tid] = make_uint4((uint32_t)o.x0 | ((uint32_t)o.y0 << 16), (uint32_t)o.x1 | ((uint32_t)opr << 16),
-                                (uint32_t)lead | ((uint32_t)v << 8), (uint32_t)i);
+      op_rect[tid] = make_uint4((uint32_t)o.x0 | ((uint32_t)o.y0 << 16), (uint32_t)o.x1 | ((uint32_t)o.y1 << 16), (uint32_t)v, (uint32_t)i);
       op_depth[tid] = __float_as_uint(o.depth);
       __syncthreads();
 #pragma unroll 1
@@ -578,10 +582,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (op_ex[mid] <= item) lo = mid + 1; else hi = mid; }
             const int owner = lo - 1;
             const uint4 r = op_rect[owner];
-            view4[jj] = (int)(r.z >> 8);
+            view4[jj] = (int)r.z;
             key4[jj] = ((uint64_t)op_depth[owner] << 32) | r.w;
-            old4[jj] = issue(view4[jj], (int)(r.x & 0xffffu), (int)(r.x >> 16), (int)(r.y & 0xffffu), (int)(r.z & 0xffu),
-                             (int)(r.y >> 16), 4 + (int)(item - op_ex[owner]), tx4[jj], ty4[jj], pr4[jj]);
+            old4[jj] = issue(view4[jj], (int)(r.x & 0xffffu), (int)(r.x >> 16), (int)(r.y & 0xffffu), (int)(r.y >> 16),
+                             4 + (int)(item - op_ex[owner]), tx4[jj], ty4[jj], pr4[jj]);
           }
         }
 #pragma unroll

@@ -780,6 +780,8 @@ class FusedMappingLoop(MappingLoop):
             R, ov = C.c_int64(0), C.c_int32(0)
             nat.check(self.lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), self._stream()), "sgr_query")
             self.overflow_events += int(bool(ov.value))
+            if ov.value == 2:
+                raise RuntimeError(f"camera {uid}: more than 65280 splats on one 8x8 tile -- the map has degenerated")
             vb.pairs = int(R.value)
             if vb.pairs > self.max_pairs:
                 raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
