@@ -151,7 +151,7 @@ struct Layout {
     nseg = (N + kSeg - 1) / kSeg;
     size_t nb = (size_t)(pre_blocks > 0 ? pre_blocks : 1);
     o_hdr = take(sizeof(SavedHeader));
-    o_tile_count = take((size_t)gy * ((gx + 1) / 2) * 4 * kCntSlotWords);     // hdr + tile_count are zeroed by ONE launch (fresh blocks)
+    o_tile_count = take((size_t)((gy + 1) / 2) * ((gx + 1) / 2) * 4 * kCntSlotWords);     // hdr + tile_count are zeroed by ONE launch (fresh blocks)
     zero_bytes = o;
     o_grec = take(n * sizeof(GRec));   // one 64-byte record per Gaussian: what binning / blending / backward gather
     o_point_list = take(c * 4);

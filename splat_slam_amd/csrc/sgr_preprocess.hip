@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint32_t red[4];
   __shared__ uint32_t vis_bits[kSeg];            // per Gaussian of the segment: bit v = view v of the batch sees it
   __shared__ uint32_t op_ex[kSeg];               // load-balanced counting atomics: per owner thread, prefix of its remaining operations,
-  __shared__ uint4 op_rect[kSeg];                // ... its rectangle (x0 | y0 << 16, x1 | y1 << 16, view, Gaussian)
+  __shared__ uint4 op_rect[kSeg];                // ... its rectangle (x0 | x1 << 16, y0 | y1 << 16), view, Gaussian
   __shared__ uint32_t op_depth[kSeg];            // ... and the depth half of its key
   __shared__ float seg_box[4][8];                // per wave: min xyz, max xyz, max trS of its 64 Gaussians
   __shared__ uint32_t seg_views;                 // bit v = some Gaussian of this segment MAY be visible in view v
@@ -455,9 +455,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     char* saved = p_saved[v];
     if (live) {
       i = seg0 + (int)cand[v][f - vstart[v]];
-      float vm[16], pm[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { vm[k] = mats[v][k]; pm[k] = mats[v][16 + k]; }
+      const float* vm = mats[v];                 // read from LDS where used: 32 matrix registers put the loop over its budget
+      const float* pm = mats[v] + 16;
       PreIn in;
       { const F3 t = ld3(means3D + 3 * i); in.p[0] = t.x; in.p[1] = t.y; in.p[2] = t.z; }
       in.opac = opacities[i];
@@ -492,61 +491,141 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     // key is binned right here, beyond that the pair joins the view's overflow list (K3 files it at start(tile) + rank once
     // the tile starts are known).  The kernel's time follows the NUMBER of atomics (they execute at the memory side), so the
     // four 16-bit counters of a 2x2 block of tiles share ONE 64-bit word and a splat takes all its ranks in that block with
-    // one atomic: an operation = one 2x2 block of the rectangle.  The first 4 operations of every splat (most splats of a
-    // fresh map need <= 4) are issued now and consumed after the block scans below, which hide their round trip; the
-    // remaining ones -- a converged map has splats that cover tens to hundreds of tiles -- are dealt out evenly over the block.
-    const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
-    const int nbx = cnt > 0u ? ((o.x1 - 1) >> 1) - (o.x0 >> 1) + 1 : 0;              // 2x2 blocks per row of blocks
-    const int nops = cnt > 0u ? nbx * (((o.y1 - 1) >> 1) - (o.y0 >> 1) + 1) : 0;
-    // operation k of the rectangle [x0, x1) x [y0, y1) of a splat of view `view`: its 2x2 block (even bx, by = the block's
-    // first tile), which of the four tiles the rectangle covers (bit s = (y & 1) * 2 + (x & 1)), and the counting atomic
-    auto issue = [&](int view, int x0, int y0, int x1, int y1, int k, int& bx, int& by, uint32_t& cover) -> unsigned long long {
+    // one atomic: an operation = one 2x2 block of the rectangle.  Every splat issues its first 4 operations itself, right away
+    // (a fresh map's splats need no more), and their round trip hides behind the block scans; a converged map's splats need
+    // tens to hundreds: the rest is dealt out evenly over the block's threads (item -> owner by a search in the owners'
+    // prefix sums), four per thread and round.
+    const uint32_t my_rx = (uint32_t)o.x0 | ((uint32_t)o.x1 << 16), my_ry = (uint32_t)o.y0 | ((uint32_t)o.y1 << 16);
+    const uint32_t nops = cnt > 0u ? (uint32_t)((((o.x1 - 1) >> 1) - (o.x0 >> 1) + 1) * (((o.y1 - 1) >> 1) - (o.y0 >> 1) + 1)) : 0u;
+    op_rect[tid] = make_uint4(my_rx, my_ry, (uint32_t)v, (uint32_t)i);
+    op_depth[tid] = __float_as_uint(o.depth);
+    // operation k of the rectangle rx = x0 | x1 << 16, ry = y0 | y1 << 16: its 2x2 block (bx, by = the block's first tile, both
+    // even) and which of its four tiles the rectangle covers (bit s = (y & 1) * 2 + (x & 1)), packed bx | by << 14 | cover << 28
+    // so that ONE register per operation stays live across the atomic's round trip
+    auto op_geom = [](uint32_t rx, uint32_t ry, int k) -> uint32_t {
+      const int x0 = (int)(rx & 0xffffu), x1 = (int)(rx >> 16), y0 = (int)(ry & 0xffffu), y1 = (int)(ry >> 16);
       const int per_row = ((x1 - 1) >> 1) - (x0 >> 1) + 1;
-      bx = ((x0 >> 1) + k % per_row) * 2;
-      by = ((y0 >> 1) + k / per_row) * 2;
+      // k / per_row for k < 2^20: float quotient of (k + 0.5), exact after one correction step
+      int q = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)per_row));
+      int rem = k - q * per_row;
+      if (rem < 0) { --q; rem += per_row; }
+      if (rem >= per_row) { ++q; rem -= per_row; }
+      const int bx = ((x0 >> 1) + rem) * 2, by = ((y0 >> 1) + q) * 2;
       const bool c0 = bx >= x0, c1 = bx + 1 < x1, r0 = by >= y0, r1 = by + 1 < y1;
-      cover = (uint32_t)(r0 && c0) | ((uint32_t)(r0 && c1) << 1) | ((uint32_t)(r1 && c0) << 2) | ((uint32_t)(r1 && c1) << 3);
+      const uint32_t cover = (uint32_t)(r0 && c0) | ((uint32_t)(r0 && c1) << 1) | ((uint32_t)(r1 && c0) << 2) | ((uint32_t)(r1 && c1) << 3);
+      return (uint32_t)bx | ((uint32_t)by << 14) | (cover << 28);
+    };
+    // ... and its counting atomic: the old word holds the rank of this splat in each covered tile
+    auto issue = [&](int view, uint32_t geo) -> unsigned long long {
+      const uint32_t cover = geo >> 28;
       const unsigned long long inc = (unsigned long long)(cover & 1u) | ((unsigned long long)((cover >> 1) & 1u) << 16) |
                                      ((unsigned long long)((cover >> 2) & 1u) << 32) | ((unsigned long long)((cover >> 3) & 1u) << 48);
-      unsigned long long* c = (unsigned long long*)(p_saved[view] + L.o_tile_count) + tile_counter_word(bx, by, L.gxp);
+      unsigned long long* c = (unsigned long long*)(p_saved[view] + L.o_tile_count) +
+                              tile_counter_word((int)(geo & 0x3fffu), (int)((geo >> 14) & 0x3fffu), L.gxp);
       return atomicAdd(c, inc);
     };
-    // a pair whose tile's bucket is full joins its view's overflow list; the lanes of a wave that overflow in the same step
-    // share ONE atomic on the list cursor per view present in the wave.  Called by the whole wave (`want` selects lanes).
-    auto spill = [&](bool want, int view, uint32_t tile, uint32_t rank, uint64_t kk) {
-      unsigned long long m = __ballot(want);
+    // Binning of a batch of (up to) four operations per lane; desc(jj) -> (on, view, key) of operation jj, geo[jj] its block.
+    // A pair whose rank fits the tile's bucket is written there; the others join their view's overflow list.  On a converged
+    // map a third of all pairs overflow (lists of ~100 against kBucket = 64) and the list cursor is ONE word per view, so the
+    // append is aggregated as far as it goes: per batch the wave takes ONE returning atomic per view present in it (5-bit-plane
+    // ballots give every lane its offset), where one atomic per (operation, tile) -- sixteen dependent round trips per batch
+    // -- cost 220 of K1's 395 us.
+    struct Desc { int view; uint64_t key; };
+    auto desc_of = [&](int owner) -> Desc {          // (owner >= 0) from the owner tables in LDS
+      const uint2 vz = *(const uint2*)&op_rect[owner].z;          // (view, Gaussian)
+      return Desc{(int)vz.x, ((uint64_t)op_depth[owner] << 32) | vz.y};
+    };
+    auto consume4 = [&](const unsigned long long old[4], const uint32_t geo[4], const int owner[4]) {
+      uint32_t sp = 0u;                         // 4 bits per operation: which of its four tiles overflow
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const bool on = owner[jj] >= 0;
+        const Desc d = desc_of(on ? owner[jj] : 0);
+        const uint32_t t00 = ((geo[jj] >> 14) & 0x3fffu) * (uint32_t)L.gx + (geo[jj] & 0x3fffu);
+        uint64_t* bucket = (uint64_t*)(p_scratch[d.view] + L.o_bucket);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const bool mine = on && ((geo[jj] >> (28 + s4)) & 1u);
+          const uint32_t t = t00 + (uint32_t)((s4 >> 1) * L.gx + (s4 & 1));
+          const uint32_t r = (uint32_t)(old[jj] >> (16 * s4)) & 0xffffu;
+          if (mine && r < (uint32_t)kBucket) bucket[(size_t)t * kBucket + r] = d.key;
+          if (mine && r >= (uint32_t)kBucket) sp |= 1u << (4 * jj + s4);
+        }
+      }
+      unsigned long long m = __ballot(sp != 0u);
+      if (m == 0ull) return;                                   // (a fresh map: nothing overflows)
+      // the slow path is written ROLLED over the four operations (selects instead of register arrays): unrolled it put the
+      // whole kernel 50 registers over its budget
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      auto pick = [](auto a0, auto a1, auto a2, auto a3, int j) { return j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)); };
       while (m != 0ull) {
         const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-        const int lv = __builtin_amdgcn_readlane(view, leader);
-        const unsigned long long same = __ballot(want && view == lv);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&((SavedHeader*)(p_saved[lv] + L.o_hdr))->ovf_cursor, (uint32_t)__popcll(same));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if (want && view == lv) {
-          const uint64_t pos = (uint64_t)base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-          if ((int64_t)pos < L.cap) ((OvfEntry*)(p_scratch[lv] + L.o_ovf))[pos] = OvfEntry{tile, rank, kk};
+        int mine_v = 0;
+        if (sp != 0u) mine_v = desc_of(pick(owner[0], owner[1], owner[2], owner[3], (__ffs((int)sp) - 1) >> 2)).view;
+        const int lv = __builtin_amdgcn_readlane(mine_v, leader);
+        uint32_t c = 0;                         // this lane's overflowing pairs of view lv: 0..16
+#pragma unroll 1
+        for (int jj = 0; jj < 4; ++jj) {
+          const uint32_t nib = (sp >> (4 * jj)) & 15u;
+          if (nib != 0u && desc_of(pick(owner[0], owner[1], owner[2], owner[3], jj)).view == lv) c += (uint32_t)__popc(nib);
         }
-        m &= ~same;
-      }
-    };
-    auto consume = [&](bool on, int view, unsigned long long old, int bx, int by, uint32_t cover, uint64_t kk) {
-      uint64_t* bucket = (uint64_t*)(p_scratch[view] + L.o_bucket);
+        uint32_t pre = 0, tot = 0;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const bool mine = on && ((cover >> s4) & 1u);
-        const uint32_t t = (uint32_t)((by + (s4 >> 1)) * L.gx + bx + (s4 & 1));
-        const uint32_t r = (uint32_t)(old >> (16 * s4)) & 0xffffu;
-        if (mine && r < (uint32_t)kBucket) bucket[(size_t)t * kBucket + r] = kk;
-        if (mine && r >= kTileCountLimit) ((SavedHeader*)(p_saved[view] + L.o_hdr))->count_saturated = 1u;   // (before the field can wrap)
-        spill(mine && r >= (uint32_t)kBucket, view, t, r, kk);
+        for (int bit = 0; bit < 5; ++bit) {
+          const unsigned long long bal = __ballot((c >> bit) & 1u);
+          pre += (uint32_t)__popcll(bal & lt) << bit;
+          tot += (uint32_t)__popcll(bal) << bit;
+        }
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&((SavedHeader*)(p_saved[lv] + L.o_hdr))->ovf_cursor, tot);
+        uint64_t pos = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)base, leader) + pre;
+        OvfEntry* ovf = (OvfEntry*)(p_scratch[lv] + L.o_ovf);
+#pragma unroll 1
+        for (int jj = 0; jj < 4; ++jj) {
+          const uint32_t nib = (sp >> (4 * jj)) & 15u;
+          if (nib == 0u) continue;
+          const Desc d = desc_of(pick(owner[0], owner[1], owner[2], owner[3], jj));
+          if (d.view != lv) continue;
+          const uint32_t g = pick(geo[0], geo[1], geo[2], geo[3], jj);
+          const unsigned long long oj = pick(old[0], old[1], old[2], old[3], jj);
+          const uint32_t t00 = ((g >> 14) & 0x3fffu) * (uint32_t)L.gx + (g & 0x3fffu);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            if ((nib >> s4) & 1u) {
+              const uint32_t r = (uint32_t)(oj >> (16 * s4)) & 0xffffu;
+              if ((int64_t)pos < L.cap) ovf[pos] = OvfEntry{t00 + (uint32_t)((s4 >> 1) * L.gx + (s4 & 1)), r, d.key};
+              if (r >= kTileCountLimit) ((SavedHeader*)(p_saved[lv] + L.o_hdr))->count_saturated = 1u;    // (before the field can wrap)
+              ++pos;
+            }
+          sp &= ~(15u << (4 * jj));
+        }
+        m = __ballot(sp != 0u);
       }
     };
     unsigned long long old4[4] = {0ull, 0ull, 0ull, 0ull};
-    int tx4[4] = {0, 0, 0, 0}, ty4[4] = {0, 0, 0, 0};
-    uint32_t pr4[4] = {0u, 0u, 0u, 0u};
+    uint32_t geo4[4] = {0u, 0u, 0u, 0u};
+    int owner4[4];                                               // (-1: no operation)
+    auto issue_round = [&](uint32_t it0, uint32_t tot_r) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      if (jj < nops) old4[jj] = issue(v, o.x0, o.y0, o.x1, o.y1, jj, tx4[jj], ty4[jj], pr4[jj]);
+      for (int jj = 0; jj < 4; ++jj) {
+        const uint32_t item = it0 + (uint32_t)jj * 256u + (uint32_t)tid;
+        owner4[jj] = -1;
+        if (item < tot_r) {
+          int lo = 0, hi = 256;                      // owner = last thread whose prefix is <= item
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (op_ex[mid] <= item) lo = mid + 1; else hi = mid; }
+          owner4[jj] = lo - 1;
+          const uint4 r = op_rect[lo - 1];
+          geo4[jj] = op_geom(r.x, r.y, 4 + (int)(item - op_ex[lo - 1]));
+          old4[jj] = issue((int)r.z, geo4[jj]);
+        }
+      }
+    };
+    auto consume_round = [&]() { consume4(old4, geo4, owner4); };
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      owner4[jj] = jj < (int)nops ? tid : -1;
+      if (jj < (int)nops) { geo4[jj] = op_geom(my_rx, my_ry, jj); old4[jj] = issue(v, geo4[jj]); }
+    }
     uint32_t tot_t, tot_v;
     const uint32_t ex_t = carry_t + block256_exclusive_scan(cnt, red, tot_t);
     const uint32_t ex_v = carry_v + block256_exclusive_scan(vis, red, tot_v);
@@ -557,42 +636,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         if (u > v && vstart[u] == f + 1) { vbase_t[u] = ex_t + cnt; vbase_v[u] = ex_v + vis; }
     }
     __syncthreads();
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) consume(jj < nops, v, old4[jj], tx4[jj], ty4[jj], pr4[jj], key);
-    // operations beyond the first four, dealt out evenly: item -> (owner thread, k) by a search in the owners' prefix sums
-    const int rem = nops > 4 ? nops - 4 : 0;
-    if (__syncthreads_or(rem > 0)) {
-      uint32_t tot_r;
-      const uint32_t ex_r = block256_exclusive_scan((uint32_t)rem, red, tot_r);
-      op_ex[tid] = ex_r;
-      op_rect[tid] = make_uint4((uint32_t)o.x0 | ((uint32_t)o.y0 << 16), (uint32_t)o.x1 | ((uint32_t)o.y1 << 16), (uint32_t)v, (uint32_t)i);
-      op_depth[tid] = __float_as_uint(o.depth);
-      __syncthreads();
-#pragma unroll 1
-      for (uint32_t it0 = 0; it0 < tot_r; it0 += 4 * 256) {
-        int view4[4] = {0, 0, 0, 0};
-        uint64_t key4[4] = {0ull, 0ull, 0ull, 0ull};
-        bool on4[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const uint32_t item = it0 + (uint32_t)jj * 256u + (uint32_t)tid;
-          on4[jj] = item < tot_r;
-          if (on4[jj]) {
-            int lo = 0, hi = 256;                    // owner = last thread whose prefix is <= item
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (op_ex[mid] <= item) lo = mid + 1; else hi = mid; }
-            const int owner = lo - 1;
-            const uint4 r = op_rect[owner];
-            view4[jj] = (int)r.z;
-            key4[jj] = ((uint64_t)op_depth[owner] << 32) | r.w;
-            old4[jj] = issue(view4[jj], (int)(r.x & 0xffffu), (int)(r.x >> 16), (int)(r.y & 0xffffu), (int)(r.y >> 16),
-                             4 + (int)(item - op_ex[owner]), tx4[jj], ty4[jj], pr4[jj]);
-          }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) consume(on4[jj], view4[jj], old4[jj], tx4[jj], ty4[jj], pr4[jj], key4[jj]);
-      }
-      __syncthreads();                               // (the next chunk rewrites the owner tables)
-    }
     if (o.visible) {
       const uint32_t k = ex_v - vbase_v[v];
       // touched, in-segment prefix (abs_offset() adds the segment base), list slot (relative; scatter_kernel makes it
@@ -600,6 +643,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       ((uint4*)((GRec*)(saved + L.o_grec) + i))[3] = make_uint4(cnt, ex_t - vbase_t[v], k, o.clamped);
       ((uint32_t*)(saved + L.o_seg_list))[seg0 + k] = (uint32_t)i;
     }
+    consume_round();
+    const uint32_t rem = nops > 4u ? nops - 4u : 0u;
+    if (__syncthreads_or(rem > 0u)) {
+      uint32_t tot_r;
+      op_ex[tid] = block256_exclusive_scan(rem, red, tot_r);
+      __syncthreads();
+#pragma unroll 1
+      for (uint32_t it0 = 0; it0 < tot_r; it0 += 4u * 256u) {
+        issue_round(it0, tot_r);
+        consume_round();
+      }
+    }
+    __syncthreads();                                 // (the next chunk rewrites the owner tables)
     carry_t += tot_t;
     carry_v += tot_v;
   }
