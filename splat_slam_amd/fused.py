@@ -167,6 +167,7 @@ class FusedMappingLoop(MappingLoop):
         self._acc_clean = True
         self._scratch = None
         self._since_check = 0
+        self._pair_hint = {}       # camera uid -> (measured pair count, map size it was measured at)
         self._exp = None
         self._exp_rows = []
         self._cap = 0
@@ -188,6 +189,7 @@ class FusedMappingLoop(MappingLoop):
         super().reset()
         self._views, self._acc, self._acc_key, self._acc_ids, self._acc_clean = {}, None, None, None, True
         self._exp, self._exp_rows, self._cap, self._stale_iso = None, [], 0, 0.0
+        self._pair_hint = {}
         self._plan_key = self._plan_obj = None
 
     # ------------------------------------------------------------------------------------------------ state
@@ -383,6 +385,25 @@ class FusedMappingLoop(MappingLoop):
         return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), cap,
                                 int(vb.clean), 0)
 
+    def _estimate_pairs(self, cam, vb):
+        """Pair count of a camera whose buffers are new.  A synchronous probe forward per camera and map size cost a converged
+        session ~120 host-synchronised renders per keyframe (the 2 random views of every iteration are mostly cameras not yet
+        seen at this size), so the count is carried over instead: the camera's last MEASURED count, scaled by the growth of
+        the map; a camera never measured takes the largest estimate of the others (neighbouring views of one room); only
+        with nothing to go by is it probed.  Capacity is twice the estimate; an estimate that still falls short costs that
+        view one iteration (a truncated view contributes nothing, sgr_aux.hip) until the early check below corrects it."""
+        N = self.gaussians._xyz.shape[0]
+        scaled = lambda h: int(h[0] * max(1.0, N / max(1, h[1])) * 1.25) + 1024
+        h = self._pair_hint.get(cam.uid)
+        if h is not None:
+            vb.pairs = scaled(h)
+        elif self._pair_hint:
+            vb.pairs = int(1.5 * max(scaled(x) for x in self._pair_hint.values()))
+        else:
+            self._probe(cam, vb)
+            return
+        self._since_check = max(self._since_check, self.check_every - 2)      # measure soon
+
     def _probe(self, cam, vb):
         """One synchronous forward to learn this camera's pair count at the current map size."""
         gm = self.gaussians
@@ -405,6 +426,7 @@ class FusedMappingLoop(MappingLoop):
             nat.check(rc, "sgr_forward")
             break
         vb.pairs = int(R.value)
+        self._pair_hint[cam.uid] = (vb.pairs, N)
         vb.clean = True
         if vb.pairs > self.max_pairs:
             gm = self.gaussians
@@ -468,10 +490,10 @@ class FusedMappingLoop(MappingLoop):
     def _views_array(self, cams, initialization, images=True):
         n = len(cams)
         need = self._cap
-        for c in cams:                                # cameras new at this map size: learn their pair count once
+        for c in cams:
             vb = self._view(c)
-            if vb.pairs < 0:
-                self._probe(c, vb)
+            if vb.pairs < 0:                          # buffers are new (camera, or every camera after the map changed size)
+                self._estimate_pairs(c, vb)
             need = max(need, 1 << 16, 2 * vb.pairs)
         if need != self._cap:                         # ONE capacity for all cameras: batched launches share a layout
             self._cap = need
@@ -706,6 +728,22 @@ class FusedMappingLoop(MappingLoop):
         self._ensure_state()
         self._step([viewpoint], adam=False, forward_only=True)
         vb = self._views[viewpoint.uid]
+        if viewpoint.uid not in self._pair_hint or self._pair_hint[viewpoint.uid][1] != self.gaussians._xyz.shape[0]:
+            # the caller reads the images right away (keyframe selection): one read-back more measures this camera's pair count,
+            # so that the mapping iterations that follow size their workspaces from a measurement, not an estimate
+            R, ov = C.c_int64(0), C.c_int32(0)
+            nat.check(self.lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), self._stream()), "sgr_query")
+            if ov.value:                              # the estimate was short: grow and render again
+                vb.pairs = int(R.value)
+                self._pair_hint[viewpoint.uid] = (vb.pairs, self.gaussians._xyz.shape[0])
+                self._cap = max(self._cap, 2 * vb.pairs)
+                self._views_dirty()
+                self.overflow_events += 1
+                self._step([viewpoint], adam=False, forward_only=True)
+                vb = self._views[viewpoint.uid]
+            else:
+                vb.pairs = int(R.value)
+                self._pair_hint[viewpoint.uid] = (vb.pairs, self.gaussians._xyz.shape[0])
         return {"render": vb.color, "depth": vb.depth, "opacity": vb.opacity, "radii": vb.radii, "n_touched": vb.n_touched,
                 "visibility_filter": vb.radii > 0}
 
@@ -783,6 +821,7 @@ class FusedMappingLoop(MappingLoop):
             if ov.value == 2:
                 raise RuntimeError(f"camera {uid}: more than 65280 splats on one 8x8 tile -- the map has degenerated")
             vb.pairs = int(R.value)
+            self._pair_hint[uid] = (vb.pairs, self.gaussians._xyz.shape[0])
             if vb.pairs > self.max_pairs:
                 raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
                                    "the map has degenerated")
