@@ -252,7 +252,7 @@ def test_config1_session_script_smoke(tmp_path, monkeypatch, capsys):
     spec.loader.exec_module(mod)
     out = tmp_path / "s.json"
     monkeypatch.setattr(sys, "argv", ["x", "--keyframes", "9", "--camera", "tiny", "--refine", "60", "--oracle-views", "2",
-                                      "--world", "30000", "--moved-every", "3", "--out", str(out)])
+                                      "--world", "30000", "--moved-every", "3", "--warmup-frames", "4", "--out", str(out)])
     from splat_slam_amd.gaussian_model import GaussianModel
     saved = {n: getattr(GaussianModel, n) for n in ("densify_and_prune", "extend_from_pcd_seq", "reset_opacity", "reset_opacity_nonvisible")}
     try:
