@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
     }
   } else if (blockIdx.x == 1) {
     const uint32_t* bt = (const uint32_t*)(saved + L.o_block_touched);
-    (void)block1024_scan([&](int i) { return bt[i]; }, (uint32_t*)(saved + L.o_block_base_t), L.nseg, red);
+    const uint32_t slots = block1024_scan([&](int i) { return bt[i]; }, (uint32_t*)(saved + L.o_block_base_t), L.nseg, red);
+    if (threadIdx.x == 0) hdr->slot_total = slots;
   } else {
     const uint32_t* bv = (const uint32_t*)(saved + L.o_block_vis);
     uint32_t V = block1024_scan([&](int i) { return bv[i]; }, (uint32_t*)(saved + L.o_block_base_v), L.nseg, red);
@@ -123,7 +124,15 @@ __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
     ((GRec*)(saved + L.o_grec) + i)->vis_pos = vp;
     ((uint32_t*)(saved + L.o_vis_list))[vp] = i;
   }
-  const SavedHeader* hdr = (const SavedHeader*)(saved + L.o_hdr);
+  SavedHeader* hdr = (SavedHeader*)(saved + L.o_hdr);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // K2's two scans are folded here (they ran in different blocks): what a caller sizes the workspace by is the larger of
+    // the pairs binned and the partial slots reserved (bins the exact footprint test dropped keep their slot)
+    const uint32_t binned = hdr->num_rendered, slots = hdr->slot_total;
+    hdr->num_binned = binned;
+    if (slots > binned) hdr->num_rendered = slots;
+    if ((int64_t)slots > L.cap && hdr->overflow == 0u) hdr->overflow = 1u;
+  }
   if (hdr->num_overfull == 0) return;
   const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
   uint64_t* __restrict__ entries = (uint64_t*)(tab.scratch[v] + L.o_entries);

@@ -46,6 +46,46 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
                                        -0.5900435899266435f};
 
 // ---- header at the start of the saved block
+// ---- exact footprint test of a splat against ONE 8x8 bin -----------------------------------------------------------------
+// A pixel can only pass alpha >= 1/255 where q = A dx^2 + 2 B dx dy + C dy^2 <= tau = 2 ln(255 opacity): the bin is unreachable
+// if the minimum of q over the bin's 8x8 pixel centres' bounding box exceeds tau.  K1 drops such bins from the rectangle's
+// operations (no atomic, no key, no compositing work: the axis-aligned box of the level set keeps ~15-25 % bins too many for a
+// rotated or simply round splat of a converged map); the backward skips the same bins' partial slots, which nobody wrote.
+// The two sides need NOT decide bit-identically: K1 drops a bin only beyond kFootDrop * thr, the backward skips already
+// beyond thr, and everything in between was binned, composited with alpha < 1/255 everywhere, i.e. wrote exact zeros.
+struct Footprint { float px, py, A, B, C, invA, invC, thr; };      // thr < 0: test disabled (rounding could decide), keep every bin
+constexpr float kFootDrop = 1.002f;
+// the test pays for itself on rectangles of >= 6 bins with both sides >= 2 (a one-bin-wide strip has no bin to drop: the level
+// set touches both ends of its box); a fresh map's splats (3 bins on average) skip it
+__host__ __device__ inline bool footprint_worthwhile(int w, int h) { return w >= 2 && h >= 2 && w * h >= 6; }
+__device__ __forceinline__ Footprint make_footprint(float px, float py, float A, float B, float C, float opac, float err_limit) {
+  Footprint f{px, py, A, B, C, 0.f, 0.f, -1.f};
+  const float detc = A * C - B * B, o255 = 255.f * opac;
+  if (o255 >= 1.f && A > 0.f && C > 0.f && detc > 0.f) {
+    const float tau = 2.f * __logf(o255) * 1.001f + 0.02f;
+    const float ex = __builtin_amdgcn_sqrtf(tau * C / detc), ey = __builtin_amdgcn_sqrtf(tau * A / detc);
+    const float ext = fmaxf(ex, ey) + 2.f * kTile;
+    const float err = 4e-7f * (A + C + 2.f * fabsf(B)) * ext * ext;      // fp32 rounding of q near the boundary
+    if (err < err_limit && isfinite(ex) && isfinite(ey)) { f.thr = tau; f.invA = 1.f / A; f.invC = 1.f / C; }
+  }
+  return f;
+}
+// minimum of q over the box [xl, xh] x [yl, yh] of offsets from the centre (0 when the centre is inside)
+__device__ __forceinline__ float footprint_qmin(const Footprint& f, int tx, int ty) {
+  const float xl = (float)(tx * kTile) - f.px, xh = xl + (float)(kTile - 1);
+  const float yl = (float)(ty * kTile) - f.py, yh = yl + (float)(kTile - 1);
+  if (xl <= 0.f && xh >= 0.f && yl <= 0.f && yh >= 0.f) return 0.f;
+  auto edge_x = [&](float c) {      // dx = c, dy free in [yl, yh]
+    const float d = fminf(yh, fmaxf(yl, -f.B * c * f.invC));
+    return f.A * c * c + 2.f * f.B * c * d + f.C * d * d;
+  };
+  auto edge_y = [&](float c) {      // dy = c, dx free in [xl, xh]
+    const float d = fminf(xh, fmaxf(xl, -f.B * c * f.invA));
+    return f.A * d * d + 2.f * f.B * d * c + f.C * c * c;
+  };
+  return fminf(fminf(edge_x(xl), edge_x(xh)), fminf(edge_y(yl), edge_y(yh)));
+}
+
 struct SavedHeader {
   uint32_t num_rendered;   // R: total (tile, Gaussian) pairs demanded (may exceed capacity)
   uint32_t overflow;       // 1: R > capacity (pairs were dropped); 2: a 16-bit tile counter saturated (> kTileCountLimit splats on one tile)
@@ -55,7 +95,10 @@ struct SavedHeader {
   uint32_t ovf_cursor;     // K1's append cursor into the overflow list (pairs whose rank in their tile is >= kBucket); K2 resets it
   uint32_t ovf_count;      // ... its final value for this forward (written by K2, read by K3)
   uint32_t count_saturated;  // K1: some pair drew a rank >= kTileCountLimit (sticky until K2 folds it into `overflow` and clears it)
-  uint32_t pad[8];
+  uint32_t slot_total;     // partial slots the view's Gaussians reserve (sum of their bin-rectangle areas, >= pairs binned: bins of the
+                           // rectangle that the exact footprint test dropped keep their slot); K2 writes it, K3 folds it into num_rendered
+  uint32_t num_binned;     // pairs actually binned (K3; num_rendered then holds the capacity-relevant max(pairs binned, slot_total))
+  uint32_t pad[6];
 };
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint32_t vis_bits[kSeg];            // per Gaussian of the segment: bit v = view v of the batch sees it
   __shared__ uint32_t op_ex[kSeg];               // load-balanced counting atomics: per owner thread, prefix of its remaining operations,
   __shared__ uint4 op_rect[kSeg];                // ... its rectangle (x0 | x1 << 16, y0 | y1 << 16), view, Gaussian
-  __shared__ uint32_t op_depth[kSeg];            // ... and the depth half of its key
+  __shared__ uint32_t op_depth[kSeg];            // ... the depth half of its key
+  __shared__ float4 op_foot[kSeg][2];            // ... and its footprint (exact bin test): px py A B | C 1/A 1/C thr
   __shared__ float seg_box[4][8];                // per wave: min xyz, max xyz, max trS of its 64 Gaussians
   __shared__ uint32_t seg_views;                 // bit v = some Gaussian of this segment MAY be visible in view v
   const int N = L.N;
@@ -499,10 +500,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     const uint32_t nops = cnt > 0u ? (uint32_t)((((o.x1 - 1) >> 1) - (o.x0 >> 1) + 1) * (((o.y1 - 1) >> 1) - (o.y0 >> 1) + 1)) : 0u;
     op_rect[tid] = make_uint4(my_rx, my_ry, (uint32_t)v, (uint32_t)i);
     op_depth[tid] = __float_as_uint(o.depth);
+    // the rectangle is the axis-aligned box of the alpha >= 1/255 level set; the bins of it that the level set itself misses are
+    // dropped operation by operation (sgr_common.h: footprint test) -- no atomic, no key, no compositing work for them
+    Footprint my_foot{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1.f};
+    if (o.visible && footprint_worthwhile(o.x1 - o.x0, o.y1 - o.y0)) my_foot = make_footprint(o.px, o.py, o.A, o.B, o.C, o.opac, 0.005f);
+    op_foot[tid][0] = make_float4(my_foot.px, my_foot.py, my_foot.A, my_foot.B);
+    op_foot[tid][1] = make_float4(my_foot.C, my_foot.invA, my_foot.invC, my_foot.thr);
     // operation k of the rectangle rx = x0 | x1 << 16, ry = y0 | y1 << 16: its 2x2 block (bx, by = the block's first tile, both
     // even) and which of its four tiles the rectangle covers (bit s = (y & 1) * 2 + (x & 1)), packed bx | by << 14 | cover << 28
     // so that ONE register per operation stays live across the atomic's round trip
-    auto op_geom = [](uint32_t rx, uint32_t ry, int k) -> uint32_t {
+    auto op_geom = [](uint32_t rx, uint32_t ry, int k, const Footprint& foot) -> uint32_t {
       const int x0 = (int)(rx & 0xffffu), x1 = (int)(rx >> 16), y0 = (int)(ry & 0xffffu), y1 = (int)(ry >> 16);
       const int per_row = ((x1 - 1) >> 1) - (x0 >> 1) + 1;
       // k / per_row for k < 2^20: float quotient of (k + 0.5), exact after one correction step
@@ -512,12 +519,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       if (rem >= per_row) { ++q; rem -= per_row; }
       const int bx = ((x0 >> 1) + rem) * 2, by = ((y0 >> 1) + q) * 2;
       const bool c0 = bx >= x0, c1 = bx + 1 < x1, r0 = by >= y0, r1 = by + 1 < y1;
-      const uint32_t cover = (uint32_t)(r0 && c0) | ((uint32_t)(r0 && c1) << 1) | ((uint32_t)(r1 && c0) << 2) | ((uint32_t)(r1 && c1) << 3);
+      uint32_t cover = (uint32_t)(r0 && c0) | ((uint32_t)(r0 && c1) << 1) | ((uint32_t)(r1 && c0) << 2) | ((uint32_t)(r1 && c1) << 3);
+      if (foot.thr >= 0.f) {
+        const float drop = foot.thr * kFootDrop;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          if (((cover >> s4) & 1u) && footprint_qmin(foot, bx + (s4 & 1), by + (s4 >> 1)) > drop) cover &= ~(1u << s4);
+      }
       return (uint32_t)bx | ((uint32_t)by << 14) | (cover << 28);
     };
     // ... and its counting atomic: the old word holds the rank of this splat in each covered tile
     auto issue = [&](int view, uint32_t geo) -> unsigned long long {
       const uint32_t cover = geo >> 28;
+      if (cover == 0u) return 0ull;                  // (every bin of this block dropped)
       const unsigned long long inc = (unsigned long long)(cover & 1u) | ((unsigned long long)((cover >> 1) & 1u) << 16) |
                                      ((unsigned long long)((cover >> 2) & 1u) << 32) | ((unsigned long long)((cover >> 3) & 1u) << 48);
       unsigned long long* c = (unsigned long long*)(p_saved[view] + L.o_tile_count) +
@@ -615,7 +629,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
           while (lo < hi) { const int mid = (lo + hi) >> 1; if (op_ex[mid] <= item) lo = mid + 1; else hi = mid; }
           owner4[jj] = lo - 1;
           const uint4 r = op_rect[lo - 1];
-          geo4[jj] = op_geom(r.x, r.y, 4 + (int)(item - op_ex[lo - 1]));
+          const float4 f0 = op_foot[lo - 1][0], f1 = op_foot[lo - 1][1];
+          geo4[jj] = op_geom(r.x, r.y, 4 + (int)(item - op_ex[lo - 1]), Footprint{f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w});
           old4[jj] = issue((int)r.z, geo4[jj]);
         }
       }
@@ -624,7 +639,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       owner4[jj] = jj < (int)nops ? tid : -1;
-      if (jj < (int)nops) { geo4[jj] = op_geom(my_rx, my_ry, jj); old4[jj] = issue(v, geo4[jj]); }
+      if (jj < (int)nops) { geo4[jj] = op_geom(my_rx, my_ry, jj, my_foot); old4[jj] = issue(v, geo4[jj]); }
     }
     uint32_t tot_t, tot_v;
     const uint32_t ex_t = carry_t + block256_exclusive_scan(cnt, red, tot_t);
@@ -910,7 +925,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   const bool have = t < V;
   const int i = have ? (int)((const uint32_t*)(saved + L.o_vis_list))[t] : 0;
   uint4 q3 = make_uint4(0u, 0u, 0u, 0u);
-  if (have) q3 = ((const uint4*)(grec_of(saved, L) + i))[3];
+  float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+  if (have) {
+    const float4* rec = (const float4*)(grec_of(saved, L) + i);      // one 64-byte line
+    g0 = rec[0]; g1 = rec[1]; q3 = ((const uint4*)rec)[3];
+  }
+  // bins of the rectangle that K1's exact footprint test dropped were never composited: nobody wrote their partial slot.  The
+  // same test (a little more eager, sgr_common.h) says which slots to leave out of the sum.
+  const uint32_t my_r01 = __float_as_uint(g0.z), my_r23 = __float_as_uint(g0.w);
+  const bool tested = have && footprint_worthwhile((int)(my_r23 & 0xffffu) - (int)(my_r01 & 0xffffu), (int)(my_r23 >> 16) - (int)(my_r01 >> 16));
+  const Footprint foot = tested ? make_footprint(g0.x, g0.y, g1.x, g1.y, g1.z, g1.w, 0.006f)
+                                : Footprint{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1.f};
+  // slot k of a run <-> bin (x0 + k % w, y0 + k / w) of the rectangle (r01 = x0 | y0 << 16, r23 = x1 | y1 << 16)
+  auto slot_unwritten = [](const Footprint& f, uint32_t r01, uint32_t r23, uint32_t k) -> bool {
+    if (!(f.thr >= 0.f)) return false;
+    const int x0 = (int)(r01 & 0xffffu), y0 = (int)(r01 >> 16), w = (int)(r23 & 0xffffu) - x0;
+    int q = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)w));       // k / w, exact after one correction (k < 2^20)
+    int rem = (int)k - q * w;
+    if (rem < 0) { --q; rem += w; }
+    if (rem >= w) { ++q; rem -= w; }
+    return footprint_qmin(f, x0 + rem, y0 + q) > f.thr;
+  };
   // Sum of this Gaussian's per-tile partials (48 B per covered tile, one contiguous run per Gaussian).  A converged map has
   // splats that cover tens to hundreds of tiles: a lane walking its own run alone makes the wave wait for its longest run
   // and fetches 48 scattered bytes per lane and step.  Instead every group of 8 lanes sums ONE run together (lane l takes
@@ -929,7 +964,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const uint64_t e = (uint64_t)my_off + k0 + (uint32_t)u;
-          const bool in = k0 + (uint32_t)u < my_cnt && (int64_t)e < L.cap;
+          const bool in = k0 + (uint32_t)u < my_cnt && (int64_t)e < L.cap && !slot_unwritten(foot, my_r01, my_r23, k0 + (uint32_t)u);
 #pragma unroll
           for (int w = 0; w < 3; ++w) ld[3 * u + w] = in ? partials[e * 3 + w] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -945,6 +980,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     for (int r = 0; r < 8; ++r) {
       const int src = r * 8 + grp;                    // the lane whose Gaussian this group sums in round r
       const uint32_t o = (uint32_t)__shfl((int)my_off, src), c = (uint32_t)__shfl((int)my_cnt, src);
+      const uint32_t s01 = (uint32_t)__shfl((int)my_r01, src), s23 = (uint32_t)__shfl((int)my_r23, src);
+      const Footprint sf{__shfl(foot.px, src), __shfl(foot.py, src), __shfl(foot.A, src), __shfl(foot.B, src),
+                         __shfl(foot.C, src), __shfl(foot.invA, src), __shfl(foot.invC, src), __shfl(foot.thr, src)};
       float part[10];
 #pragma unroll
       for (int j = 0; j < 10; ++j) part[j] = 0.f;
@@ -956,7 +994,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         for (int u = 0; u < 3; ++u) {
           const uint32_t k = k0 + 8u * (uint32_t)u;
           const uint64_t e = (uint64_t)o + k;
-          const bool in = k < c && (int64_t)e < L.cap;
+          const bool in = k < c && (int64_t)e < L.cap && !slot_unwritten(sf, s01, s23, k);
 #pragma unroll
           for (int w = 0; w < 3; ++w) ld[3 * u + w] = in ? partials[e * 3 + w] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
