@@ -162,20 +162,9 @@ static void tab_set_view(ViewTab& t, int v, const SgrSettings* s, const SgrOutpu
 }
 
 // forward of a batch that shares N, H, W, capacity and the view-independent settings
-// K1 comes in two builds: with the exact per-bin footprint test (converged maps: splats of tens of bins, a fifth of which the
-// test drops -- 8 % of the whole iteration) and without (fresh maps: splats of ~3 bins, nothing to drop, and the test's
-// registers and table cost K1 5 %).  Chosen from the expected mean list length like the blend builds; the choice travels in
-// the saved header (foot_mode) so that a backward issued by a later call skips exactly what THIS forward dropped.
-static bool footprint_build(const LOff& d) {
-  const int64_t mean_len = d.mean_hint > 0 ? 2 * (int64_t)d.mean_hint : d.cap / (2 * (int64_t)(d.ntiles > 0 ? d.ntiles : 1));
-  return mean_len > 32;
-}
-
 static int forward_batch(const ViewTab& tab, int nviews, const Layout& L, const Common& cm, const SgrInputs& in, hipStream_t st,
-                         bool counters_clean, int mean_hint) {
+                         bool counters_clean = false) {
   LOff d = L.dev();
-  d.mean_hint = mean_hint;
-  d.foot = footprint_build(d) ? 1 : 0;
   // header + per-tile pair counters; tile_scan re-zeroes the counters after reading them, so only blocks that never
   // went through a forward (or the caller does not vouch for) need this launch
   if (!counters_clean) launch_zero_heads(tab, nviews, d, L.zero_bytes, st);
@@ -209,7 +198,7 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
   ViewTab tab = {};
   tab_set_view(tab, 0, s, out, ws);
   Common cm = make_common(s);
-  if (int rc = forward_batch(tab, 1, L, cm, *in, st, ws->counters_clean != 0, ws->mean_list_hint)) return rc;
+  if (int rc = forward_batch(tab, 1, L, cm, *in, st, ws->counters_clean != 0)) return rc;
   if (num_rendered_host) {
     uint32_t h2[2] = {0u, 0u};        // num_rendered, overflow
     HIP_TRY(hipMemcpyAsync(h2, (char*)ws->saved + L.o_hdr, 8, hipMemcpyDeviceToHost, st));
@@ -334,7 +323,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
         lt.parts[v] = m.loss_scratch;
       }
     }
-    if (int rc = forward_batch(tab, nv, L, cm, *in, st, all_clean, f.ws.mean_list_hint)) return rc;
+    if (int rc = forward_batch(tab, nv, L, cm, *in, st, all_clean)) return rc;
     if (forward_only) {
       launch_blend_fwd(tab, nv, d, f.settings.bg, nullptr, nullptr, st);
       continue;

@@ -73,7 +73,6 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
       uint32_t tot = 0;
       for (int wv = 0; wv < 16; ++wv) tot += red[wv];
       hdr->num_overfull = tot;
-      hdr->foot_mode = (uint32_t)L.foot;
       hdr->ovf_count = hdr->ovf_cursor;          // K1 is done appending; leave the cursor clean for the next forward
       hdr->ovf_cursor = 0u;
       hdr->num_rendered = R;

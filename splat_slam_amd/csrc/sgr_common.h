@@ -98,8 +98,7 @@ struct SavedHeader {
   uint32_t slot_total;     // partial slots the view's Gaussians reserve (sum of their bin-rectangle areas, >= pairs binned: bins of the
                            // rectangle that the exact footprint test dropped keep their slot); K2 writes it, K3 folds it into num_rendered
   uint32_t num_binned;     // pairs actually binned (K3; num_rendered then holds the capacity-relevant max(pairs binned, slot_total))
-  uint32_t foot_mode;      // != 0: this forward ran K1's exact footprint test, the backward has to skip the dropped bins' slots
-  uint32_t pad[5];
+  uint32_t pad[6];
 };
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -124,7 +123,7 @@ struct ViewTab {
 };
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {
-  int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg, mean_hint, foot;
+  int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg, mean_hint;
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
@@ -226,7 +225,7 @@ struct Layout {
   }
   __host__ LOff dev() const {
     LOff d;
-    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags(); d.mean_hint = 0; d.foot = 0;
+    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags(); d.mean_hint = 0;
     d.cap = cap;
     d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_grec = o_grec;
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;

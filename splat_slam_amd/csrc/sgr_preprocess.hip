@@ -259,7 +259,6 @@ __device__ __forceinline__ bool maybe_visible(const float p[3], float trS, int H
 //            pairs (-> partial-slot offsets, finished by tile_scan_kernel) and its slot in the (view, segment) visible
 //            list seg_list[seg*256 + k]; scatter_kernel later concatenates those lists.
 // Everything is fixed-order: results are bitwise reproducible.
-template <bool FOOT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) preprocess_fwd_kernel(
     ViewTab tab, int nviews, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
@@ -279,7 +278,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint32_t op_ex[kSeg];               // load-balanced counting atomics: per owner thread, prefix of its remaining operations,
   __shared__ uint4 op_rect[kSeg];                // ... its rectangle (x0 | x1 << 16, y0 | y1 << 16), view, Gaussian
   __shared__ uint32_t op_depth[kSeg];            // ... the depth half of its key
-  __shared__ float4 op_foot[FOOT ? kSeg : 1][2]; // ... and its footprint (exact bin test): px py A B | C 1/A 1/C thr
+  __shared__ float4 op_foot[kSeg][2];            // ... and its footprint (exact bin test): px py A B | C 1/A 1/C thr
   __shared__ float seg_box[4][8];                // per wave: min xyz, max xyz, max trS of its 64 Gaussians
   __shared__ uint32_t seg_views;                 // bit v = some Gaussian of this segment MAY be visible in view v
   const int N = L.N;
@@ -504,11 +503,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     // the rectangle is the axis-aligned box of the alpha >= 1/255 level set; the bins of it that the level set itself misses are
     // dropped operation by operation (sgr_common.h: footprint test) -- no atomic, no key, no compositing work for them
     Footprint my_foot{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1.f};
-    if constexpr (FOOT) {
-      if (o.visible && footprint_worthwhile(o.x1 - o.x0, o.y1 - o.y0)) my_foot = make_footprint(o.px, o.py, o.A, o.B, o.C, o.opac, 0.005f);
-      op_foot[tid][0] = make_float4(my_foot.px, my_foot.py, my_foot.A, my_foot.B);
-      op_foot[tid][1] = make_float4(my_foot.C, my_foot.invA, my_foot.invC, my_foot.thr);
-    }
+    if (o.visible && footprint_worthwhile(o.x1 - o.x0, o.y1 - o.y0)) my_foot = make_footprint(o.px, o.py, o.A, o.B, o.C, o.opac, 0.005f);
+    op_foot[tid][0] = make_float4(my_foot.px, my_foot.py, my_foot.A, my_foot.B);
+    op_foot[tid][1] = make_float4(my_foot.C, my_foot.invA, my_foot.invC, my_foot.thr);
     // operation k of the rectangle rx = x0 | x1 << 16, ry = y0 | y1 << 16: its 2x2 block (bx, by = the block's first tile, both
     // even) and which of its four tiles the rectangle covers (bit s = (y & 1) * 2 + (x & 1)), packed bx | by << 14 | cover << 28
     // so that ONE register per operation stays live across the atomic's round trip
@@ -523,7 +520,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       const int bx = ((x0 >> 1) + rem) * 2, by = ((y0 >> 1) + q) * 2;
       const bool c0 = bx >= x0, c1 = bx + 1 < x1, r0 = by >= y0, r1 = by + 1 < y1;
       uint32_t cover = (uint32_t)(r0 && c0) | ((uint32_t)(r0 && c1) << 1) | ((uint32_t)(r1 && c0) << 2) | ((uint32_t)(r1 && c1) << 3);
-      if (FOOT && foot.thr >= 0.f) {
+      if (foot.thr >= 0.f) {
         const float drop = foot.thr * kFootDrop;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
@@ -632,12 +629,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
           while (lo < hi) { const int mid = (lo + hi) >> 1; if (op_ex[mid] <= item) lo = mid + 1; else hi = mid; }
           owner4[jj] = lo - 1;
           const uint4 r = op_rect[lo - 1];
-          Footprint fo{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1.f};
-          if constexpr (FOOT) {
-            const float4 f0 = op_foot[lo - 1][0], f1 = op_foot[lo - 1][1];
-            fo = Footprint{f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-          }
-          geo4[jj] = op_geom(r.x, r.y, 4 + (int)(item - op_ex[lo - 1]), fo);
+          const float4 f0 = op_foot[lo - 1][0], f1 = op_foot[lo - 1][1];
+          geo4[jj] = op_geom(r.x, r.y, 4 + (int)(item - op_ex[lo - 1]), Footprint{f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w});
           old4[jj] = issue((int)r.z, geo4[jj]);
         }
       }
@@ -940,7 +933,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   // bins of the rectangle that K1's exact footprint test dropped were never composited: nobody wrote their partial slot.  The
   // same test (a little more eager, sgr_common.h) says which slots to leave out of the sum.
   const uint32_t my_r01 = __float_as_uint(g0.z), my_r23 = __float_as_uint(g0.w);
-  const bool tested = have && ((const SavedHeader*)(saved + L.o_hdr))->foot_mode != 0u && footprint_worthwhile((int)(my_r23 & 0xffffu) - (int)(my_r01 & 0xffffu), (int)(my_r23 >> 16) - (int)(my_r01 >> 16));
+  const bool tested = have && footprint_worthwhile((int)(my_r23 & 0xffffu) - (int)(my_r01 & 0xffffu), (int)(my_r23 >> 16) - (int)(my_r01 >> 16));
   const Footprint foot = tested ? make_footprint(g0.x, g0.y, g1.x, g1.y, g1.z, g1.w, 0.006f)
                                 : Footprint{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1.f};
   // slot k of a run <-> bin (x0 + k % w, y0 + k / w) of the rectangle (r01 = x0 | y0 << 16, r23 = x1 | y1 << 16)
@@ -1161,12 +1154,8 @@ __global__ void __launch_bounds__(384) tau_reduce_kernel(ViewTab tab, LOff L) {
 void launch_preprocess_fwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_FWD, st);
-  if (L.foot)
-    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(L.nseg), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
-                       in.shs, in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp);
-  else
-    hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(L.nseg), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
-                       in.shs, in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp);
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.nseg), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
+                     in.shs, in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp);
 }
 
 void launch_preprocess_bwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in,
