@@ -34,7 +34,7 @@ def psnr_vs_oracle(n, camera):
 
 rows = []
 for name, n, cam in CONFIGS:
-    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", str(n), "--camera", cam]
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", str(n), "--camera", cam, "--no-extras"]
     if n > 20000:
         args.append("--no-cpu-baseline")
     out = subprocess.run(args, capture_output=True, text=True).stdout
@@ -42,7 +42,8 @@ for name, n, cam in CONFIGS:
     row = {"config": name, "fwd_ms": d["render_ms"]["forward"], "fwd_bwd_loss_ms": d["render_ms"]["forward_backward_loss"],
            "map_it_per_s": d["map_iterations_per_s"], "kf_per_s": d["value"], "refine_it_per_s": d["refine_iterations_per_s"],
            "hbm_frac_blend_bwd": d["roofline"]["frac"], "valu_frac_blend_bwd": d["roofline"]["valu_frac_at_60flop_per_pair"],
-           "blend_bwd_ms": d["roofline"]["avg_launch_ms"], "work_per_view": d["work_per_view"]}
+           "blend_bwd_ms": d["roofline"]["avg_launch_ms"], "fused_tile_kernel_ms": d["roofline_fused"]["avg_launch_ms"],
+           "ms_per_step": d["ms_per_step"], "work_per_view": d["work_per_view"]}
     if "cpu_baseline" in d:
         row["cpu_oracle"] = d["cpu_baseline"]
     row.update(psnr_vs_oracle(n, cam))
