@@ -932,6 +932,7 @@ class FusedMappingLoop(MappingLoop):
                 self.iteration_count = c0 + n
                 self.gaussians.update_learning_rate(self.iteration_count)
                 self.last_used = list(viewpoint_stack) + [random_viewpoint_stack[k] for k in picks[len(picks) - per:]]
+                gaussian_split = False               # (regular iterations: mapper.py:491 resets the flag every iteration)
                 it += n - 1
                 if it == iters - 1:
                     self.occ_aware_visibility = self._window_visibility(current_window, viewpoint_stack)
@@ -941,6 +942,7 @@ class FusedMappingLoop(MappingLoop):
                     self.check_overflow()
                 continue
             self.iteration_count += 1
+            gaussian_split = False
             self._ensure_state()
             used = list(viewpoint_stack)
             for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2].tolist():
@@ -953,6 +955,7 @@ class FusedMappingLoop(MappingLoop):
                 if self._exp is not None:
                     self._exp.keep_stale([r for r in (self._exp.row_of(c) for c in used) if r is not None])
                 self.occ_aware_visibility = self._window_visibility(current_window, viewpoint_stack)
+                self._count_observations(current_window)
                 self.last_used = used
                 return False
             update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset

@@ -130,6 +130,14 @@ class MappingLoop:
         self.occ_aware_visibility[cur_frame_idx] = (n_touched > 0).long()
         return pkg
 
+    def _count_observations(self, current_window):
+        """mapper.py:503-508: with a full window the prune pass leaves in `n_obs` how many window keyframes see each Gaussian
+        (the mask it then derives from it is dropped, the counts stay in the model)."""
+        if len(current_window) == self.window_size:
+            self.gaussians.n_obs.fill_(0)
+            for vis in self.occ_aware_visibility.values():
+                self.gaussians.n_obs += vis.to(self.gaussians.n_obs.device, self.gaussians.n_obs.dtype)
+
     # ---------------------------------------------------------------------------------- mapper.py:400-568
     def map(self, current_window, prune=False, iters=1):
         if len(current_window) == 0:
@@ -141,6 +149,7 @@ class MappingLoop:
         pose_opt = bool(self.config["mapping"]["BA"]) and not self.config["mapping"]["Training"].get("gt_camera", False)
         gaussian_split = False
         for _ in range(iters):
+            gaussian_split = False                      # (per iteration, mapper.py:491: the LAST iteration decides the result)
             self.iteration_count += 1
             loss_mapping = 0
             vsp_acm, vis_acm, radii_acm, n_touched_acm = [], [], [], []
@@ -172,8 +181,9 @@ class MappingLoop:
                 for idx in range(len(current_window)):
                     self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
                 if prune:
-                    # the reference computes `to_prune` here and drops it (mapper.py:502-520): a pass that only
-                    # refreshes occ_aware_visibility and returns before optimizer.step()/zero_grad()
+                    # the reference computes `to_prune` here and drops it (mapper.py:502-520): a pass that refreshes
+                    # occ_aware_visibility and n_obs and returns before optimizer.step()/zero_grad()
+                    self._count_observations(current_window)
                     return False
                 for idx in range(len(vsp_acm)):
                     self._visible_stats(vsp_acm[idx], vis_acm[idx], radii_acm[idx])
