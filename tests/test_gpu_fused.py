@@ -562,3 +562,44 @@ def test_views_that_overflow_the_pair_capacity_take_no_part_in_the_step():
     assert all(vb.pairs <= f._cap for vb in f._views.values() if vb.clean)
     for n in before:
         assert torch.isfinite(getattr(gm, n)).all(), n
+
+
+def test_exact_footprint_test_drops_bins_and_the_backward_skips_their_slots():
+    """Large rotated splats: a good part of the bins of their rectangles are missed by the alpha >= 1/255 level set and are
+    not binned (pairs binned < partial slots reserved); whatever the backward then sums must not depend on what the
+    dropped bins' slots hold -- poison the partial region and run the same batch again: identical gradients."""
+    from splat_slam_amd import _native as nat
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    intr = syn.INTRINSICS["replica"]
+    params = syn.room_parameters(20000, seed=9, device=DEV)
+    params["scaling"] = params["scaling"] + 2.0
+    params["scaling"][:, 0] += 1.0                       # elongated
+    cams = syn.make_views(params, 3, intr, DEV, seed=9)
+    lib = nat.lib()
+
+    def run(poison):
+        f = _loop(FusedMappingLoop, syn, params, cams, [0, 1, 2])
+        f._ensure_state()
+        f._activate()
+        if poison is not None:
+            f._views_array(cams, False)                 # allocate the workspaces, then fill every scratch block with NaN bits
+            for vb in f._views.values():
+                vb.scratch.view(torch.int32).fill_(poison)
+        f._run_views(cams, stats=True)
+        torch.cuda.synchronize()
+        return f
+
+    f = run(None)
+    vb = f._views[cams[0].uid]
+    ws = nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), f._cap)
+    stats = (C.c_int64 * 4)()
+    nat.check(lib.sgr_query_stats(C.byref(ws), 20000, intr["H"], intr["W"], vb.radii.data_ptr(), stats,
+                                  torch.cuda.current_stream().cuda_stream), "stats")
+    R, ov = C.c_int64(0), C.c_int32(0)
+    nat.check(lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), torch.cuda.current_stream().cuda_stream), "query")
+    binned, slots = int(stats[1]), int(R.value)
+    assert ov.value == 0 and 0 < binned < 0.93 * slots, (binned, slots)
+    g = run(0x7fc00000)                                   # quiet-NaN bit pattern
+    assert torch.isfinite(g._acc["flat"]).all()
+    assert torch.equal(f._acc["flat"], g._acc["flat"])
