@@ -1,8 +1,10 @@
 """`simple_knn._C.distCUDA2` backed by the gfx950 kernel `sknn_dist2` (include/splat_hip.h).
 
 Reference call site: /root/reference/thirdparty/gaussian_splatting/scene/gaussian_model.py:194-200.
-Upstream (camenduru/simple-knn) finds the exact 3 nearest neighbours with a Morton-ordered box search; MI355X has the
-flops to do the exact search by brute force through LDS tiles, which is also order-independent and deterministic.
+Upstream (camenduru/simple-knn) finds the exact 3 nearest neighbours with a Morton-ordered box search.  Here: up to 16 k
+points (what the mapper feeds it: one keyframe's seeds) the exact search is brute force through LDS tiles, beyond that a
+uniform-grid search that widens its box until the third-nearest distance is proven -- both exact, order-independent and
+deterministic (csrc/sgr_aux.hip).
 """
 import ctypes as C
 

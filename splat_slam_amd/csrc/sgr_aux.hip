@@ -489,6 +489,152 @@ static int knn_splits(int n) {
   return s < 1 ? 1 : s;
 }
 
+// ---- large inputs: exact 3-NN through a uniform grid ------------------------------------------------------------------
+// Brute force is the right tool for what the reference feeds distCUDA2 (the 6-13 k seeds of one keyframe: 40 us) and the
+// wrong one for a whole map (300 k: 36 ms; 1.5 M: 0.9 s).  From kKnnGridFrom points on: bounding box -> cell size for ~8
+// points per cell if the box were filled (a surface-like map ends up with a few dozen per occupied cell) -> counting sort
+// into cells (order inside a cell is arbitrary, the result does not depend on it) -> every point searches the (2r+1)^3
+// cells around its own, r = 1, 2, ... until its third-nearest distance is no larger than the distance to the searched
+// box's faces (shrunk by the rounding of the cell coordinates), which proves that no unvisited point is nearer.
+constexpr int kKnnGridFrom = 16384;
+struct KnnGrid { float lo[3]; float h, inv_h, eps; int g[3]; int cells; };
+__device__ __forceinline__ uint32_t knn_ordered(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float knn_unordered(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+static size_t knn_max_cells(int n) { return (size_t)n / 2 + 1024; }
+
+__global__ void __launch_bounds__(256) knn_bounds_kernel(int n, const float* __restrict__ xyz, uint32_t* __restrict__ mm /* min3, max3 (ordered) */) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float v = xyz[3 * i + k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    for (int off = 32; off > 0; off >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[k], knn_ordered(lo[k])); atomicMax(&mm[3 + k], knn_ordered(hi[k])); }
+  }
+}
+
+__global__ void knn_grid_setup_kernel(int n, int max_cells, const uint32_t* __restrict__ mm, KnnGrid* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  KnnGrid G;
+  float ext[3], amax = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    const float lo = knn_unordered(mm[k]), hi = knn_unordered(mm[3 + k]);
+    G.lo[k] = lo;
+    ext[k] = fmaxf(hi - lo, 0.f);
+    amax = fmaxf(amax, fmaxf(fabsf(lo), fabsf(hi)));
+  }
+  const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+  // volume of the box with degenerate sides lifted to 1/1024 of the longest one (planar / linear maps)
+  float vol = 1.f;
+  for (int k = 0; k < 3; ++k) vol *= fmaxf(ext[k], emax * (1.f / 1024.f));
+  float h = emax > 0.f ? cbrtf(vol * 8.f / (float)n) : 1.f;
+  h = fmaxf(h, emax * (1.f / 1024.f));
+  if (!(h > 0.f) || !isfinite(h)) h = 1.f;
+  for (int iter = 0; iter < 32; ++iter) {
+    long long cells = 1;
+    for (int k = 0; k < 3; ++k) { G.g[k] = min(1024, max(1, (int)floorf(ext[k] / h) + 1)); cells *= G.g[k]; }
+    if (cells <= (long long)max_cells) break;
+    h *= 1.26f;                              // (cells shrink by ~2 per step)
+  }
+  G.cells = G.g[0] * G.g[1] * G.g[2];
+  G.h = h; G.inv_h = 1.f / h;
+  G.eps = 8e-6f * (amax + emax) + 1e-30f;    // what fp32 rounding can move a cell coordinate by, in length units
+  *out = G;
+}
+
+__device__ __forceinline__ int knn_cell_coord(float v, float lo, float inv_h, int g) { return min(g - 1, max(0, (int)floorf((v - lo) * inv_h))); }
+
+__global__ void __launch_bounds__(256) knn_count_kernel(int n, const float* __restrict__ xyz, const KnnGrid* __restrict__ Gp,
+                                                        uint32_t* __restrict__ count, uint32_t* __restrict__ cell_of) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const KnnGrid G = *Gp;
+  const int cx = knn_cell_coord(xyz[3 * i], G.lo[0], G.inv_h, G.g[0]), cy = knn_cell_coord(xyz[3 * i + 1], G.lo[1], G.inv_h, G.g[1]),
+            cz = knn_cell_coord(xyz[3 * i + 2], G.lo[2], G.inv_h, G.g[2]);
+  const uint32_t c = (uint32_t)((cz * G.g[1] + cy) * G.g[0] + cx);
+  cell_of[i] = c;
+  atomicAdd(&count[c], 1u);
+}
+
+// exclusive scan of count[0..cells) by one 1024-thread block (cells <= n/2 + 1024: ~50 passes at 300 k points)
+__global__ void __launch_bounds__(1024) knn_scan_kernel(const KnnGrid* __restrict__ Gp, const uint32_t* __restrict__ count,
+                                                        uint32_t* __restrict__ start, uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t red[16];
+  const int cells = Gp->cells, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (int base = 0; base < cells; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const uint32_t v = i < cells ? count[i] : 0u;
+    const uint32_t inc = wave_scan_add_u32(v);
+    if (lane == 63) red[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint32_t r = red[w]; pre += w < wv ? r : 0u; tot += r; }
+    __syncthreads();
+    if (i < cells) { start[i] = carry + pre + inc - v; cursor[i] = carry + pre + inc - v; }
+    carry += tot;
+  }
+}
+
+__global__ void __launch_bounds__(256) knn_fill_kernel(int n, const float* __restrict__ xyz, const uint32_t* __restrict__ cell_of,
+                                                       uint32_t* __restrict__ cursor, float* __restrict__ sorted_xyz,
+                                                       uint32_t* __restrict__ sorted_idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t pos = atomicAdd(&cursor[cell_of[i]], 1u);
+  sorted_xyz[3 * pos] = xyz[3 * i]; sorted_xyz[3 * pos + 1] = xyz[3 * i + 1]; sorted_xyz[3 * pos + 2] = xyz[3 * i + 2];
+  sorted_idx[pos] = (uint32_t)i;
+}
+
+// thread = point in CELL order (neighbouring lanes search the same cells)
+__global__ void __launch_bounds__(256) knn_query_kernel(int n, const KnnGrid* __restrict__ Gp, const uint32_t* __restrict__ start,
+                                                        const uint32_t* __restrict__ count, const float* __restrict__ sorted_xyz,
+                                                        const uint32_t* __restrict__ sorted_idx, float* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const KnnGrid G = *Gp;
+  const float q[3] = {sorted_xyz[3 * t], sorted_xyz[3 * t + 1], sorted_xyz[3 * t + 2]};
+  int c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c[k] = knn_cell_coord(q[k], G.lo[k], G.inv_h, G.g[k]);
+  Top3 best;
+  for (int r = 1;; ++r) {
+    best = {INFINITY, INFINITY, INFINITY};
+    const int x0 = max(0, c[0] - r), x1 = min(G.g[0] - 1, c[0] + r), y0 = max(0, c[1] - r), y1 = min(G.g[1] - 1, c[1] + r),
+              z0 = max(0, c[2] - r), z1 = min(G.g[2] - 1, c[2] + r);
+    for (int cz = z0; cz <= z1; ++cz)
+      for (int cy = y0; cy <= y1; ++cy) {
+        const int row = (cz * G.g[1] + cy) * G.g[0];
+        const uint32_t j0 = start[row + x0], j1 = start[row + x1] + count[row + x1];     // cells of one row are consecutive
+        for (uint32_t j = j0; j < j1; ++j) {
+          const float dx = sorted_xyz[3 * j] - q[0], dy = sorted_xyz[3 * j + 1] - q[1], dz = sorted_xyz[3 * j + 2] - q[2];
+          const float d = dx * dx + dy * dy + dz * dz;
+          if ((int)j != t) top3_push(best, d);
+        }
+      }
+    // faces of the searched box that are not faces of the grid: anything beyond them is unvisited
+    float bound = INFINITY;
+    const int lo_c[3] = {x0, y0, z0}, hi_c[3] = {x1, y1, z1};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (lo_c[k] > 0) bound = fminf(bound, q[k] - (G.lo[k] + (float)lo_c[k] * G.h));
+      if (hi_c[k] < G.g[k] - 1) bound = fminf(bound, (G.lo[k] + (float)(hi_c[k] + 1) * G.h) - q[k]);
+    }
+    if (isinf(bound)) break;                         // the whole grid has been searched
+    const float safe = bound - G.eps;
+    if (safe > 0.f && best.c <= safe * safe) break;
+  }
+  const float a = isinf(best.a) ? 0.f : best.a, b = isinf(best.b) ? 0.f : best.b, cc = isinf(best.c) ? 0.f : best.c;
+  out[sorted_idx[t]] = (a + b + cc) / 3.f;
+}
+
+static size_t knn_grid_scratch_bytes(int n) {
+  const size_t mc = knn_max_cells(n);
+  return 256 + 256 + 3 * align_up(mc * 4) + align_up((size_t)n * 4) + align_up((size_t)n * 12) + align_up((size_t)n * 4);
+}
+
 // ------------------------------------------------------------------------------------------------ SE3
 struct Pose { float t[3]; float q[4]; };   // q = (x, y, z, w)
 __device__ __forceinline__ Pose load_pose(const float* p) { return {{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}}; }
@@ -722,16 +868,42 @@ int sgr_masked_adam(int32_t rows, int32_t row_width, float* param, const float* 
   return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "masked_adam launch failed");
 }
 
-size_t sknn_scratch_bytes(int32_t n) { return n <= 0 ? 256 : (size_t)knn_splits(n) * (size_t)n * sizeof(Top3) + 256; }
+size_t sknn_scratch_bytes(int32_t n) {
+  if (n <= 0) return 256;
+  if (n >= kKnnGridFrom) return knn_grid_scratch_bytes(n);
+  return (size_t)knn_splits(n) * (size_t)n * sizeof(Top3) + 256;
+}
 
 int sknn_dist2(const float* xyz, int32_t n, float* mean_dist2, void* scratch, size_t scratch_bytes, void* stream) {
   if (n < 0 || (n > 0 && (!xyz || !mean_dist2))) return set_error(SGR_ERR_INVALID, "sknn: null argument");
   if (n == 0) return SGR_OK;
   if (!scratch || scratch_bytes < sknn_scratch_bytes(n)) return set_error(SGR_ERR_WORKSPACE, "sknn scratch too small");
-  int splits = knn_splits(n);
-  int per = ((n + splits - 1) / splits + 255) / 256 * 256;
   int qb = (n + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
+  if (n >= kKnnGridFrom) {
+    const size_t mc = knn_max_cells(n);
+    char* base = (char*)scratch;
+    uint32_t* mm = (uint32_t*)base;                      base += 256;
+    KnnGrid* G = (KnnGrid*)base;                         base += 256;
+    uint32_t* count = (uint32_t*)base;                   base += align_up(mc * 4);
+    uint32_t* start = (uint32_t*)base;                   base += align_up(mc * 4);
+    uint32_t* cursor = (uint32_t*)base;                  base += align_up(mc * 4);
+    uint32_t* cell_of = (uint32_t*)base;                 base += align_up((size_t)n * 4);
+    float* sorted_xyz = (float*)base;                    base += align_up((size_t)n * 12);
+    uint32_t* sorted_idx = (uint32_t*)base;
+    if (hipMemsetAsync(mm, 0xff, 12, st) != hipSuccess || hipMemsetAsync(mm + 3, 0, 12, st) != hipSuccess ||
+        hipMemsetAsync(count, 0, mc * 4, st) != hipSuccess)
+      return set_error(SGR_ERR_HIP, "sknn memset failed");
+    hipLaunchKernelGGL(knn_bounds_kernel, dim3(min(qb, 1024)), dim3(256), 0, st, n, xyz, mm);
+    hipLaunchKernelGGL(knn_grid_setup_kernel, dim3(1), dim3(64), 0, st, n, (int)mc, mm, G);
+    hipLaunchKernelGGL(knn_count_kernel, dim3(qb), dim3(256), 0, st, n, xyz, G, count, cell_of);
+    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, st, G, count, start, cursor);
+    hipLaunchKernelGGL(knn_fill_kernel, dim3(qb), dim3(256), 0, st, n, xyz, cell_of, cursor, sorted_xyz, sorted_idx);
+    hipLaunchKernelGGL(knn_query_kernel, dim3(qb), dim3(256), 0, st, n, G, start, count, sorted_xyz, sorted_idx, mean_dist2);
+    return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "sknn launch failed");
+  }
+  int splits = knn_splits(n);
+  int per = ((n + splits - 1) / splits + 255) / 256 * 256;
   hipLaunchKernelGGL(knn_partial_kernel, dim3(qb, splits), dim3(256), 0, st, n, xyz, per, (Top3*)scratch);
   hipLaunchKernelGGL(knn_merge_kernel, dim3(qb), dim3(256), 0, st, n, splits, (const Top3*)scratch, mean_dist2);
   return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "sknn launch failed");

@@ -25,6 +25,45 @@ def test_knn_mean_dist2_is_exact(n):
     assert torch.allclose(got, ref, rtol=2e-5, atol=1e-9)
 
 
+def _knn_ref_chunked(pts, rows=500):
+    """oracle.aux_oracle.knn_mean_dist2 without the N x N matrix in memory (same arithmetic, row blocks)."""
+    x = pts.double()
+    out = torch.empty(x.shape[0], dtype=torch.float64)
+    for a in range(0, x.shape[0], rows):
+        d2 = torch.cdist(x[a:a + rows], x) ** 2
+        d2[torch.arange(d2.shape[0]), torch.arange(a, a + d2.shape[0])] = float("inf")
+        out[a:a + rows] = torch.topk(d2, 3, dim=1, largest=False).values.sum(dim=1) / 3.0
+    return out
+
+
+@pytest.mark.parametrize("shape", ["blob", "room", "plane", "outliers"])
+def test_knn_grid_path_is_exact(shape):
+    """From 16384 points on distCUDA2 searches a uniform grid instead of all pairs: same exact 3-NN, whatever the layout --
+    anisotropic blob, surface-like room, exactly planar set (a degenerate bounding box), far outliers and duplicates (the
+    search has to widen its box until the proof holds)."""
+    from oracle.aux_oracle import knn_mean_dist2
+    from simple_knn._C import distCUDA2
+    from splat_slam_amd import synthetic as syn
+    n = 40000
+    g = torch.Generator().manual_seed(3)
+    if shape == "room":
+        pts = syn.room_points(n, g)
+    else:
+        pts = torch.randn(n, 3, generator=g) * torch.tensor([3.0, 1.0, 0.2])
+    if shape == "plane":
+        pts[:, 2] = 0.75
+    if shape == "outliers":
+        pts[:5] += torch.tensor([400.0, -250.0, 90.0])          # a far cluster of five
+        pts[5] = torch.tensor([-1000.0, 0.0, 0.0])              # and a loner
+    pts[11] = pts[4]
+    pts[12] = pts[4]                                            # a triple point: two zero distances
+    small = pts[:300]
+    assert torch.allclose(_knn_ref_chunked(small), knn_mean_dist2(small))          # the chunked reference is the oracle
+    got = distCUDA2(pts.to(DEV)).cpu().double()
+    ref = _knn_ref_chunked(pts)
+    assert torch.allclose(got, ref, rtol=2e-5, atol=1e-9), float((got - ref).abs().max())
+
+
 def test_se3_ops_match_oracle_and_reference_exp():
     import lietorch
     from oracle import aux_oracle as A
