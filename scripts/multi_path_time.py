@@ -1,30 +1,72 @@
-"""Host-side cost of the multi-GPU iteration path on ONE GPU: the all-reduce is replaced by an in-place self-add so that
-the two C-ABI calls + collective slot per iteration are exercised without a second device."""
-import os, sys, time
+"""ONE rank's share of a W-rank strong-scaling iteration, timed on one GPU: the loop is configured as rank 0 of W (views
+dealt round-robin, ZeRO-1 rows of rank 0) with a stand-in Comm whose collectives move no data between devices
+(reduce-scatter = take my slice, all-gather = leave the other slices as they are, all-reduce = nothing).  What it
+gives is the per-iteration GPU + host time of a rank WITHOUT the xGMI time: an upper bound of the strong-scaling speed-up
+of the reference's 12-view iteration.  (Parameters of the other ranks' rows never move here: timing only.)
+
+    python scripts/multi_path_time.py  ->  one JSON line per W"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
-from splat_slam_amd import synthetic as syn
-from splat_slam_amd.fused import FusedMappingLoop
+from splat_slam_amd import synthetic as syn          # noqa: E402
+from splat_slam_amd.fused import FusedMappingLoop     # noqa: E402
+
+
+class NullComm:
+    staged = False
+
+    def __init__(self, world):
+        self.world = world
+
+    def all_reduce(self, t, op=None):
+        pass
+
+    def reduce_scatter(self, out, inp):
+        out.copy_(inp[: out.numel()])                # rank 0's slice
+
+    def all_gather(self, full, shard):
+        pass
+
+
 dev = torch.device("cuda:0")
-torch.manual_seed(43); np.random.seed(43)
 intr = syn.INTRINSICS["metric"]
+torch.manual_seed(43)
+np.random.seed(43)
 params = syn.room_parameters(300000, seed=43, device=dev)
 cams = syn.make_views(params, 16, intr, dev, seed=43)
-for world, span in ((1, True), (2, True), (2, False)):
-    loop = FusedMappingLoop(syn.DEFAULT_CONFIG, device=dev, span_calls=span)
+for world in (1, 2, 4, 8):
+    loop = FusedMappingLoop(syn.DEFAULT_CONFIG, device=dev)
     loop.gaussians = syn.model_from_parameters(params, device=dev)
     loop.viewpoints = {c.uid: c for c in cams}
     loop.current_window = list(range(10))
     loop.build_keyframe_optimizers()
     loop.iteration_count = 50
-    loop.world = world
-    loop._all_reduce_sum = lambda t: t.mul_(1.0)          # one tiny-kernel stand-in for the collective
-    loop.map(loop.current_window, iters=10)
+    if world > 1:
+        loop.set_parallel(world, 0, split_views=True, sync="zero1", comm=NullComm(world))
+    loop.map(loop.current_window, iters=20)
+    loop.check_overflow()
+    loop.check_every = 1 << 30                       # (no capacity poll inside the timed window)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loop.map(loop.current_window, iters=60)
-    host = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    tot = time.perf_counter() - t0
-    print("world", world, "span", span, "ms/step %.4f" % (1e3 * tot / 60), "host enqueue ms/step %.4f" % (1e3 * host / 60), flush=True)
+    tot = host = 1e9
+    for _ in range(3):
+        loop.iteration_count = 50
+        t0 = time.perf_counter()
+        loop.map(loop.current_window, iters=80)
+        h = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        if t < tot:
+            tot, host = t, h
+    N = 300000
+    print(json.dumps({"world": world, "views_of_rank0_per_iteration": len(range(0, 12, world)), "ms_per_iteration_rank0_no_collective_time":
+                      round(1e3 * tot / 80, 4), "host_enqueue_ms_per_iteration": round(1e3 * host / 80, 4),
+                      "bytes_reduce_scatter_plus_all_gather": 2 * 56 * N if world > 1 else 0}), flush=True)
+    del loop
+    torch.cuda.empty_cache()
