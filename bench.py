@@ -211,7 +211,10 @@ class Bench:
             pass
         a = gbs(bytes_bwd, bwd_ms)
         roof = {"kernel": "blend_bwd_kernel<true>", "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(bwd_ms, 5), "launches": bwd_n,
+                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": "profiles/latest_pmc_hbm_bytes.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                  "(scripts/collect_profiles.py), not measured by this run",
+                "avg_launch_ms": round(bwd_ms, 5), "launches": bwd_n,
                 "views_per_launch": nv, "algorithmic_bytes": bytes_bwd, "own_formula_bytes": own_bytes,
                 "pixel_splat_pairs_per_launch": pair_evals,
                 "valu_frac_at_60flop_per_pair": round(pair_evals * 60 / (bwd_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if bwd_ms > 0 else 0.0,
