@@ -47,3 +47,45 @@ def test_tile_rectangle_at_tile_corner():
     x0, y0, x1, y1 = pp.rect[0].tolist()
     assert (x1 - x0) * (y1 - y0) == 4 and (x0, y0) == (1, 1)
     assert bool(pp.visible[0]) and pp.radii[0].item() == math.ceil(3 * math.sqrt((FX * 0.02 / z) ** 2 + 0.3))
+
+
+def _one(u, v, sc, opac=0.5, z=2.0):
+    X, Y = (u - (CX - 0.5)) * z / FX, (v - (CY - 0.5)) * z / FY
+    s = O.make_settings(torch.eye(4, dtype=DT), FX, FY, CX, CY, W, H, dtype=DT)
+    return dict(means3D=torch.tensor([[X, Y, z]], dtype=DT), opacities=torch.tensor([[opac]], dtype=DT),
+                shs=torch.zeros(1, 1, 3, dtype=DT), scales=torch.full((1, 3), sc, dtype=DT),
+                rotations=torch.tensor([[1.0, 0, 0, 0]], dtype=DT)), s
+
+
+def test_knife_edge_report_flags_the_integer_decisions_of_the_projection():
+    """knife_edge_gaussians: a splat whose (centre - radius) sits within fp32 rounding of a multiple of 16 is reported (the
+    tile rectangle trunc((xy -+ r)/16) may come out one tile wider in another implementation), one a quarter pixel away is
+    not; likewise a radius 3 sqrt(lambda) within rounding of an integer."""
+    sc, z = 0.02, 2.0
+    r = math.ceil(3 * math.sqrt((FX * sc / z) ** 2 + 0.3 + math.sqrt(0.1)))   # 3 px (lambda = mid + sqrt(max(0.1, mid^2 - det)))
+    for du, flagged in ((1e-5, True), (-1e-5, True), (0.25, False)):
+        inp, s = _one(16.0 + r + du, 24.3, sc)                                # xy.x - r = 16 + du
+        d = O.knife_edge_gaussians(inp["means3D"], inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                                   rotations=inp["rotations"], settings=s, detail=True)
+        assert (d["geometric"].numel() == 1) == flagged, (du, d)
+    # radius: choose the scale so that 3 sqrt(lambda) = 4 (1 + 1e-5) -> ceil() is a coin toss in fp32
+    for rel, flagged in ((1e-5, True), (3e-2, False)):
+        target = 4.0 * (1.0 + rel) / 3.0
+        sc = math.sqrt(target * target - 0.3 - math.sqrt(0.1)) * z / FX
+        inp, s = _one(30.37, 22.41, sc)
+        d = O.knife_edge_gaussians(inp["means3D"], inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                                   rotations=inp["rotations"], settings=s, detail=True)
+        assert (d["geometric"].numel() == 1) == flagged, (rel, d)
+
+
+def test_knife_edge_report_flags_alpha_at_the_1_over_255_cutoff():
+    """An isotropic splat centred ON a pixel whose opacity puts alpha at a chosen pixel exactly at 1/255 is reported; with the
+    opacity 1 % higher it is not (every other pixel of a symmetric splat sits at a different, well separated alpha)."""
+    sc, z = 0.06, 2.0
+    sig2 = (FX * sc / z) ** 2 + 0.3
+    G = math.exp(-0.5 * (3.0 ** 2) / sig2)                                   # the pixels 3 px to the left / right / above / below
+    for opac, flagged in ((1.0 / 255.0 / G, True), (1.01 / 255.0 / G, False)):
+        inp, s = _one(31.0, 23.0, sc, opac=opac)
+        d = O.knife_edge_gaussians(inp["means3D"], inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                                   rotations=inp["rotations"], settings=s, detail=True)
+        assert (d["alpha"].numel() == 1) == flagged, (opac, d)
