@@ -34,9 +34,9 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-KINDS = ["preprocess_fwd", "tile_scan", "scatter", "blend_fused_fwd_loss_bwd", "unused4", "blend_fwd_incl_tile_sort", "unused6",
-         "blend_bwd", "preprocess_bwd"]
-PK_FUSED, PK_FWD, PK_BWD = 3, 5, 7
+KINDS = ["preprocess_fwd", "tile_scan", "scatter", "blend_fused_fwd_loss_bwd", "blend_fwd_incl_tile_sort", "blend_bwd",
+         "preprocess_bwd_incl_optimiser_pass"]
+PK_FUSED, PK_FWD, PK_BWD = 3, 4, 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
 HIST_BINS = ["0", "1-4", "5-8", "9-16", "17-32", "33-64", "65-256", ">256"]

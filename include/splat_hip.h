@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 6
+#define SGR_ABI_VERSION 7
 
 typedef enum SgrStatus {
   SGR_OK = 0,
@@ -216,12 +216,12 @@ int sgr_query_list_histogram(const SgrWorkspace* ws, int32_t num_gaussians, int3
 int sgr_set_option(int32_t option, int32_t value);
 int sgr_get_option(int32_t option);
 
-/* Per-kernel HIP-event timing.  kind: 0 preprocess_fwd (+ per-tile pair counting), 1 tile_scan, 2 scatter,
- * 3 fused tile kernel (blend forward + loss + blend backward), 4/6 unused, 5 blend_fwd (+ in-wave tile sort), 7 blend_bwd,
- * 8 preprocess_bwd (+ pose reduce).  sgr_profile_enable(mask) arms event pairs around the kinds whose
+/* Per-kernel HIP-event timing.  kind: 0 preprocess_fwd (+ binning), 1 tile_scan, 2 scatter, 3 fused tile kernel (blend
+ * forward + loss + blend backward), 4 blend_fwd (+ in-wave tile sort), 5 blend_bwd, 6 preprocess_bwd (+ gather / optimiser
+ * pass, pose reduce).  sgr_profile_enable(mask) arms event pairs around the kinds whose
  * bit is set (0 disarms); sgr_profile_read() synchronises, returns accumulated milliseconds and launch counts per
  * kind since the last read, and resets them. Events are recorded on the stream the kernel is launched on. */
-#define SGR_PROFILE_KINDS 9
+#define SGR_PROFILE_KINDS 7
 int sgr_profile_enable(uint32_t kind_mask);
 int sgr_profile_read(float ms_host[SGR_PROFILE_KINDS], int64_t launches_host[SGR_PROFILE_KINDS]);
 

@@ -98,7 +98,7 @@ def main():
         setattr(gm_cls, name, timed)
     status, n_hist, t_kf = [], [], []
     if a.profile:
-        loop.lib.sgr_profile_enable(0x1ff)
+        loop.lib.sgr_profile_enable(0x7f)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for f in frames:
@@ -118,10 +118,10 @@ def main():
     kernel_ms = None
     if a.profile:
         import ctypes as C
-        ms, cnt = (C.c_float * 9)(), (C.c_int64 * 9)()
+        ms, cnt = (C.c_float * 7)(), (C.c_int64 * 7)()
         loop.lib.sgr_profile_read(ms, cnt)
         loop.lib.sgr_profile_enable(0)
-        names = ["preprocess_fwd", "tile_scan", "scatter", "blend_fused", "-", "blend_fwd", "-", "blend_bwd", "preprocess_bwd"]
+        names = ["preprocess_fwd", "tile_scan", "scatter", "blend_fused", "blend_fwd", "blend_bwd", "preprocess_bwd"]
         kernel_ms = {n: {"total_s": round(float(ms[i]) / 1e3, 3), "launches": int(cnt[i]), "avg_ms": round(float(ms[i]) / max(1, int(cnt[i])), 4)}
                      for i, n in enumerate(names) if int(cnt[i])}
         from splat_slam_amd import _native as nat

@@ -156,7 +156,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.sgr_abi_version() != 6:
+        if h.sgr_abi_version() != 7:
             raise ImportError("libsplat_hip.so ABI version mismatch")
         _lib = h
     return _lib

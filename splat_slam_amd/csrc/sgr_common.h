@@ -291,7 +291,7 @@ int gaussian_adam_step_act(int64_t n, const SgrAdamGroup groups[5], float beta1,
 void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st);
 
 // ---- optional per-kernel event timing (sgr_profile_enable / sgr_profile_read)
-enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_SCATTER, PK_BLEND_FUSED, PK_UNUSED4, PK_BLEND_FWD, PK_UNUSED6, PK_BLEND_BWD, PK_PRE_BWD };
+enum ProfKind { PK_PRE_FWD = 0, PK_SCAN, PK_SCATTER, PK_BLEND_FUSED, PK_BLEND_FWD, PK_BLEND_BWD, PK_PRE_BWD };
 void prof_begin(int kind, hipStream_t st);
 void prof_end(int kind, hipStream_t st);
 struct ProfScope {
