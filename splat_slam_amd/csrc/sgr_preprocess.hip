@@ -950,6 +950,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   // splats that cover tens to hundreds of tiles: a lane walking its own run alone makes the wave wait for its longest run
   // and fetches 48 scattered bytes per lane and step.  Instead every group of 8 lanes sums ONE run together (lane l takes
   // slots l, l + 8, ...: 384 contiguous bytes per step), eight rounds cover the wave's 64 Gaussians; fixed order, no atomics.
+  constexpr uint32_t kLongRun = 96u;
   float gsum[10];
   {
     const float4* __restrict__ partials = (const float4*)(tab.scratch[v] + L.o_partials);
@@ -979,7 +980,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 #pragma unroll 1
     for (int r = 0; r < 8; ++r) {
       const int src = r * 8 + grp;                    // the lane whose Gaussian this group sums in round r
-      const uint32_t o = (uint32_t)__shfl((int)my_off, src), c = (uint32_t)__shfl((int)my_cnt, src);
+      const uint32_t o = (uint32_t)__shfl((int)my_off, src), c_all = (uint32_t)__shfl((int)my_cnt, src);
+      const uint32_t c = c_all > kLongRun ? 0u : c_all;           // (long runs: the whole wave, below)
       const uint32_t s01 = (uint32_t)__shfl((int)my_r01, src), s23 = (uint32_t)__shfl((int)my_r23, src);
       const Footprint sf{__shfl(foot.px, src), __shfl(foot.py, src), __shfl(foot.A, src), __shfl(foot.B, src),
                          __shfl(foot.C, src), __shfl(foot.invA, src), __shfl(foot.invC, src), __shfl(foot.thr, src)};
@@ -1014,6 +1016,48 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
       for (int j = 0; j < 10; ++j) {
         const float got = __shfl(part[j], sub * 8);
         if (grp == r) gsum[j] = got;
+      }
+    }
+    // A run of more than kLongRun slots -- a young SLAM map has splats that cover a quarter of the image, thousands of bins --
+    // would keep ONE 8-lane group busy for c / 24 dependent round trips while the rest of the wave waits (the dense backward
+    // was the most expensive kernel of a session's first 40 keyframes: 0.29 ms per launch).  Those runs are summed by the
+    // whole wave, one Gaussian at a time: 192 slots per batch.
+    if (longest > (int)kLongRun) {
+      unsigned long long lm = __ballot(my_cnt > kLongRun);
+      while (lm != 0ull) {
+        const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
+        lm &= lm - 1ull;
+        const uint32_t o = (uint32_t)__shfl((int)my_off, src), c = (uint32_t)__shfl((int)my_cnt, src);
+        const uint32_t s01 = (uint32_t)__shfl((int)my_r01, src), s23 = (uint32_t)__shfl((int)my_r23, src);
+        const Footprint sf{__shfl(foot.px, src), __shfl(foot.py, src), __shfl(foot.A, src), __shfl(foot.B, src),
+                           __shfl(foot.C, src), __shfl(foot.invA, src), __shfl(foot.invC, src), __shfl(foot.thr, src)};
+        float part[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) part[j] = 0.f;
+        for (uint32_t k0 = (uint32_t)lane; k0 < c; k0 += 192u) {
+          float4 ld[9];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const uint32_t k = k0 + 64u * (uint32_t)u;
+            const uint64_t e = (uint64_t)o + k;
+            const bool in = k < c && (int64_t)e < L.cap && !slot_unwritten(sf, s01, s23, k);
+#pragma unroll
+            for (int w = 0; w < 3; ++w) ld[3 * u + w] = in ? partials[e * 3 + w] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const float4 p0 = ld[3 * u], p1 = ld[3 * u + 1], p2 = ld[3 * u + 2];
+            part[0] += p0.x; part[1] += p0.y; part[2] += p0.z; part[3] += p0.w; part[4] += p1.x;
+            part[5] += p1.y; part[6] += p1.z; part[7] += p1.w; part[8] += p2.x; part[9] += p2.y;
+          }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+          for (int j = 0; j < 10; ++j) part[j] += __shfl_xor(part[j], off);
+        if (lane == src)
+#pragma unroll
+          for (int j = 0; j < 10; ++j) gsum[j] = part[j];
       }
     }
   }
