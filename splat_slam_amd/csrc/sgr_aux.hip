@@ -371,7 +371,9 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
   // K1 left one word per Gaussian with the views of the batch that see it.  Every lane walks ITS OWN set bits in
   // ascending view order (the fixed summation order of grad_gather_kernel): a wave makes max-over-lanes(popcount) record
   // round trips -- about 3 for a SLAM batch -- instead of one per view of the batch.
-  uint32_t seen = ((const uint32_t*)(tab.saved[0] + L.o_vismask))[i] & ~truncated;
+  uint32_t seen = 0u;
+  for (int p = 0; p < min(L.k1_parts, nviews); ++p) seen |= ((const uint32_t*)(tab.saved[0] + L.o_vismask))[(size_t)p * L.N + i];
+  seen &= ~truncated;
   const bool any = seen != 0u;
   while (seen) {
     const int v = __builtin_ctz(seen);

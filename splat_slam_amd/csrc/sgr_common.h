@@ -28,6 +28,11 @@ constexpr int kCntSlotWords = 8;       // uint32 units per 2x2-block slot
 constexpr uint32_t kTileCountLimit = 0xff00u;
 __host__ __device__ inline size_t tile_counter_word(int x, int y, int gxp) { return ((size_t)(y >> 1) * gxp + (x >> 1)) * (kCntSlotWords / 2); }   // in uint64 units
 __host__ __device__ inline int tile_counter_shift(int x, int y) { return 16 * ((y & 1) * 2 + (x & 1)); }
+// K1's block = one 256-Gaussian segment x a SUBSET of the batch's views (view v belongs to part v % parts).  One part when the
+// map has enough segments to fill the chip; a young SLAM map (60 k Gaussians = 235 segments, 40 % of them visible, splats of
+// hundreds of bins) would otherwise run its whole forward binning on a quarter of the CUs.
+constexpr int kK1MaxParts = 4;
+__host__ __device__ inline int k1_parts_for(int nseg) { return nseg >= 768 ? 1 : (nseg >= 384 ? 2 : kK1MaxParts); }
 constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
 // Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the
 // key goes straight into the tile's fixed bucket -- no second pass.  Only tiles with more than kBucket pairs are re-scattered
@@ -123,7 +128,7 @@ struct ViewTab {
 };
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {
-  int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg, mean_hint;
+  int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg, mean_hint, k1_parts;
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
@@ -208,7 +213,8 @@ struct Layout {
     o_block_base_v = take(nb * 4);
     o_vis_list = take(n * 4);
     o_seg_list = take(n * 4);        // per-segment visible lists written by K1; K3 turns them into the compact o_vis_list
-    o_vismask = take(n * 4);         // per Gaussian: the views of the BATCH that see it (bit v; kept in the batch's first saved block)
+    o_vismask = take(n * 4 * kK1MaxParts);   // per Gaussian: the views of the BATCH that see it (bit v; kept in the batch's first saved block;
+                                             // one word per K1 view part, OR-ed by the reader)
     saved_bytes = o;
 
     o = 0;
@@ -225,7 +231,7 @@ struct Layout {
   }
   __host__ LOff dev() const {
     LOff d;
-    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags(); d.mean_hint = 0;
+    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags(); d.mean_hint = 0; d.k1_parts = k1_parts_for(nseg);
     d.cap = cap;
     d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_grec = o_grec;
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;

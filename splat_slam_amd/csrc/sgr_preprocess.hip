@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint32_t seg_views;                 // bit v = some Gaussian of this segment MAY be visible in view v
   const int N = L.N;
   const int seg = blockIdx.x, seg0 = seg * kSeg;
+  const int part = blockIdx.y, nparts = gridDim.y;      // this block's views: v % nparts == part
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   // ---- per-view constants into LDS (constant indices only: a dynamically indexed by-value struct would go to scratch)
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
 #pragma unroll 2
     for (int v = 0; v < nviews; ++v) {
       bool pass = false;
-      if (ia < N) {
+      if (ia < N && (v % nparts) == part) {
         p_radii[v][ia] = 0;                // outputs of the culled majority; phase B overwrites the visible ones
         if (p_ntouched[v]) p_ntouched[v][ia] = 0;
         if (L.dbg & 2) pass = (p[0] + trS == 12345.678f);
@@ -676,8 +677,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   }
   __syncthreads();
   // which views of the batch see Gaussian ia (one word instead of one radii word per view for the optimiser pass)
-  if (ia < N) ((uint32_t*)(p_saved[0] + L.o_vismask))[ia] = vis_bits[tid];
-  if (tid < nviews) {
+  if (ia < N) ((uint32_t*)(p_saved[0] + L.o_vismask))[(size_t)part * N + ia] = vis_bits[tid];
+  if (tid < nviews && (tid % nparts) == part) {
     char* saved = p_saved[tid];
     ((uint32_t*)(saved + L.o_block_touched))[seg] = vbase_t[tid + 1] - vbase_t[tid];
     ((uint32_t*)(saved + L.o_block_vis))[seg] = vbase_v[tid + 1] - vbase_v[tid];
@@ -1198,7 +1199,7 @@ __global__ void __launch_bounds__(384) tau_reduce_kernel(ViewTab tab, LOff L) {
 void launch_preprocess_fwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in, hipStream_t st) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_FWD, st);
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.nseg), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(L.nseg, min(L.k1_parts, nviews)), dim3(256), 0, st, tab, nviews, L, cm, in.means3D, in.opacities,
                      in.shs, in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp);
 }
 
