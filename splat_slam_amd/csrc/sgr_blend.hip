@@ -43,11 +43,11 @@ template <typename LD, typename ST, typename SYNC>
 __device__ __forceinline__ void wave_sort_any(int n, int lane, LD load, ST store, SYNC sync) {
   int P = 1;
   while (P < n) P <<= 1;
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const bool first = (j == (k >> 1));
+  for (int k = 2, lk = 1; k <= P; k <<= 1, ++lk) {
+    for (int j = k >> 1, lj = lk - 1; j > 0; j >>= 1, --lj) {       // j = 1 << lj: shifts, not the integer divisions t / j, t % j
+      const bool first = (j == (k >> 1));                           // (half of a 129..256-entry tile's forward was this sort)
       for (int t = lane; t < (P >> 1); t += kWave) {
-        int i = ((t / j) * (j << 1)) + (t % j);                     // lower index of the pair
+        int i = ((t >> lj) << (lj + 1)) + (t & (j - 1));            // lower index of the pair
         int l = first ? (i ^ (k - 1)) : (i ^ j);                    // mirror partner on the first step of a merge
         if (l < i) { int tmp = i; i = l; l = tmp; }
         if (l < n) {
