@@ -781,12 +781,15 @@ static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, co
 }
 
 // 0 light / 1 mid / 2 heavy, from the expected mean list length: SgrWorkspace.mean_list_hint (x 2 for safety) when the caller
-// gives one, else capacity / tiles / 2 (the fused loop sizes `capacity` at 2x the pair count it has seen).  Tiles beyond the
-// build's key count fall back to the in-HBM sort, which is correct but slow, so a build is chosen when the estimated mean
-// is a factor ~4 below its key count.
+// gives one, else capacity / tiles / 2 (the fused loop sizes `capacity` at 2x the pair count it has seen, and the pair
+// count includes the bins the footprint test drops: an over-estimate by 1.2-1.5x).  Tiles beyond the build's key count
+// fall back to the in-HBM sort, which is correct but slow.  The light build (256 keys) is kept up to an estimated mean of
+// 160: it is the one that runs forward and backward of a tile in ONE wave, and on lists of 65-256 that is worth more than
+// the rare tile that spills (opaque bench scene 1.36 -> 1.17 ms per iteration, a 60-keyframe session 66 -> 59 ms per
+// keyframe; estimated means of 160 and 256 as the limit measured the same).
 static int blend_build(const LOff& L) {
   const int64_t mean_len = L.mean_hint > 0 ? 2 * (int64_t)L.mean_hint : L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
-  return mean_len > 256 ? 2 : (mean_len > 64 ? 1 : 0);
+  return mean_len > 256 ? 2 : (mean_len > 160 ? 1 : 0);
 }
 
 // lt: per-view loss pointers (gt_image[v] == NULL -> plain render).  With a loss, every 8x8 tile also leaves one
