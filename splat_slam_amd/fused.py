@@ -153,6 +153,19 @@ class _ExposureSlab:
                                       0.999, 1e-8, stream), "sgr_masked_adam")
 
 
+def estimate_pairs(hints, uid, n_now):
+    """(tile, Gaussian) pair count to size a camera's workspace by when its buffers are new (FusedMappingLoop._estimate_pairs).
+    `hints`: uid -> (pairs measured, map size at that time).  The camera's own measurement scaled by the growth of the map
+    (never down) x 1.25; for a camera never measured 1.5 x the largest such estimate of the others; None = nothing known."""
+    scaled = lambda h: int(h[0] * max(1.0, n_now / max(1, h[1])) * 1.25) + 1024
+    h = hints.get(uid)
+    if h is not None:
+        return scaled(h)
+    if hints:
+        return int(1.5 * max(scaled(x) for x in hints.values()))
+    return None
+
+
 class FusedMappingLoop(MappingLoop):
     def __init__(self, config, device="cuda:0", knn_fn=None, check_every=50, span_calls=True):
         super().__init__(config, device=device, fused_loss=True, knn_fn=knn_fn)
@@ -392,16 +405,11 @@ class FusedMappingLoop(MappingLoop):
         the map; a camera never measured takes the largest estimate of the others (neighbouring views of one room); only
         with nothing to go by is it probed.  Capacity is twice the estimate; an estimate that still falls short costs that
         view one iteration (a truncated view contributes nothing, sgr_aux.hip) until the early check below corrects it."""
-        N = self.gaussians._xyz.shape[0]
-        scaled = lambda h: int(h[0] * max(1.0, N / max(1, h[1])) * 1.25) + 1024
-        h = self._pair_hint.get(cam.uid)
-        if h is not None:
-            vb.pairs = scaled(h)
-        elif self._pair_hint:
-            vb.pairs = int(1.5 * max(scaled(x) for x in self._pair_hint.values()))
-        else:
+        est = estimate_pairs(self._pair_hint, cam.uid, self.gaussians._xyz.shape[0])
+        if est is None:
             self._probe(cam, vb)
             return
+        vb.pairs = est
         self._since_check = max(self._since_check, self.check_every - 2)      # measure soon
 
     def _probe(self, cam, vb):

@@ -71,3 +71,15 @@ def test_seeding_from_rgbd_backprojects_valid_pixels_only():
     assert torch.allclose(gm._scaling.detach(), torch.full_like(gm._scaling, float(np.log(np.sqrt(0.04 * 0.05)))), atol=1e-6)
     assert torch.equal(gm._rotation.detach()[:, 0], torch.ones(pc.shape[0])) and gm._rotation.detach()[:, 1:].abs().max() == 0
     assert gm._opacity.detach().abs().max() < 1e-6 and torch.all(gm.unique_kfIDs == 5)
+
+
+def test_pair_estimates_carried_across_map_sizes():
+    """FusedMappingLoop sizes a camera's workspace from carried-over measurements instead of a probe render per map size."""
+    from splat_slam_amd.fused import estimate_pairs
+    assert estimate_pairs({}, 3, 1000) is None                                   # nothing known: the caller probes
+    hints = {3: (40000, 100000), 7: (90000, 200000)}
+    assert estimate_pairs(hints, 3, 100000) == int(40000 * 1.25) + 1024           # own measurement, same map size
+    assert estimate_pairs(hints, 3, 150000) == int(40000 * 1.5 * 1.25) + 1024     # scaled with the growth of the map
+    assert estimate_pairs(hints, 3, 50000) == int(40000 * 1.25) + 1024            # never scaled down
+    new_cam = estimate_pairs(hints, 11, 200000)                                   # never measured: 1.5 x the largest of the others
+    assert new_cam == int(1.5 * max(int(40000 * 2.0 * 1.25) + 1024, int(90000 * 1.25) + 1024))
