@@ -83,3 +83,33 @@ def test_pair_estimates_carried_across_map_sizes():
     assert estimate_pairs(hints, 3, 50000) == int(40000 * 1.25) + 1024            # never scaled down
     new_cam = estimate_pairs(hints, 11, 200000)                                   # never measured: 1.5 x the largest of the others
     assert new_cam == int(1.5 * max(int(40000 * 2.0 * 1.25) + 1024, int(90000 * 1.25) + 1024))
+
+
+def test_tile_sort_network_index_arithmetic():
+    """csrc/sgr_blend.hip wave_sort_any: the bitonic 'mirror' network (every compare-exchange ascending, virtual +inf padding
+    behind n never moves) with the pair index computed by shifts -- i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), j = 1 << lj --
+    restated here: it must be the same index as the division form and must sort ANY n."""
+    import random
+    rnd = random.Random(7)
+    for n in list(range(0, 70)) + [127, 128, 129, 200, 255, 256, 257, 300, 1000]:
+        a = [rnd.getrandbits(40) for _ in range(n)]
+        want = sorted(a)
+        P = 1
+        while P < n:
+            P <<= 1
+        k, lk = 2, 1
+        while k <= P:
+            j, lj = k >> 1, lk - 1
+            while j > 0:
+                first = j == (k >> 1)
+                for t in range(P >> 1):
+                    i = ((t >> lj) << (lj + 1)) + (t & (j - 1))
+                    assert i == (t // j) * (j << 1) + (t % j)
+                    l = (i ^ (k - 1)) if first else (i ^ j)
+                    if l < i:
+                        i, l = l, i
+                    if l < n and a[l] < a[i]:
+                        a[i], a[l] = a[l], a[i]
+                j, lj = j >> 1, lj - 1
+            k, lk = k << 1, lk + 1
+        assert a == want, n
