@@ -113,3 +113,39 @@ def test_tile_sort_network_index_arithmetic():
                 j, lj = j >> 1, lj - 1
             k, lk = k << 1, lk + 1
         assert a == want, n
+
+
+def test_footprint_bin_test_is_a_lower_bound_of_the_quadratic_form():
+    """csrc/sgr_common.h footprint_qmin, restated: the minimum of q = A dx^2 + 2 B dx dy + C dy^2 over the bounding box of a
+    bin's 8x8 pixel centres (0 if the centre is inside, else the smallest of the four edge minima).  It must never exceed q at
+    any pixel of the bin -- so 'qmin > tau' proves that no pixel reaches alpha >= 1/255 -- and must be attained on the box."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+
+    def qmin(px, py, A, B, C, tx, ty):
+        xl, yl = tx * 8 - px, ty * 8 - py
+        xh, yh = xl + 7, yl + 7
+        if xl <= 0 <= xh and yl <= 0 <= yh:
+            return 0.0
+        ex = lambda c: (lambda d: A * c * c + 2 * B * c * d + C * d * d)(min(yh, max(yl, -B * c / C)))
+        ey = lambda c: (lambda d: A * d * d + 2 * B * d * c + C * c * c)(min(xh, max(xl, -B * c / A)))
+        return min(ex(xl), ex(xh), ey(yl), ey(yh))
+
+    for _ in range(300):
+        s1, s2, th = rng.uniform(0.6, 30.0), rng.uniform(0.6, 30.0), rng.uniform(0, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        conic = np.linalg.inv(R @ np.diag([s1 * s1, s2 * s2]) @ R.T)
+        A, B, C = conic[0, 0], conic[0, 1], conic[1, 1]
+        px, py = rng.uniform(0, 64, 2)
+        for tx in range(-1, 9):
+            for ty in range(-1, 9):
+                xs = np.arange(tx * 8, tx * 8 + 8) - px
+                ys = np.arange(ty * 8, ty * 8 + 8) - py
+                dx, dy = np.meshgrid(xs, ys)
+                q_pix = (A * dx * dx + 2 * B * dx * dy + C * dy * dy).min()
+                fx, fy = np.meshgrid(np.linspace(xs[0], xs[-1], 57), np.linspace(ys[0], ys[-1], 57))
+                q_box = (A * fx * fx + 2 * B * fx * fy + C * fy * fy).min()
+                m = qmin(px, py, A, B, C, tx, ty)
+                assert m <= q_pix * (1 + 1e-9) + 1e-12                     # lower bound of every pixel of the bin
+                # ... and it IS the box minimum (the 57 x 57 sample grid misses the true minimiser by <= 1/16 px per axis)
+                assert m <= q_box * (1 + 1e-9) + 1e-12 and m >= q_box - 0.05 * q_box - (A + C + 2 * abs(B)) / 128.0
