@@ -7,6 +7,10 @@ mapping loss per view, the isotropy regulariser, one Adam step on all Gaussian p
 update, and the exposure (keyframe) Adam step.  A mapped keyframe costs 60 such iterations + 1 prune pass (forward +
 backward, no optimiser step: configs/splat_slam.yaml:44, mapper.py:1113-1114), so  mapping frames/sec = steps/sec / 61.
 
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (re-executes under
+torch.distributed.run on 127.0.0.1); under the driver's own torch.distributed.run launch it is one of the ranks.  With
+fewer GPUs than ranks (tests on a 1-GPU box) the ranks share the GPUs and exchange through host-staged gloo.
+
 N > 1, --scaling strong (default): the 12 views of ONE iteration are split round-robin over the ranks -- the reference's
 iteration, parallelised; gradients meet in one RCCL reduce-scatter, Adam runs on each rank's 1/N slice of the Gaussians,
 an all-gather returns the parameters (ZeRO-1).  value = steps/sec / 61, no factor N.
@@ -68,7 +72,52 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the drop-in and opaque-scene legs")
     ap.add_argument("--refine-iters", type=int, default=200, help="final_refine iterations timed for refine it/s (0 = skip)")
     ap.add_argument("--profile-all", action="store_true", help="event-time every kernel kind inside the timed region (adds overhead)")
+    ap.add_argument("--refine-views", default="world", help="views per optimiser step of the timed final_refine leg on N > 1 GPUs: "
+                    "'world' (one random view per rank and step: configs[4]) or 1 (the reference's step, replicated)")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing protocol only, no GPU work (CPU test of --gpus N)")
     return ap.parse_args()
+
+
+def relaunch(args):
+    """`python bench.py --gpus N` outside a launcher: become the launcher (one process per GPU, RCCL over xGMI inside)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """The launch path without a GPU: rendezvous (gloo), the barrier-bracketed timed region, max over ranks, one line."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    seen = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"metric": "mapping frames/sec + render ms @640x480, 300k Gaussians; PSNR vs ref", "value": None, "dry_run": True,
+                          "n_gpus": world, "ranks_seen": int(seen.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * float(t.item()) / max(1, args.steps), 6), "scaling": args.scaling}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 class Bench:
@@ -78,14 +127,21 @@ class Bench:
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+        ngpu = torch.cuda.device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
+        # fewer GPUs than ranks (2 ranks on a 1-GPU box: tests): the ranks share GPUs, messages go through host memory (gloo)
+        self.staged = local_world > ngpu
+        local_rank = local_rank % ngpu
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
         self.dist = None
+        self.transport = "none"
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world)
+            dist.init_process_group("gloo" if self.staged else "nccl", rank=self.rank, world_size=self.world)
             self.dist = dist
+            self.transport = ("gloo, host-staged: %d ranks share %d GPU(s)" % (local_world, ngpu)) if self.staged else "RCCL (nccl backend)"
         from splat_slam_amd import _native as nat
         from splat_slam_amd import synthetic as syn
         self.nat, self.syn, self.lib = nat, syn, nat.lib()
@@ -118,7 +174,9 @@ class Bench:
         loop.iteration_count = 50
         if self.world > 1:
             if loop_kind == "fused":
-                loop.set_parallel(self.world, self.rank, split_views=(args.scaling == "strong"), sync=args.sync)
+                from splat_slam_amd.parallel import Comm
+                loop.set_parallel(self.world, self.rank, split_views=(args.scaling == "strong"), sync=args.sync,
+                                  comm=Comm(staged=self.staged))
             else:
                 from splat_slam_amd.parallel import GradientSync
                 loop.grad_sync = GradientSync(loop.gaussians, self.world)
@@ -135,6 +193,7 @@ class Bench:
             k -= n
 
     def barrier(self):
+        torch.cuda.synchronize()
         if self.dist is not None:
             self.dist.barrier()
         torch.cuda.synchronize()
@@ -148,7 +207,7 @@ class Bench:
         self.barrier()
         elapsed = time.perf_counter() - t0
         if self.dist is not None:
-            t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            t = torch.tensor([elapsed], device="cpu" if self.staged else self.dev, dtype=torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, host_issue
@@ -274,7 +333,13 @@ class Bench:
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(args))
+    if args.dry_run:
+        return dry_run(args)
     B = Bench(args)
+    if B.world != args.gpus and B.rank == 0:
+        print("[bench] --gpus %d but the launcher started %d rank(s): reporting n_gpus = %d" % (args.gpus, B.world, B.world), file=sys.stderr)
     world, rank, dev, intr, lib = B.world, B.rank, B.dev, B.intr, B.lib
     N = args.gaussians
     loop, cams = B.build(args.loop, args.scale_add)
@@ -303,7 +368,7 @@ def main():
         "metric": "mapping frames/sec + render ms @640x480, 300k Gaussians; PSNR vs ref",
         "value": round(value, 4), "unit": "mapped keyframes/s (61 map() iterations each)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "configs[1]-shaped: synthetic room (SURVEY 8d), %d Gaussians, %dx%d, %d views/step "
                                "(10 window + 2 random) fwd+bwd + loss + isotropy + Adam%s"
@@ -316,7 +381,20 @@ def main():
                                                  if args.sync == "zero1" else "one RCCL all-reduce of the flat gradient buffer"))},
         "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4),
         "map_iterations_per_s": round(args.steps / elapsed, 2),
+        "world_size_seen": (B.dist.get_world_size() if B.dist is not None else 1), "transport": B.transport,
     }
+    if world > 1 and args.loop == "fused" and args.refine_iters > 0:
+        # configs[4]: global map refinement over the ranks (mapper.py:656-708 with one random view per RANK and optimiser step,
+        # ZeRO-1 exchange) -- renders/s of the whole job; --refine-views 1 times the reference's single-view step, replicated
+        g = world if args.refine_views == "world" else int(args.refine_views)
+        loop.final_refine(iters=5 * g, views_per_step=g)
+        B.barrier()
+        a = time.perf_counter()
+        loop.final_refine(iters=args.refine_iters, views_per_step=g)
+        B.barrier()
+        dt = time.perf_counter() - a
+        out["refine"] = {"views_per_step": g, "renders_per_s": round(args.refine_iters / dt, 1),
+                         "optimiser_steps_per_s": round(args.refine_iters / g / dt, 1)}
     if kernel_ms is not None:
         out["kernel_ms"] = kernel_ms
 

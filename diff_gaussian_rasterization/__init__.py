@@ -5,12 +5,24 @@ gfx950 kernels in libsplat_hip.so through the C ABI of include/splat_hip.h.
 
 The upstream package (rmurai0610/diff-gaussian-rasterization-w-pose @ 43e21bf) is CUDA; this one is MI355X only.
 There is no CPU / eager fallback: CPU tensors or a missing library raise.
+
+How a mapping iteration runs through it (src/mapper.py:426-490: up to 12 render() calls, their losses summed, ONE
+loss.backward()).  Every forward is one C-ABI call (four launches).  The backward is BATCHED: the renders of one iteration
+receive the same parameter tensors, so the first of them routes those tensors through an identity autograd node (the
+"collector") whose aliases all of them consume.  A view's own backward node then only records the image gradients it was
+handed and returns no gradient for the shared inputs; autograd runs the collector's backward exactly once, after the last
+of them -- and there ONE sgr_backward_views call does the tile backward, the projection backward and the gather of all
+views (one launch per stage) and returns the five summed gradients.  Per view that replaces two launches, six dense
+[N, .] gradient tensors and their accumulation by the autograd engine.  Views whose inputs are not shared (the caller
+recomputes its activations per render) form batches of one: same results, no saving.  SPLAT_RASTER_BATCH=0 switches the
+batching off (every view returns its own dense gradients, as upstream does).
 """
 # flake8: noqa: E501
 from typing import NamedTuple
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -41,21 +53,30 @@ class GaussianRasterizationSettings(NamedTuple):
 #   saved   : one block per forward call (up to 12 forwards are outstanding before one backward, mapper.py:426-490),
 #             leased from a per-shape pool and handed back when autograd drops the graph node -- a block that went through
 #             a forward has clean per-tile counters, so the library skips its zeroing launch
-#   scratch : one growing block per device, shared by all calls on the stream
-#   capacity: number of (8x8 tile, Gaussian) pairs the blocks are sized for = max(1 Mi, 4x the largest pair count seen so
-#             far): 288 GB of HBM make that head-room free (4 B + 56 B of scratch per pair), and the pair count of a map
-#             drifts by per cents between calls while different cameras of one map differ by small factors.
-# No host synchronisation in the steady state: the pair count R of a forward comes back through a 64-byte asynchronous copy
-# of the saved block's header into a pinned ring, read at the start of a LATER forward.  Only the first forward of a new MAP
-# (another `means3D` storage or another N: a densification, a different model) waits for its R.  A forward that still finds
-# the capacity too small drops pairs and the next call raises.  SPLAT_RASTER_SYNC=1 makes every forward wait (upstream's
-# behaviour: never drops anything).
+#   scratch : a pool of blocks per device: block 0 serves every forward (and an unbatched backward); the batched backward
+#             hands view v block v (its partial slots and gradient records must outlive the launch of the other views)
+#   capacity: number of (8x8 tile, Gaussian) pairs the blocks are sized for = max(1 Mi, 8 x N, 512 x tiles, 4 x the largest pair
+#             count seen so far): 288 GB of HBM make that head-room free (4 B of saved and 72 B of scratch per pair), a map's pair
+#             count drifts by per cents between calls, cameras of one map differ by small factors, and a view of a SLAM map with
+#             more than 8 bins per Gaussian or lists of 512 on EVERY tile does not occur.
+# Upstream never drops a pair (it sizes its buffers inside the call, with a host synchronisation per forward).  Here:
+#   * the first forward of a new map (another N or another `means3D` storage) waits for its pair count R like upstream does;
+#   * later forwards are asynchronous: R comes back through a 64-byte copy of the saved block's header into a pinned ring;
+#   * the headers of all forwards of an iteration are checked INSIDE loss.backward(), before any gradient is produced: a
+#     forward that exceeded the capacity (its image was rendered from truncated lists) raises there -- the optimiser has not
+#     stepped, nothing was consumed silently -- and the capacity is raised for the re-run.  Forward-only renders are checked by
+#     the next call.  SPLAT_RASTER_SYNC=1 makes every forward wait for R and re-run in place: upstream's guarantee, at a
+#     host synchronisation per forward.
 # ----------------------------------------------------------------------------------------------------------------
 SYNC = os.environ.get("SPLAT_RASTER_SYNC", "0") == "1"
+BATCH = os.environ.get("SPLAT_RASTER_BATCH", "1") != "0"
 _RING = 64
 _SENTINEL = 0xFFFFFFFF
 _CAP_FLOOR = 1 << 20
 _CAP_FACTOR = 4
+_OVERFLOW_MSG = ("a rasterizer forward exceeded the (tile, Gaussian) pair capacity: its image was rendered from truncated tile lists. "
+                 "No gradient has been produced and the capacity has been raised -- re-run the iteration "
+                 "(SPLAT_RASTER_SYNC=1 sizes every forward synchronously and never drops pairs)")
 
 
 class _Lease:
@@ -73,18 +94,25 @@ class _Lease:
 class _DeviceState:
     def __init__(self, dev):
         self.dev = dev
-        self.scratch = None
+        self.scratch = []                 # blocks of the current scratch size
+        self.scratch_bytes = 0
         self.capacity = _CAP_FLOOR
         self.sizes = {}
         self.pools = {}
         self.last_map = None
         self.last_pairs = 0               # pair count of the most recent forward whose header has arrived
+        self.longest_list = 0             # longest per-tile list of recent forwards (header word 10): picks the sort build
         self.ring = torch.empty((_RING, 16), dtype=torch.int32, pin_memory=True)   # headers of recent forwards
         self.ring_np = self.ring.numpy().view("uint32")
         self.ring_ptr = self.ring.data_ptr()
         self.pending = []          # (slot, capacity the forward ran with)
         self.next_slot = 0
         self.overflowed = 0
+        self.unreported = 0        # forwards found truncated that no caller has been told about yet
+        self.batch = None          # the batch forwards currently join (see _Batch)
+
+    def floor_for(self, N, ntiles):
+        return max(_CAP_FLOOR, 8 * N, 512 * ntiles)
 
     def bytes_for(self, N, H, W, cap):
         key = (N, H, W, cap)
@@ -96,6 +124,14 @@ class _DeviceState:
                 self.sizes.clear()
             self.sizes[key] = v
         return v
+
+    def scratch_block(self, k, nbytes):
+        """Scratch block k (0 = the one every forward uses), at least `nbytes` large."""
+        if nbytes > self.scratch_bytes:
+            self.scratch, self.scratch_bytes = [], nbytes
+        while len(self.scratch) <= k:
+            self.scratch.append(torch.empty(self.scratch_bytes, dtype=torch.uint8, device=self.dev))
+        return self.scratch[k]
 
     def lease(self, N, H, W, cap, saved_bytes):
         key = (N, H, W, cap)
@@ -122,13 +158,23 @@ class _DeviceState:
                 self.pending.pop(0)
                 raise RuntimeError("more than 65280 splats on one 8x8 tile: the map has degenerated")
             self.last_pairs = R
+            self.longest_list = max(int(self.ring_np[slot, 10]), (self.longest_list * 7) // 8)     # (decays when lists shrink)
             if _CAP_FACTOR * R > self.capacity:
                 self.capacity = _CAP_FACTOR * R
             if R > cap:
                 bad += 1
             self.pending.pop(0)
         self.overflowed += bad
+        self.unreported += bad
         return bad
+
+    def report(self, wait=False):
+        """Raises if a forward since the last report dropped pairs (checked without waiting unless `wait`)."""
+        if self.pending:
+            self.drain(wait)
+        if self.unreported:
+            self.unreported = 0
+            raise RuntimeError(_OVERFLOW_MSG)
 
     def post(self, saved_ptr, cap, stream):
         if len(self.pending) >= _RING - 1:
@@ -164,20 +210,9 @@ def _empty_to_none(t):
 
 
 def _settings_struct(rs, N, M, bg, view, proj, praw, campos):
-    s = nat.SgrSettings()
-    s.num_gaussians = N
-    s.image_height = int(rs.image_height)
-    s.image_width = int(rs.image_width)
-    s.sh_degree = int(rs.sh_degree)
-    s.sh_coeffs = M
-    s.tanfovx = float(rs.tanfovx)
-    s.tanfovy = float(rs.tanfovy)
-    s.scale_modifier = float(rs.scale_modifier)
-    s.prefiltered = int(bool(rs.prefiltered))
-    s.debug = int(bool(rs.debug))
-    s.bg, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.campos = (
-        bg.data_ptr(), view.data_ptr(), proj.data_ptr(), praw.data_ptr(), campos.data_ptr())
-    return s
+    return nat.SgrSettings(N, int(rs.image_height), int(rs.image_width), int(rs.sh_degree), M, float(rs.tanfovx), float(rs.tanfovy),
+                           float(rs.scale_modifier), int(bool(rs.prefiltered)), int(bool(rs.debug)), bg.data_ptr(), view.data_ptr(),
+                           proj.data_ptr(), praw.data_ptr(), campos.data_ptr())
 
 
 def _stream_of(dev):
@@ -186,10 +221,113 @@ def _stream_of(dev):
     return torch.cuda.current_stream().cuda_stream
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# batched backward
+# ----------------------------------------------------------------------------------------------------------------
+class _ViewRecord:
+    """What the collector needs from one forward to run its backward later."""
+    __slots__ = ("settings", "keep", "radii", "lease", "cap", "saved_bytes", "H", "W", "grad_color", "grad_depth", "arena",
+                 "means2D", "theta", "rho", "armed", "__weakref__")
+
+
+class _Batch:
+    """The forwards that share one set of input tensors (the renders of a mapping iteration).  `inputs` holds the caller's
+    tensors (identity decides membership: objects, not id()s), `alias` the collector's outputs the forwards consume.
+    A record belongs to its forward's autograd node (a render whose outputs are dropped frees its saved block right away,
+    however long the batch lives: an evaluation loop renders thousands of views of one parameter set); the batch only
+    holds the records whose backward has been called (`armed`) until the collector has used them."""
+    __slots__ = ("inputs", "versions", "alias", "armed", "closed", "dev", "N", "M", "__weakref__")
+
+    def matches(self, tensors):
+        return (not self.closed and len(tensors) == len(self.inputs) and all(a is b for a, b in zip(self.inputs, tensors))
+                and all(t._version == v for t, v in zip(tensors, self.versions)))
+
+
+class _Collect(torch.autograd.Function):
+    """Identity on (means3D, sh, opacities, scales, rotations).  Its backward runs once per backward pass, after every view
+    that consumed its outputs has recorded its image gradients: the batched backward of all of them happens here."""
+
+    @staticmethod
+    def forward(ctx, batch, means3D, sh, opacities, scales, rotations):
+        ctx.batch_ref = weakref.ref(batch)     # (weak: batch -> aliases -> this node -> ctx must not close a cycle that pins HBM)
+        ctx.set_materialize_grads(False)
+        return means3D.detach(), sh.detach(), opacities.detach(), scales.detach(), rotations.detach()
+
+    @staticmethod
+    def backward(ctx, g_means3D, g_sh, g_opac, g_scales, g_rot):
+        batch = ctx.batch_ref()
+        if batch is None:
+            raise RuntimeError("diff_gaussian_rasterization: the renders of this backward pass are gone")
+        grads = _batched_backward(batch)
+        extra = (g_means3D, g_sh, g_opac, g_scales, g_rot)      # (somebody else differentiated through the aliases: rare)
+        out = tuple(g if e is None else g + e for g, e in zip(grads, extra))
+        return (None,) + out
+
+
+def _batched_backward(batch):
+    if batch.closed:
+        raise RuntimeError("diff_gaussian_rasterization: backward through the renders of this parameter set a second time "
+                           "(their workspaces were released by the first backward; render again, or set SPLAT_RASTER_BATCH=0)")
+    batch.closed = True
+    lib = nat.lib()
+    dev = batch.dev
+    st = _state(dev)
+    if st.batch is batch:
+        st.batch = None
+    views, batch.armed = batch.armed, []
+    means3D, sh, opacities, scales, rotations = batch.alias
+    N, M = batch.N, batch.M
+    # every forward of this iteration has its header on the way: make sure none of them dropped pairs BEFORE producing gradients
+    st.report(wait=True)
+    # ONE arena for the five summed gradients (each written in full by the gather pass)
+    widths = (3, 3 * M, 1, 3, 4)
+    arena = torch.empty(N * sum(widths), dtype=torch.float32, device=dev)
+    parts, o = [], 0
+    for w_ in widths:
+        parts.append(arena[o:o + N * w_])
+        o += N * w_
+    d_means3D, d_sh, d_opac, d_scales, d_rot = parts
+    stream = _stream_of(dev)
+    inp = nat.SgrInputs(means3D.data_ptr(), opacities.data_ptr(), sh.data_ptr(), None, scales.data_ptr(), rotations.data_ptr(), None)
+    gi = nat.SgrGradInputs(d_means3D.data_ptr(), None, d_opac.data_ptr(), d_sh.data_ptr(), None, d_scales.data_ptr(), d_rot.data_ptr(),
+                           None, None)
+    nv = len(views)
+    arr = (nat.SgrBackwardView * max(1, nv))()
+    keep = []
+    for k, r in enumerate(views):
+        _, scratch_bytes = st.bytes_for(N, r.H, r.W, r.cap)
+        sc = st.scratch_block(k, scratch_bytes)
+        keep.append(sc)
+        bv = arr[k]
+        bv.settings = r.settings
+        bv.radii = r.radii.data_ptr()
+        bv.ws = nat.SgrWorkspace(r.lease.block.data_ptr(), r.saved_bytes, sc.data_ptr(), sc.numel(), r.cap)
+        bv.dL_dcolor = r.grad_color.data_ptr()
+        bv.dL_ddepth = None if r.grad_depth is None else r.grad_depth.data_ptr()
+        bv.dL_dmeans2D = r.arena.data_ptr()
+        bv.dL_dtau = r.arena.data_ptr() + 12 * N
+    if nv == 0:
+        arena.zero_()
+    else:
+        nat.check(lib.sgr_backward_views(nv, arr, C.byref(inp), C.byref(gi), stream), "sgr_backward_views")
+    # the per-view gradients (means2D, pose) were RETURNED by the views' own backward nodes as zero tensors before this launch
+    # filled them.  Where autograd kept that very tensor as `.grad` (a fresh leaf: it steals a gradient nobody else references)
+    # the values are in place now; where it copied or accumulated (an existing `.grad`, a retained non-leaf), the copy holds
+    # zeros + whatever was there before: add the values.
+    for r in views:
+        for p, off, n in ((r.means2D, 0, 3 * N), (r.rho, 3 * N, 3), (r.theta, 3 * N + 3, 3)):
+            if p is None:
+                continue
+            g = p.grad
+            if g is not None and g.data_ptr() != r.arena.data_ptr() + 4 * off:
+                g.add_(r.arena[off:off + n].view(g.shape))
+    return d_means3D.view(means3D.shape), d_sh.view(sh.shape), d_opac.view(opacities.shape), d_scales.view(scales.shape), d_rot.view(rotations.shape)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
-                raster_settings):
+                raster_settings, batch=None):
         lib = nat.lib()
         rs = raster_settings
         if not means3D.is_cuda:
@@ -211,9 +349,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = sh.shape[1] if sh is not None else 0
         stream = _stream_of(dev)
         st = _state(dev)
-        if st.pending and st.drain():
-            raise RuntimeError("an earlier rasterizer forward exceeded the (tile, Gaussian) pair capacity and dropped pairs; "
-                               "the capacity has been raised -- re-run the step (SPLAT_RASTER_SYNC=1 never drops pairs)")
+        st.report()          # (headers that have landed; the forwards of an iteration are all waited for inside their backward)
 
         # one arena per call: colour | depth | opacity, and radii | n_touched
         HW = H * W
@@ -228,17 +364,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         out = nat.SgrOutputs(color.data_ptr(), depth.data_ptr(), opac.data_ptr(), radii.data_ptr(), n_touched.data_ptr())
         this_map = (N, means3D.data_ptr())
         wait = SYNC or this_map != st.last_map   # a new map: learn its pair count before trusting the capacity
+        ntiles = ((H + 7) // 8) * ((W + 7) // 8)
+        floor = st.floor_for(N, ntiles)
+        if st.capacity < floor:
+            st.capacity = floor
         R = C.c_int64(0)
         while True:
             cap = st.capacity
             saved_bytes, scratch_bytes = st.bytes_for(N, H, W, cap)
-            if st.scratch is None or st.scratch.numel() < scratch_bytes:
-                st.scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+            scratch = st.scratch_block(0, scratch_bytes)
             lease, clean = st.lease(N, H, W, cap, saved_bytes)
             saved = lease.block
-            ntiles = ((H + 7) // 8) * ((W + 7) // 8)
-            ws = nat.SgrWorkspace(saved.data_ptr(), saved_bytes, st.scratch.data_ptr(), st.scratch.numel(), cap, clean,
-                                  max(1, st.last_pairs // ntiles))
+            ws = nat.SgrWorkspace(saved.data_ptr(), saved_bytes, scratch.data_ptr(), scratch.numel(), cap, clean, st.longest_list)
             rc = lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(R) if wait else None, stream)
             if rc == nat.SGR_ERR_CAPACITY:
                 st.capacity = int(R.value) * _CAP_FACTOR
@@ -251,33 +388,65 @@ class _RasterizeGaussians(torch.autograd.Function):
             st.last_pairs = int(R.value)
             if R.value * _CAP_FACTOR > st.capacity:
                 st.capacity = int(R.value) * _CAP_FACTOR
-        else:
-            st.post(saved.data_ptr(), cap, stream)
+        st.post(saved.data_ptr(), cap, stream)       # (also after a synchronous forward: the header carries the longest list)
         ctx.raster_settings = rs
-        ctx.capacity = cap
-        ctx.lease = lease
         ctx.has_theta = theta is not None and theta.numel() == 3
         ctx.has_rho = rho is not None and rho.numel() == 3
+        ctx.mark_non_differentiable(radii, n_touched)
+        if batch is not None:
+            r = _ViewRecord()
+            r.settings, r.keep, r.radii, r.lease, r.cap, r.saved_bytes, r.H, r.W = s, (bg, view, proj, praw, campos), radii, lease, cap, saved_bytes, H, W
+            r.grad_color = r.grad_depth = r.arena = None
+            r.means2D = means2D if (means2D is not None and means2D.requires_grad) else None
+            r.theta = theta if (ctx.has_theta and theta.requires_grad) else None
+            r.rho = rho if (ctx.has_rho and rho.requires_grad) else None
+            r.armed = False
+            ctx.record, ctx.batch = r, batch
+            ctx.pose_like = (theta if ctx.has_theta else None, rho if ctx.has_rho else None)
+            return color, radii, depth, opac, n_touched
+        ctx.record = None
+        ctx.capacity = cap
+        ctx.lease = lease
         ctx.pose_like = (theta if ctx.has_theta else None, rho if ctx.has_rho else None)
         ctx.keep = (bg, view, proj, praw, campos)
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, saved)
-        ctx.mark_non_differentiable(radii, n_touched)
         return color, radii, depth, opac, n_touched
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_opacity, grad_n_touched):
-        lib = nat.lib()
         rs = ctx.raster_settings
+        H, W = int(rs.image_height), int(rs.image_width)
+        r = ctx.record
+        if r is not None:
+            # batched: record the image gradients, hand autograd zero tensors for this view's own leaves (filled by the collector)
+            batch = ctx.batch
+            if batch.closed:
+                raise RuntimeError("diff_gaussian_rasterization: backward through a render whose batch has already run its backward "
+                                   "(render again, or set SPLAT_RASTER_BATCH=0 for independent per-view backward passes)")
+            dev, N = batch.dev, batch.N
+            r.grad_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev) if grad_color is None else _f32c(grad_color)
+            r.grad_depth = None if grad_depth is None else _f32c(grad_depth)
+            # grad of the `opacity` image is ignored exactly like upstream (the reference never differentiates it:
+            # slam_utils.py:71-77 / :108-119)
+            r.arena = torch.zeros(3 * N + 6, dtype=torch.float32, device=dev)        # dL/dmeans2D [N,3] | rho [3] | theta [3]
+            if not r.armed:
+                r.armed = True
+                batch.armed.append(r)
+            theta_like, rho_like = ctx.pose_like
+            g_rho = r.arena[3 * N:3 * N + 3].view(rho_like.shape) if ctx.has_rho else None
+            g_theta = r.arena[3 * N + 3:].view(theta_like.shape) if ctx.has_theta else None
+            return (None, r.arena[:3 * N].view(N, 3), None, None, None, None, None, None, g_theta, g_rho, None, None)
+
+        lib = nat.lib()
         means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, saved = ctx.saved_tensors
         bg, view, proj, praw, campos = ctx.keep
         dev = means3D.device
         N = means3D.shape[0]
-        H, W = int(rs.image_height), int(rs.image_width)
         M = sh.shape[1] if sh is not None else 0
         grad_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev) if grad_color is None else _f32c(grad_color)
         grad_depth = None if grad_depth is None else _f32c(grad_depth)
-        # grad of the `opacity` image is ignored exactly like upstream (the reference never differentiates it:
-        # slam_utils.py:71-77 / :108-119)
+        st = _state(dev)
+        st.report(wait=True)
 
         # one arena for every gradient this call returns (each is written once, in full, by the gather pass)
         widths = [3, 3, 1, 3 * M if sh is not None else 0, 3 if colors_precomp is not None else 0,
@@ -296,13 +465,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         go = nat.SgrGradOutputs(grad_color.data_ptr(), nat.ptr(grad_depth))
         gi = nat.SgrGradInputs(nat.ptr(d_means3D), nat.ptr(d_means2D), nat.ptr(d_opac), nat.ptr(d_sh), nat.ptr(d_col),
                                nat.ptr(d_scales), nat.ptr(d_rot), nat.ptr(d_cov), nat.ptr(d_tau))
-        st = _state(dev)
         cap = ctx.capacity
         _, scratch_bytes = st.bytes_for(N, H, W, cap)
         stream = _stream_of(dev)
-        if st.scratch is None or st.scratch.numel() < scratch_bytes:
-            st.scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
-        ws = nat.SgrWorkspace(saved.data_ptr(), saved.numel(), st.scratch.data_ptr(), st.scratch.numel(), cap)
+        scratch = st.scratch_block(0, scratch_bytes)
+        ws = nat.SgrWorkspace(saved.data_ptr(), saved.numel(), scratch.data_ptr(), scratch.numel(), cap)
         nat.check(lib.sgr_backward(C.byref(s), C.byref(inp), radii.data_ptr(), C.byref(go), C.byref(gi), C.byref(ws), stream),
                   "sgr_backward")
         theta_like, rho_like = ctx.pose_like
@@ -311,28 +478,69 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (d_means3D.view(N, 3), d_means2D.view(N, 3), d_sh.view(N, M, 3) if d_sh is not None else None,
                 d_col.view(N, 3) if d_col is not None else None, d_opac.view(opacities.shape),
                 d_scales.view(N, 3) if d_scales is not None else None, d_rot.view(N, 4) if d_rot is not None else None,
-                d_cov.view(N, 6) if d_cov is not None else None, g_theta, g_rho, None)
+                d_cov.view(N, 6) if d_cov is not None else None, g_theta, g_rho, None, None)
+
+
+def _batchable(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+    """The batched backward covers the reference's call (gaussian_renderer/__init__.py:130-141 at sh_degree 0: shs [N,1,3],
+    scales + rotations, fp32 contiguous GPU tensors) when at least one shared input wants a gradient."""
+    if not (BATCH and torch.is_grad_enabled()) or colors_precomp is not None or cov3Ds_precomp is not None:
+        return False
+    if sh is None or scales is None or rotations is None or int(rs.sh_degree) != 0 or sh.dim() != 3 or sh.shape[1] != 1:
+        return False
+    ok = False
+    for t in (means3D, sh, opacities, scales, rotations):
+        if not (t.is_cuda and t.dtype is torch.float32 and t.is_contiguous()):
+            return False
+        ok = ok or t.requires_grad
+    return ok and means3D.shape[0] > 0
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
                         raster_settings):
+    if _batchable(means3D, sh, _empty_to_none(colors_precomp), opacities, scales, rotations, _empty_to_none(cov3Ds_precomp),
+                  raster_settings):
+        st = _state(means3D.device)
+        tensors = (means3D, sh, opacities, scales, rotations)
+        b = st.batch
+        if b is None or not b.matches(tensors):
+            b = _Batch()
+            b.inputs, b.versions = tensors, tuple(t._version for t in tensors)
+            b.armed, b.closed, b.dev, b.N, b.M = [], False, means3D.device, means3D.shape[0], sh.shape[1]
+            b.alias = _Collect.apply(b, *tensors)
+            st.batch = b
+        a = b.alias
+        return _RasterizeGaussians.apply(a[0], means2D, a[1], None, a[2], a[3], a[4], None, theta, rho, raster_settings, b)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, theta, rho, raster_settings)
+                                     cov3Ds_precomp, theta, rho, raster_settings, None)
 
 
 def check_overflow():
     """Waits for the pair counts of all forwards issued so far and raises if any of them dropped pairs."""
-    bad = 0
     for st in _states.values():
-        bad += st.drain(wait=True)
-    if bad:
-        raise RuntimeError(f"{bad} rasterizer forward(s) exceeded the pair capacity; it has been raised, re-run the step")
+        st.report(wait=True)
 
 
 class GaussianRasterizer(nn.Module):
+    """Same constructor and call as upstream.  The mapping loop builds one per render (gaussian_renderer/__init__.py:74):
+    nn.Module.__init__ (a dozen dicts, ~10 us) is deferred until something needs the Module machinery."""
+
     def __init__(self, raster_settings):
-        super().__init__()
-        self.raster_settings = raster_settings
+        object.__setattr__(self, "raster_settings", raster_settings)
+
+    def __getattr__(self, name):           # only reached for attributes that are missing
+        d = object.__getattribute__(self, "__dict__")
+        if "_parameters" not in d:
+            rs = d.pop("raster_settings", None)
+            nn.Module.__init__(self)
+            object.__setattr__(self, "raster_settings", rs)
+            return getattr(self, name)
+        return nn.Module.__getattr__(self, name)
+
+    def __call__(self, *args, **kwargs):
+        if "_parameters" in self.__dict__:
+            return nn.Module.__call__(self, *args, **kwargs)       # (hooks may have been registered)
+        return self.forward(*args, **kwargs)
 
     def markVisible(self, positions):
         """Frustum test of the upstream module (p_view.z > near plane); unused by Splat-SLAM."""

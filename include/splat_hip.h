@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 7
+#define SGR_ABI_VERSION 8
 
 typedef enum SgrStatus {
   SGR_OK = 0,
@@ -112,9 +112,9 @@ typedef struct SgrWorkspace {
   int32_t counters_clean;      /* != 0: the per-tile pair counters inside `saved` are zero -- every completed forward
                                   (same N, H, W, capacity) leaves them so; 0 for a fresh / foreign block: the library
                                   then spends one extra launch zeroing them */
-  int32_t mean_list_hint;      /* > 0: the caller's estimate of the mean number of pairs per 8x8 tile (e.g. the last pair count
-                                  it saw / tiles): picks the in-LDS sort build of the compositing kernels.  0: derived from
-                                  `capacity` (right when the capacity is ~2x the expected pair count) */
+  int32_t max_list_hint;       /* > 0: the LONGEST per-8x8-tile list the caller has measured for these cameras (header word 10 of a
+                                  recent forward, sgr_query_header): picks the sort build of the compositing kernels -- a
+                                  deterministic function of a measurement.  0: guessed from `capacity` / tiles */
 } SgrWorkspace;
 
 typedef struct SgrGradOutputs {
@@ -168,11 +168,39 @@ int sgr_backward(const SgrSettings* settings, const SgrInputs* in, const int32_t
                  const SgrGradOutputs* grad_out, const SgrGradInputs* grad_in,
                  const SgrWorkspace* ws, void* stream);
 
+/* The backward of SEVERAL forwards that share the Gaussian inputs, in one host call and -- when the views share N, H, W, the
+ * view-independent settings and the capacity, and have private scratch blocks -- one launch per stage: what a mapping
+ * iteration's loss.backward() asks of the rasterizer (src/mapper.py:426-490: up to 12 forwards, then ONE backward).  The
+ * per-Gaussian gradients in `grad_in` are the SUMS over the views (written in full when grad_in->accumulate == 0, added
+ * otherwise); every view additionally receives its own dL_dmeans2D ([N,3]; only rows of Gaussians with radii > 0 are written:
+ * pass a zeroed buffer) and dL_dtau ([6]).  grad_in->dL_dmeans2D / dL_dtau are ignored.  The drop-in package's autograd
+ * collector calls this once per backward pass. */
+typedef struct SgrBackwardView {
+  SgrSettings settings;
+  const int32_t* radii;        /* [N] as written by the view's sgr_forward */
+  SgrWorkspace ws;             /* the view's saved block + a scratch block of its own */
+  const float* dL_dcolor;      /* [3,H,W] */
+  const float* dL_ddepth;      /* [1,H,W] or NULL */
+  float* dL_dmeans2D;          /* [N,3] zero-initialised by the caller, or NULL */
+  float* dL_dtau;              /* [6] or NULL */
+} SgrBackwardView;
+int sgr_backward_views(int32_t num_views, const SgrBackwardView* views, const SgrInputs* in, const SgrGradInputs* grad_in,
+                       void* stream);
+
+/* add_densification_stats + the max_radii2D update of one view (gaussian_model.py:738-742, src/mapper.py:522-529) in one pass:
+ * for every Gaussian with radii > 0: grad_accum += |dL_dmeans2D[i, :2]|, denom += 1, max_radii = max(max_radii, radii). */
+int sgr_densify_stats(int64_t n, const float* dL_dmeans2D, const int32_t* radii, float* stat_grad_accum, float* stat_denom,
+                      float* stat_max_radii, void* stream);
+
 /* Synchronous read-back of (pair count, overflow flag) from a saved block produced by sgr_forward. */
 int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_host, void* stream);
 
-/* Asynchronous variant: enqueues a 64-byte copy of the saved block's header (uint32 words: [0] pair count R, [1] overflow
- * flag, [2] pairs binned, [3] visible Gaussians, [4] over-full tiles, [5..14] internal, [15] zero) into PINNED host memory on `stream`.
+/* The whole 64-byte header of a saved block, synchronously: uint32 words [0] pair count R the workspace must hold (the larger of
+ * pairs binned and partial slots reserved), [1] overflow flag, [2] pairs sorted, [3] visible Gaussians, [4] tiles with more
+ * than 64 pairs, [5..8] internal, [9] pairs actually binned, [10] longest per-tile list, [11..14] internal, [15] zero. */
+int sgr_query_header(const void* saved, uint32_t words_host[16], void* stream);
+
+/* Asynchronous variant: enqueues a 64-byte copy of the same header into PINNED host memory on `stream`.
  * The caller pre-sets word 15 to a non-zero sentinel and knows the copy has landed when it reads 0 there: a later call can
  * then learn R without ever waiting (the drop-in package sizes its capacity this way). */
 int sgr_header_to_host(const void* saved, void* pinned_host64, void* stream);

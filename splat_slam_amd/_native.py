@@ -35,7 +35,7 @@ class SgrOutputs(C.Structure):
 
 class SgrWorkspace(C.Structure):
     _fields_ = [("saved", _fp), ("saved_bytes", C.c_size_t), ("scratch", _fp), ("scratch_bytes", C.c_size_t),
-                ("capacity", C.c_int64), ("counters_clean", C.c_int32), ("mean_list_hint", C.c_int32)]
+                ("capacity", C.c_int64), ("counters_clean", C.c_int32), ("max_list_hint", C.c_int32)]
 
 
 class SgrGradOutputs(C.Structure):
@@ -53,6 +53,11 @@ class SgrMapView(C.Structure):
     _fields_ = [("settings", SgrSettings), ("out", SgrOutputs), ("ws", SgrWorkspace), ("gt_image", _fp), ("gt_depth", _fp),
                 ("exposure_a", _fp), ("exposure_b", _fp), ("loss", _fp), ("dL_dimage", _fp), ("dL_ddepth", _fp),
                 ("dL_dexposure", _fp), ("dL_dtau", _fp), ("loss_scratch", _fp), ("loss_scratch_bytes", C.c_size_t)]
+
+
+class SgrBackwardView(C.Structure):
+    _fields_ = [("settings", SgrSettings), ("radii", _fp), ("ws", SgrWorkspace), ("dL_dcolor", _fp), ("dL_ddepth", _fp),
+                ("dL_dmeans2D", _fp), ("dL_dtau", _fp)]
 
 
 class SgrAdamGroup(C.Structure):
@@ -98,7 +103,10 @@ SIGNATURES = {
                               C.POINTER(SgrWorkspace), C.POINTER(C.c_int64), _fp]),
     "sgr_backward": (C.c_int, [C.POINTER(SgrSettings), C.POINTER(SgrInputs), _fp, C.POINTER(SgrGradOutputs),
                                C.POINTER(SgrGradInputs), C.POINTER(SgrWorkspace), _fp]),
+    "sgr_backward_views": (C.c_int, [C.c_int32, C.POINTER(SgrBackwardView), C.POINTER(SgrInputs), C.POINTER(SgrGradInputs), _fp]),
+    "sgr_densify_stats": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sgr_query": (C.c_int, [_fp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _fp]),
+    "sgr_query_header": (C.c_int, [_fp, C.POINTER(C.c_uint32), _fp]),
     "sgr_header_to_host": (C.c_int, [_fp, _fp, _fp]),
     "sgr_query_stats": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(C.c_int64), _fp]),
     "sgr_query_depth_keys": (C.c_int, [C.POINTER(SgrWorkspace), C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp]),
@@ -156,7 +164,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.sgr_abi_version() != 7:
+        if h.sgr_abi_version() != 8:
             raise ImportError("libsplat_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -210,7 +210,7 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
     if ((int64_t)R > L.cap) return set_error(SGR_ERR_CAPACITY, "%u (tile, Gaussian) pairs exceed capacity %lld", R, (long long)L.cap);
   }
   LOff d1 = L.dev();
-  d1.mean_hint = ws->mean_list_hint;
+  d1.mean_hint = ws->max_list_hint;
   launch_blend_fwd(tab, 1, d1, s->bg, nullptr, nullptr, st);          // K4: per-tile sort + compositing
   HIP_TRY(hipGetLastError());
   return SGR_OK;
@@ -240,6 +240,102 @@ int sgr_backward(const SgrSettings* s, const SgrInputs* in, const int32_t* radii
   Common cm = make_common(s);
   launch_blend_bwd(tab, 1, d, s->bg, nullptr, nullptr, st);
   launch_preprocess_bwd(tab, 1, d, cm, *in, *gi, nullptr, st);
+  HIP_TRY(hipGetLastError());
+  return SGR_OK;
+}
+
+}  // extern "C"
+
+__global__ void __launch_bounds__(256) densify_stats_kernel(int64_t n, const float* __restrict__ m2, const int32_t* __restrict__ radii,
+                                                            float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ maxr) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = radii[i];
+  if (r <= 0) return;
+  const F3 g = ld3(m2 + 3 * i);
+  accum[i] += sqrtf(g.x * g.x + g.y * g.y);
+  denom[i] += 1.f;
+  maxr[i] = fmaxf(maxr[i], (float)r);
+}
+
+extern "C" {
+
+int sgr_densify_stats(int64_t n, const float* dL_dmeans2D, const int32_t* radii, float* stat_grad_accum, float* stat_denom,
+                      float* stat_max_radii, void* stream) {
+  if (n < 0 || (n > 0 && (!dL_dmeans2D || !radii || !stat_grad_accum || !stat_denom || !stat_max_radii)))
+    return set_error(SGR_ERR_INVALID, "densify_stats: null argument");
+  if (n > 0)
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, dL_dmeans2D, radii,
+                       stat_grad_accum, stat_denom, stat_max_radii);
+  HIP_TRY(hipGetLastError());
+  return SGR_OK;
+}
+
+int sgr_backward_views(int32_t num_views, const SgrBackwardView* views, const SgrInputs* in, const SgrGradInputs* grad_in, void* stream) {
+  if (num_views < 0 || (num_views > 0 && (!views || !in || !grad_in))) return set_error(SGR_ERR_INVALID, "backward_views: null argument");
+  if (num_views == 0) return SGR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const SgrBackwardView& f = views[0];
+  bool uniform = in->shs && in->scales && in->rotations && !in->colors_precomp && !in->cov3D_precomp && f.settings.sh_degree == 0 &&
+                 f.settings.num_gaussians > 0;
+  for (int v = 0; v < num_views; ++v) {
+    const SgrBackwardView& m = views[v];
+    if (int rc = check_settings(&m.settings, in)) return rc;
+    if (!m.dL_dcolor || (m.settings.num_gaussians > 0 && !m.radii)) return set_error(SGR_ERR_INVALID, "backward_views: dL_dcolor and radii are required");
+    uniform = uniform && m.settings.num_gaussians == f.settings.num_gaussians && m.settings.image_height == f.settings.image_height &&
+              m.settings.image_width == f.settings.image_width && m.settings.tanfovx == f.settings.tanfovx &&
+              m.settings.tanfovy == f.settings.tanfovy && m.settings.scale_modifier == f.settings.scale_modifier &&
+              m.settings.sh_degree == f.settings.sh_degree && m.settings.sh_coeffs == f.settings.sh_coeffs &&
+              m.settings.bg == f.settings.bg && m.settings.projmatrix_raw == f.settings.projmatrix_raw && m.ws.capacity == f.ws.capacity;
+    for (int u = 0; u < v; ++u) uniform = uniform && views[u].ws.scratch != m.ws.scratch && views[u].ws.saved != m.ws.saved;
+  }
+  SgrGradInputs g = *grad_in;
+  g.dL_dmeans2D = nullptr;
+  g.dL_dtau = nullptr;
+  if (!uniform) {
+    // one view after the other: the first call defines every element (unless the caller accumulates), the others add
+    for (int v = 0; v < num_views; ++v) {
+      const SgrBackwardView& m = views[v];
+      const int N = m.settings.num_gaussians;
+      Layout L = make_layout(N, m.settings.image_height, m.settings.image_width, m.ws.capacity);
+      if (int rc = check_workspace(&m.ws, L)) return rc;
+      if (N == 0) {
+        if (m.dL_dtau) HIP_TRY(hipMemsetAsync(m.dL_dtau, 0, 24, st));
+        continue;
+      }
+      ViewTab tab = {};
+      tab_set_view(tab, 0, &m.settings, nullptr, &m.ws);
+      tab.radii[0] = const_cast<int32_t*>(m.radii);
+      tab.dL_dcolor[0] = m.dL_dcolor; tab.dL_ddepth[0] = m.dL_ddepth; tab.dL_dtau[0] = m.dL_dtau; tab.dL_dmeans2D[0] = m.dL_dmeans2D;
+      SgrGradInputs gv = g;
+      gv.accumulate = (grad_in->accumulate || v > 0) ? 1 : 0;
+      Common cm = make_common(&m.settings);
+      LOff d = L.dev();
+      launch_blend_bwd(tab, 1, d, m.settings.bg, nullptr, nullptr, st);
+      launch_preprocess_bwd(tab, 1, d, cm, *in, gv, nullptr, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return SGR_OK;
+  }
+  Layout L = make_layout(f.settings.num_gaussians, f.settings.image_height, f.settings.image_width, f.ws.capacity);
+  LOff d = L.dev();
+  Common cm = make_common(&f.settings);
+  for (int base = 0; base < num_views; base += kMaxViews) {
+    const int nv = num_views - base < kMaxViews ? num_views - base : kMaxViews;
+    ViewTab tab = {};
+    for (int v = 0; v < nv; ++v) {
+      const SgrBackwardView& m = views[base + v];
+      if (int rc = check_workspace(&m.ws, L)) return rc;
+      tab_set_view(tab, v, &m.settings, nullptr, &m.ws);
+      tab.radii[v] = const_cast<int32_t*>(m.radii);
+      tab.dL_dcolor[v] = m.dL_dcolor; tab.dL_ddepth[v] = m.dL_ddepth; tab.dL_dtau[v] = m.dL_dtau; tab.dL_dmeans2D[v] = m.dL_dmeans2D;
+    }
+    SgrGradInputs gv = g;
+    gv.accumulate = (grad_in->accumulate || base > 0) ? 1 : 0;
+    launch_blend_bwd(tab, nv, d, f.settings.bg, nullptr, nullptr, st);
+    launch_preprocess_bwd(tab, nv, d, cm, *in, gv, nullptr, st);
+  }
   HIP_TRY(hipGetLastError());
   return SGR_OK;
 }
@@ -294,7 +390,8 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
   }
   Layout L = make_layout(f.settings.num_gaussians, f.settings.image_height, f.settings.image_width, f.ws.capacity);
   LOff d = L.dev();
-  d.mean_hint = f.ws.mean_list_hint;
+  d.mean_hint = 0;
+  for (int v = 0; v < num_views; ++v) d.mean_hint = views[v].ws.max_list_hint > d.mean_hint ? views[v].ws.max_list_hint : d.mean_hint;
   Common cm = make_common(&f.settings);
   const int HW = f.settings.image_height * f.settings.image_width;
   for (int base = 0; base < num_views; base += kMaxViews) {
@@ -575,6 +672,14 @@ int sgr_profile_read(float ms_host[SGR_PROFILE_KINDS], int64_t launches_host[SGR
 int sgr_header_to_host(const void* saved, void* pinned_host64, void* stream) {
   if (!saved || !pinned_host64) return set_error(SGR_ERR_INVALID, "null argument");
   HIP_TRY(hipMemcpyAsync(pinned_host64, saved, sizeof(SavedHeader), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return SGR_OK;
+}
+
+int sgr_query_header(const void* saved, uint32_t words_host[16], void* stream) {
+  if (!saved || !words_host) return set_error(SGR_ERR_INVALID, "null argument");
+  static_assert(sizeof(SavedHeader) == 64, "header is 16 words");
+  HIP_TRY(hipMemcpyAsync(words_host, saved, sizeof(SavedHeader), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return SGR_OK;
 }
 

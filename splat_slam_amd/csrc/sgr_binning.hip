@@ -54,10 +54,11 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
     };
     uint32_t R = block1024_scan([&](int t) { return count_of(t); }, tmp, L.ntiles, red);
     __syncthreads();
-    uint32_t over = 0, saturated = 0;
+    uint32_t over = 0, saturated = 0, longest = 0;
     for (int t = threadIdx.x; t < L.ntiles; t += 1024) {
       const uint32_t s0 = tmp[t], c = count_of(t);
       saturated |= c >= kTileCountLimit ? 1u : 0u;
+      longest = c > longest ? c : longest;
       // <= kBucket pairs: K1 already binned them in the tile's bucket, the run [s0, s0+c) only addresses point_list.
       // more: scatter_kernel fills the run; .y is its fill cursor and ends at s0 + c as well.
       ranges[(size_t)t * kRngStride] = make_uint2(c <= (uint32_t)kBucket ? s0 : (s0 | kOverfull), s0 + c);
@@ -65,14 +66,19 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
     }
     over = wave_scan_add_u32(over);
     saturated = __syncthreads_or((int)saturated) ? 1u : 0u;
+    longest = (uint32_t)wave_max_i32((int)longest);
+    __shared__ uint32_t red_max[16];
+    if ((threadIdx.x & 63) == 0) red_max[threadIdx.x >> 6] = longest;
     // consumed: leave the counters clean for the next forward
     for (int w = threadIdx.x; w < ((L.gy + 1) / 2) * L.gxp; w += 1024) tile_count[(size_t)w * (kCntSlotWords / 2)] = 0ull;
     if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = over;
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t tot = 0;
-      for (int wv = 0; wv < 16; ++wv) tot += red[wv];
+      uint32_t mx = 0;
+      for (int wv = 0; wv < 16; ++wv) { tot += red[wv]; mx = red_max[wv] > mx ? red_max[wv] : mx; }
       hdr->num_overfull = tot;
+      hdr->max_tile_count = mx;
       hdr->ovf_count = hdr->ovf_cursor;          // K1 is done appending; leave the cursor clean for the next forward
       hdr->ovf_cursor = 0u;
       hdr->num_rendered = R;

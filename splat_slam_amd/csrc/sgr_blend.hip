@@ -26,9 +26,12 @@
 
 namespace sgr {
 
-// keys sorted inside the wave's LDS slice: three builds of the forward kernel, picked per launch from the expected
-// list length (capacity / tiles): "light" keeps 8 workgroups per CU resident, "mid" 3, "heavy" 1 (LDS for occupancy).
-constexpr int kSortLight = 256, kSortMid = 1024, kSortHeavy = 4096;
+// Lists the wave sorts on chip: three builds of the forward kernel, picked per launch from the LONGEST list the caller has
+// measured for these cameras (SgrWorkspace.max_list_hint).  "light": up to 512 keys sorted IN REGISTERS (below), only the
+// sorted Gaussian indices (4 B each) go to LDS -- 5 workgroups per CU stay resident and it is the build that runs forward
+// and backward of a tile in one wave; "mid" / "heavy": 1024 / 4096 64-bit keys bitonic in LDS (3 / 1 workgroups per CU).
+constexpr int kSortLight = 512, kSortMid = 1024, kSortHeavy = 4096;
+constexpr bool sort_in_registers(int sort_max) { return sort_max <= kSortLight; }
 
 // workgroup -> 16x16 super tile with an XCD-aware remap: hardware places block b on XCD b%8, we hand every XCD a
 // contiguous run of super tiles so neighbouring tiles (which share Gaussians) hit the same 4 MiB L2.
@@ -58,6 +61,71 @@ __device__ __forceinline__ void wave_sort_any(int n, int lane, LD load, ST store
       sync();
     }
   }
+}
+
+// ---- register-blocked bitonic sort of 64 * KPL keys: lane l holds elements l * KPL .. l * KPL + KPL - 1.  A stage of stride j
+// compares elements e and e ^ j: for j < KPL both live in the same lane's registers (no data movement at all), for j >= KPL the
+// partner is the same register of lane l ^ (j / KPL): one DPP quad_perm (lane ^ 1, lane ^ 2), ds_swizzle (^ 4, 8, 16) or
+// ds_bpermute (^ 32) per dword -- no LDS storage, no barrier, no index arithmetic.  256 keys: 15 of the 36 stages stay in
+// registers; the LDS-resident network this replaces spent ~40 instructions per stage (index arithmetic + two round trips +
+// a fence): half of a 129..256-entry tile's forward.  Padding keys (~0) sort to the end.
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
+  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);        // quad_perm:[1,0,3,2]
+  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+  else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | (M << 10));          // bit mode: xor mask M
+  else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ M) << 2, (int)v);
+}
+template <int KPL, int KK, int J>
+struct SortStage {
+  static __device__ __forceinline__ void run(uint64_t (&k)[KPL], int lane) {
+    if constexpr (J < KPL) {
+#pragma unroll
+      for (int r = 0; r < KPL; ++r) {
+        if ((r & J) != 0) continue;
+        // block of KK elements ascending iff (e & KK) == 0, e = lane * KPL + r
+        // (keys are unique up to the ~0 padding, so "a < b" is "not b < a": ONE compare, the direction is an xor of lane masks)
+        const bool down = KK < KPL ? ((r & KK) != 0) : (((lane * KPL) & KK) != 0);
+        const uint64_t a = k[r], b = k[r | J];
+        const bool sw = (b < a) != down;
+        k[r] = sw ? b : a;
+        k[r | J] = sw ? a : b;
+      }
+    } else {
+      constexpr int M = J / KPL;
+      const bool lower = (lane & M) == 0;
+      const bool up = ((lane * KPL) & KK) == 0;
+      const bool keep_max = lower != up;
+#pragma unroll
+      for (int r = 0; r < KPL; ++r) {
+        const uint64_t mine = k[r];
+        const uint64_t other = ((uint64_t)lane_xor<M>((uint32_t)(mine >> 32), lane) << 32) | lane_xor<M>((uint32_t)mine, lane);
+        const bool take = (other < mine) != keep_max;
+        k[r] = take ? other : mine;
+      }
+    }
+    if constexpr (J > 1) SortStage<KPL, KK, J / 2>::run(k, lane);
+  }
+};
+template <int KPL, int KK>
+struct SortMerge {
+  static __device__ __forceinline__ void run(uint64_t (&k)[KPL], int lane) {
+    SortStage<KPL, KK, KK / 2>::run(k, lane);
+    if constexpr (KK < kWave * KPL) SortMerge<KPL, KK * 2>::run(k, lane);
+  }
+};
+// sorts keys_in[0..count) (count <= 64 * KPL) and leaves the sorted Gaussian indices (low words) in ids[0..64 * KPL)
+template <int KPL>
+__device__ __forceinline__ void wave_sort_registers(const uint64_t* __restrict__ keys_in, int count, int lane, uint32_t* ids /*LDS*/) {
+  uint64_t k[KPL];
+#pragma unroll
+  for (int r = 0; r < KPL; ++r) {
+    const int e = lane * KPL + r;
+    k[r] = e < count ? keys_in[e] : ~0ull;
+  }
+  SortMerge<KPL, 2>::run(k, lane);
+#pragma unroll
+  for (int r = 0; r < KPL; ++r) ids[lane * KPL + r] = (uint32_t)k[r];
 }
 
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot); both blend kernels use 2-vectors
@@ -197,12 +265,8 @@ __device__ __forceinline__ float group_shr1<4>(float v, float fill, int lane) {
 // ten sums being two small GEMMs over the pixels -- cut the instruction count by 20 % but ran 8 % slower: fp32 MFMA
 // passes contend with the VALU work of the other waves of the SIMD.)
 
-// pixel pair g (0..31) of a tile for group width GW:  p0 = 2*PP*(g/PP) + g%PP,  p1 = p0 + PP   (PP = 64/GW)
-template <int GW>
-__device__ __forceinline__ int pair_first_pixel(int g) {
-  constexpr int PP = kWave / GW;
-  return 2 * PP * (g / PP) + (g % PP);
-}
+// pixel pair g (0..31) of a tile = the horizontally adjacent pixels 2g, 2g + 1 -- ONE layout of the staged pixel state for
+// every group width, so that chunks of different widths can follow each other on the same tile (see tile_backward)
 
 // What a lane needs to know about ITS splat: footprint, colour, depth and the slot of this (tile, Gaussian) pair inside
 // the Gaussian's run of partials (0xffffffff: not stored -- beyond the capacity).
@@ -231,8 +295,9 @@ struct SrcPointList {
 };
 // fused kernel, list longer than one chunk: the sorted keys are still where the wave sorted them (LDS, or HBM for huge lists)
 struct SrcKeys {
-  const uint64_t* keys_lds; const uint64_t* __restrict__ keys_hbm; const GRec* __restrict__ grec; const char* __restrict__ saved; int tx, ty; int64_t cap;
+  const uint32_t* ids_lds; const uint64_t* keys_lds; const uint64_t* __restrict__ keys_hbm; const GRec* __restrict__ grec; const char* __restrict__ saved; int tx, ty; int64_t cap;
   __device__ __forceinline__ uint32_t gaussian(int idx) const {
+    if (ids_lds) return ids_lds[idx];           // light build: the register sort left the sorted indices
     return keys_lds ? (uint32_t)keys_lds[idx] : (uint32_t)__hip_atomic_load(keys_hbm + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ SplatRec load(int idx, const LOff& L) const { return splat_from_grec(grec, saved, L, gaussian(idx), tx, ty, cap); }
@@ -250,18 +315,19 @@ struct SrcStaged {
   }
 };
 
-// One chunk of <= GW splats against the 64 pixels of the tile, 2*64/GW pixels per iteration.
-// Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix scan.
+// One chunk = the list positions [start, start + GW) (those below `end`) against the 64 pixels of the tile, 2*64/GW pixels
+// per iteration.  Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix
+// scan.  Chunks run back to front; `carry`: more (nearer) chunks follow, leave (T, S) in front of this chunk per pixel.
 // LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | nc0,nc1, -,-) for pair g.
 template <int GW, typename SRC>
 __device__ __forceinline__ void bwd_chunk2(
-    int lane, int c, int eff, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
+    int lane, int start, int end, bool carry, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
     const LOff& L, float halfW, float halfH, float4* __restrict__ partials) {
   constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
   const int sub = lane / GW;                     // which of them this lane works on
   const int sl = lane % GW;
-  const int idx = c * GW + (GW - 1 - sl);        // list position of this lane's splat
-  const bool valid = idx < eff;
+  const int idx = start + (GW - 1 - sl);         // list position of this lane's splat
+  const bool valid = idx < end;
   float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
   uint32_t slot = 0xffffffffu;                   // this (tile, Gaussian) pair's slot inside the Gaussian's run of partials
   if (valid) {
@@ -278,10 +344,10 @@ __device__ __forceinline__ void bwd_chunk2(
     const float4 b0 = pixB2[gp * 2];
     const float2 b1 = *(const float2*)&pixB2[gp * 2 + 1];
     const int nc0 = __float_as_int(b1.x), nc1 = __float_as_int(b1.y);
-    if (GW == kWave && __builtin_amdgcn_readfirstlane(max(nc0, nc1)) <= c * kWave) continue;   // both ended before this chunk
-    const int p0 = pair_first_pixel<GW>(gp), p1 = p0 + PP;     // horizontally adjacent, or (GW = 8) vertically adjacent
-    const v2f dx = splat2(mx) - (v2f){tx0 + (float)(p0 & 7), tx0 + (float)(p1 & 7)};
-    const v2f dy = splat2(my) - (v2f){ty0 + (float)(p0 >> 3), ty0 + (float)(p1 >> 3)};
+    if (GW == kWave && __builtin_amdgcn_readfirstlane(max(nc0, nc1)) <= start) continue;   // both ended before this chunk
+    const int p0 = 2 * gp;                                     // pixels p0, p0 + 1: same row
+    const v2f dx = splat2(mx) - (v2f){tx0 + (float)(p0 & 7), tx0 + (float)((p0 & 7) + 1)};
+    const v2f dy = splat2(my) - splat2(ty0 + (float)(p0 >> 3));
     // eval_alpha() on the pair, same operation order
     const v2f adx = splat2(A) * dx;
     const v2f cdy2 = (splat2(Cc) * dy) * dy;
@@ -314,12 +380,10 @@ __device__ __forceinline__ void bwd_chunk2(
     const v2f Sc = {b0.z, b0.w};
     const v2f Sx = (Qi - q) + Sc;                        // strictly behind (+ carried chunks + background term)
     const v2f dL_dalpha = __builtin_elementwise_fma(Tj, w, -(Sx * inv1ma));
-    if (GW == kWave) {
-      // carry to the next (nearer) chunk: the last lane holds the nearest splat of this chunk
-      if (lane == kWave - 1) {
-        const v2f S2 = Qi + Sc;
-        pixB2[gp * 2] = make_float4(Tj.x, Tj.y, S2.x, S2.y);
-      }
+    if (carry && sl == GW - 1) {
+      // carry to the next (nearer) chunk: the last lane of the group holds the nearest splat of this chunk
+      const v2f S2 = Qi + Sc;
+      pixB2[gp * 2] = make_float4(Tj.x, Tj.y, S2.x, S2.y);
     }
     a_r = __builtin_elementwise_fma(aT, dCr, a_r);
     a_g = __builtin_elementwise_fma(aT, dCg, a_g);
@@ -369,36 +433,34 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
                                               const LOff& L, float4* __restrict__ partials) {
   // the background term -T_final/(1-alpha_j) * (bg . dL/dC) has the same shape as "colour behind splat j"
   pxB[1] = pxB[0] * (bg[0] * pxA[0] + bg[1] * pxA[1] + bg[2] * pxA[2]);
-  // pair layout depends on the group width (see bwd_chunk2): pixel p -> pair g, half h
-  auto stage = [&](auto gw_tag) {
-    constexpr int GW = decltype(gw_tag)::value, PP = kWave / GW;
-    const int q2 = lane % (2 * PP), h = q2 / PP, gidx = (lane / (2 * PP)) * PP + (q2 % PP);
-    float* fa = (float*)pixA + gidx * 8 + h;
-    float* fb = (float*)pixB + gidx * 8 + h;
+  // pixel p -> pair p / 2, half p % 2
+  {
+    float* fa = (float*)pixA + (lane >> 1) * 8 + (lane & 1);
+    float* fb = (float*)pixB + (lane >> 1) * 8 + (lane & 1);
     fa[0] = pxA[0]; fa[2] = pxA[1]; fa[4] = pxA[2]; fa[6] = pxA[3];
     fb[0] = pxB[0]; fb[2] = pxB[1]; fb[4] = pxB[2];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-  };
+  }
   const float halfW = 0.5f * (float)L.W, halfH = 0.5f * (float)L.H;
   const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
-  if (eff <= 4) {          // 32 pixels per iteration
-    stage(std::integral_constant<int, 4>{});
-    bwd_chunk2<4>(lane, 0, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
-  } else if (eff <= 8) {   // half of the iterations of the 16-lane form: 16 pixels per iteration
-    stage(std::integral_constant<int, 8>{});
-    bwd_chunk2<8>(lane, 0, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
-  } else if (eff <= 16) {
-    stage(std::integral_constant<int, 16>{});
-    bwd_chunk2<16>(lane, 0, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
-  } else if (eff <= 32) {
-    stage(std::integral_constant<int, 32>{});
-    bwd_chunk2<32>(lane, 0, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
-  } else {
-    stage(std::integral_constant<int, 64>{});
-    const int nchunks = (eff + kWave - 1) / kWave;
-    for (int c = nchunks - 1; c >= 0; --c) {
-      bwd_chunk2<64>(lane, c, eff, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+  // The list is cut into chunks of 64 / 32 / 16 / 8 / 4 splats from the far end: a lane = a splat, and a chunk of width GW works
+  // on 64 / GW pixel pairs at once, so a chunk costs 32 * GW / 64 iterations of the loop above whatever part of its lanes is
+  // filled.  One 64-wide chunk per started 64 splats left the lists of a converged map (33-256) at 55-75 % lane use; the
+  // remainder now takes the narrowest chunks that hold it (70 splats: 64 + 8 lanes = 36 iterations instead of 64).  A width is
+  // rounded up when the chunk would be at least 3/4 full (the per-chunk epilogue costs about one iteration).
+  int end = eff;
+  while (end > 0) {
+    const int gw = end >= 48 ? 64 : (end >= 24 ? 32 : (end >= 12 ? 16 : (end >= 5 ? 8 : 4)));
+    const int start = gw >= end ? 0 : end - gw;
+    const bool carry = start > 0;
+    if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+    else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+    else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+    else if (gw == 8) bwd_chunk2<8>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+    else bwd_chunk2<4>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+    end = start;
+    if (carry) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
@@ -415,7 +477,7 @@ __device__ __forceinline__ float sign_code(uint32_t c, float k) { return (c & 1u
 // registers and the tile's sorted splats are still staged in LDS, so the wave goes straight on with tile_backward():
 // no final_T / n_contrib / code-byte / index-list round trip through HBM, no second launch, one tile prologue.
 template <int SORT_MAX, bool FUSED>
-__global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
                                                         LossCoef lc) {
   const int vw = blockIdx.y;
   char* saved = tab.saved[vw];
@@ -431,8 +493,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   float2* __restrict__ pix_state = (float2*)(saved + L.o_final_T);
   uint32_t* __restrict__ tile_maxc = (uint32_t*)(saved + L.o_tile_maxc);
   int32_t* __restrict__ n_touched = tab.n_touched[vw];
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // per wave: SORT_MAX keys (8 B) + 64 splats x 48 B (+ FUSED: 2 x 64 float4 of pixel state)
-  constexpr size_t kSlice = (size_t)SORT_MAX * 8 + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0);
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // per wave: SORT_MAX sorted ids (4 B) or keys (8 B) + 64 splats x 48 B (+ FUSED: 2 x 64 float4 of pixel state)
+  constexpr bool REGSORT = sort_in_registers(SORT_MAX);
+  constexpr size_t kKeyBytes = REGSORT ? 4 : 8;
+  constexpr size_t kSlice = (size_t)SORT_MAX * kKeyBytes + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0);
   const int nblocks = sgx * sgy;
   const int st = super_tile_of_block(blockIdx.x, nblocks);
   if (st >= nblocks) return;
@@ -445,8 +509,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  uint64_t* keys = (uint64_t*)slice;
-  float4* lds = (float4*)(slice + SORT_MAX * 8);
+  uint64_t* keys = (uint64_t*)slice;          // mid / heavy build: the keys, sorted in place
+  uint32_t* ids = (uint32_t*)slice;           // light build: sorted Gaussian indices (the keys were sorted in registers)
+  float4* lds = (float4*)(slice + SORT_MAX * kKeyBytes);
 
   // ground truth of the fused loss epilogue: fetched NOW so that the round trip hides behind sorting and blending
   const float* __restrict__ gt_image = lt.gt_image[vw];
@@ -507,6 +572,15 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
       f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
       if (FUSED) f[22] = __uint_as_float(slot);
     }
+  } else if (REGSORT && count <= kLdsSortMax) {
+    mode = 1;                                 // 65..512 keys: sorted in registers, 2 / 4 / 8 per lane (count > 64: keys_in = the tile's run)
+    if (count <= 2 * kWave) wave_sort_registers<2>(keys_in, count, lane, ids);
+    else if (count <= 4 * kWave) wave_sort_registers<4>(keys_in, count, lane, ids);
+    else wave_sort_registers<8>(keys_in, count, lane, ids);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!FUSED)
+      for (int i = lane; i < count; i += kWave) point_list[begin + i] = ids[i];
   } else if (count <= kLdsSortMax) {
     mode = 1;
     for (int i = lane; i < count; i += kWave) keys[i] = keys_in[i];
@@ -542,7 +616,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
       uint32_t g = 0;
       if (lane < n) {
-        if (mode == 1) g = (uint32_t)keys[base + lane];
+        if (mode == 1) g = REGSORT ? ids[base + lane] : (uint32_t)keys[base + lane];
         else g = (uint32_t)__hip_atomic_load(entries + begin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float4* rec = (const float4*)(grec + g);
         m = rec[0];
@@ -668,7 +742,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
   const float k_rgb = lc.w_rgb * (lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f);     // the floats blend_bwd<true> rebuilds from the code byte
   float pxA[4] = {sign_code(code, k_rgb), sign_code(code >> 2, k_rgb), sign_code(code >> 4, k_rgb), sign_code(code >> 6, lc.w_dep)};
   float pxB[3] = {T, 0.f, __uint_as_float(last)};
-  float4* pixA = (float4*)(slice + (size_t)SORT_MAX * 8 + kWave * 48);
+  float4* pixA = (float4*)(slice + (size_t)SORT_MAX * kKeyBytes + kWave * 48);
   float4* pixB = pixA + kWave;
   if (mode == 0) {
     const SrcStaged src = {(const float*)lds};
@@ -683,7 +757,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
     if (eff == 0) return;
     tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixA, pixB, src, L, partials);
   } else {
-    const SrcKeys src = {mode == 1 ? keys : nullptr, entries + begin, grec, saved, tx, ty, cap};
+    const SrcKeys src = {mode == 1 && REGSORT ? ids : nullptr, mode == 1 && !REGSORT ? keys : nullptr, entries + begin, grec, saved, tx, ty, cap};
     for (int idx = eff + lane; idx < count; idx += kWave) {
       const uint32_t g = src.gaussian(idx);
       const float4 q0 = ((const float4*)(grec + g))[0];
@@ -700,7 +774,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(ViewTab tab, LOff L, con
 }
 
 template <bool PACKED>
-__global__ void __launch_bounds__(256) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
   const int vw = blockIdx.y;
   const char* saved = tab.saved[vw];
   const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
@@ -771,7 +845,7 @@ static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, co
                                const LossCoef& lc, hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
   int grid = ((nblocks + 7) / 8) * 8;
-  constexpr size_t lds = 4 * ((size_t)SORT_MAX * 8 + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0));
+  constexpr size_t lds = 4 * ((size_t)SORT_MAX * (sort_in_registers(SORT_MAX) ? 4 : 8) + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0));
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -780,16 +854,16 @@ static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, co
   hipLaunchKernelGGL((blend_fwd_kernel<SORT_MAX, FUSED>), dim3(grid, nviews), dim3(256), lds, st, tab, L, bg, lt, lc);
 }
 
-// 0 light / 1 mid / 2 heavy, from the expected mean list length: SgrWorkspace.mean_list_hint (x 2 for safety) when the caller
-// gives one, else capacity / tiles / 2 (the fused loop sizes `capacity` at 2x the pair count it has seen, and the pair
-// count includes the bins the footprint test drops: an over-estimate by 1.2-1.5x).  Tiles beyond the build's key count
-// fall back to the in-HBM sort, which is correct but slow.  The light build (256 keys) is kept up to an estimated mean of
-// 160: it is the one that runs forward and backward of a tile in ONE wave, and on lists of 65-256 that is worth more than
-// the rare tile that spills (opaque bench scene 1.36 -> 1.17 ms per iteration, a 60-keyframe session 66 -> 59 ms per
-// keyframe; estimated means of 160 and 256 as the limit measured the same).
+// 0 light / 1 mid / 2 heavy from the longest list the caller has MEASURED for the cameras of the batch (max_list_hint =
+// SavedHeader.max_tile_count of a recent forward): a deterministic function of a measurement, where a guess from the
+// capacity -- which depends on the probe history of the caller -- flipped the build between two runs of the same scene.
+// Without a hint the longest list is taken as 4x the mean the capacity allows for (capacity is ~2x the pair count).
+// Tiles beyond the chosen build's key count fall back to the in-HBM sort: correct, slow; the light build (the one that runs
+// forward and backward of a tile in ONE wave) is kept while the longest list exceeds its 512 keys by no more than a few
+// tiles' worth (x1.5), because fusing pays on long lists too (opaque bench scene 1.36 -> 1.17 ms per iteration).
 static int blend_build(const LOff& L) {
-  const int64_t mean_len = L.mean_hint > 0 ? 2 * (int64_t)L.mean_hint : L.cap / (2 * (int64_t)(L.ntiles > 0 ? L.ntiles : 1));
-  return mean_len > 256 ? 2 : (mean_len > 160 ? 1 : 0);
+  const int64_t longest = L.mean_hint > 0 ? (int64_t)L.mean_hint : 2 * L.cap / (int64_t)(L.ntiles > 0 ? L.ntiles : 1);
+  return longest > 3 * kSortMid / 2 ? 2 : (longest > 3 * kSortLight / 2 ? 1 : 0);
 }
 
 // lt: per-view loss pointers (gt_image[v] == NULL -> plain render).  With a loss, every 8x8 tile also leaves one

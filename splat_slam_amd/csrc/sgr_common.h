@@ -56,10 +56,14 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 // if the minimum of q over the bin's 8x8 pixel centres' bounding box exceeds tau.  K1 drops such bins from the rectangle's
 // operations (no atomic, no key, no compositing work: the axis-aligned box of the level set keeps ~15-25 % bins too many for a
 // rotated or simply round splat of a converged map); the backward skips the same bins' partial slots, which nobody wrote.
-// The two sides need NOT decide bit-identically: K1 drops a bin only beyond kFootDrop * thr, the backward skips already
-// beyond thr, and everything in between was binned, composited with alpha < 1/255 everywhere, i.e. wrote exact zeros.
+// The two sides need NOT decide bit-identically: K1 drops a bin only beyond kFootDrop * thr + kFootGuard, the backward skips
+// already beyond thr, and everything in between was binned, composited with alpha < 1/255 everywhere, i.e. wrote exact zeros.
+// kFootGuard is ABSOLUTE and twice the largest rounding error of q the test is enabled for (err_limit <= 0.006 below): the two
+// evaluations -- inlined into different kernels -- may round differently (and thr is ~0.02 for a faint splat, so a relative
+// band alone would be 4e-5), but never by more than the band; footprint_qmin() is additionally compiled without contraction.
 struct Footprint { float px, py, A, B, C, invA, invC, thr; };      // thr < 0: test disabled (rounding could decide), keep every bin
 constexpr float kFootDrop = 1.002f;
+constexpr float kFootGuard = 0.012f;
 // the test pays for itself on rectangles of >= 6 bins with both sides >= 2 (a one-bin-wide strip has no bin to drop: the level
 // set touches both ends of its box); a fresh map's splats (3 bins on average) skip it
 __host__ __device__ inline bool footprint_worthwhile(int w, int h) { return w >= 2 && h >= 2 && w * h >= 6; }
@@ -77,14 +81,17 @@ __device__ __forceinline__ Footprint make_footprint(float px, float py, float A,
 }
 // minimum of q over the box [xl, xh] x [yl, yh] of offsets from the centre (0 when the centre is inside)
 __device__ __forceinline__ float footprint_qmin(const Footprint& f, int tx, int ty) {
+#pragma clang fp contract(off)
   const float xl = (float)(tx * kTile) - f.px, xh = xl + (float)(kTile - 1);
   const float yl = (float)(ty * kTile) - f.py, yh = yl + (float)(kTile - 1);
   if (xl <= 0.f && xh >= 0.f && yl <= 0.f && yh >= 0.f) return 0.f;
   auto edge_x = [&](float c) {      // dx = c, dy free in [yl, yh]
+#pragma clang fp contract(off)
     const float d = fminf(yh, fmaxf(yl, -f.B * c * f.invC));
     return f.A * c * c + 2.f * f.B * c * d + f.C * d * d;
   };
   auto edge_y = [&](float c) {      // dy = c, dx free in [xl, xh]
+#pragma clang fp contract(off)
     const float d = fminf(xh, fmaxf(xl, -f.B * c * f.invA));
     return f.A * d * d + 2.f * f.B * d * c + f.C * c * c;
   };
@@ -103,7 +110,8 @@ struct SavedHeader {
   uint32_t slot_total;     // partial slots the view's Gaussians reserve (sum of their bin-rectangle areas, >= pairs binned: bins of the
                            // rectangle that the exact footprint test dropped keep their slot); K2 writes it, K3 folds it into num_rendered
   uint32_t num_binned;     // pairs actually binned (K3; num_rendered then holds the capacity-relevant max(pairs binned, slot_total))
-  uint32_t pad[6];
+  uint32_t max_tile_count; // longest per-tile list of this forward (K2): what the caller picks the tile kernels' sort build by
+  uint32_t pad[5];
 };
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -125,6 +133,7 @@ struct ViewTab {
   const float* dL_dcolor[kMaxViews];
   const float* dL_ddepth[kMaxViews];
   float* dL_dtau[kMaxViews];
+  float* dL_dmeans2D[kMaxViews];   // per-view [N,3] screen-space mean gradients (rows of visible Gaussians are written) or NULL
 };
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {

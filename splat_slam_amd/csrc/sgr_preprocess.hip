@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       const bool c0 = bx >= x0, c1 = bx + 1 < x1, r0 = by >= y0, r1 = by + 1 < y1;
       uint32_t cover = (uint32_t)(r0 && c0) | ((uint32_t)(r0 && c1) << 1) | ((uint32_t)(r1 && c0) << 2) | ((uint32_t)(r1 && c1) << 3);
       if (foot.thr >= 0.f) {
-        const float drop = foot.thr * kFootDrop;
+        const float drop = foot.thr * kFootDrop + kFootGuard;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
           if (((cover >> s4) & 1u) && footprint_qmin(foot, bx + (s4 & 1), by + (s4 >> 1)) > drop) cover &= ~(1u << s4);
@@ -1081,6 +1081,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   rec[1] = make_float4(acc.rgb_or_sh0[1], acc.rgb_or_sh0[2], acc.op, acc.s[0]);
   rec[2] = make_float4(acc.s[1], acc.s[2], acc.q[0], acc.q[1]);
   rec[3] = make_float4(acc.q[2], acc.q[3], acc.m2[0], acc.m2[1]);
+  if (float* m2 = tab.dL_dmeans2D[v]) {      // this view's own screen-space gradient (the drop-in API's `means2D.grad`): the caller
+    if (((const SavedHeader*)(saved + L.o_hdr))->overflow == 0u) {        // zeroed the buffer; a truncated view contributes nothing
+      m2[3 * (size_t)i] = acc.m2[0];
+      m2[3 * (size_t)i + 1] = acc.m2[1];
+    }
+  }
   if (dcov3D) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) { if (accumulate) dcov3D[6 * i + j] += acc.S6[j]; else dcov3D[6 * i + j] = acc.S6[j]; }

@@ -117,6 +117,7 @@ def _update_mapping_points_hip(gaussians, frame_idx, w2c, w2c_old, depth, depth_
     with torch.cuda.device(dev):
         nat.check(nat.lib().sgr_deform_points(xyz.shape[0], ids.data_ptr(), C.byref(f), xyz.data_ptr(), rot.data_ptr(),
                                               sc.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "sgr_deform_points")
+    gaussians.invalidate_activations()         # (raw-pointer writes: no _version bump)
     gaussians._xyz = gaussians.replace_tensor_to_optimizer(xyz, "xyz")["xyz"]
     gaussians._rotation = gaussians.replace_tensor_to_optimizer(rot, "rotation")["rotation"]
     if not f.rigid:

@@ -56,6 +56,7 @@ class _ViewBuffers:
         self.scratch = None
         self.clean = False         # the saved block went through a forward with its current layout (counters are zero)
         self.pairs = -1            # (tile, Gaussian) pairs seen by the probe render; -1 = not probed at this map size
+        self.estimated = False     # `pairs` is a carried-over estimate, not yet confirmed by a header read at this map size
         self.capacity = 0
         self.gt_depth = None
         self.depth_src = None
@@ -169,6 +170,10 @@ def estimate_pairs(hints, uid, n_now):
 class FusedMappingLoop(MappingLoop):
     def __init__(self, config, device="cuda:0", knn_fn=None, check_every=50, span_calls=True):
         super().__init__(config, device=device, fused_loss=True, knn_fn=knn_fn)
+        # `ssim_loss: True` (slam_utils.py:89-98, off by default) is not a per-pixel L1: the fused tile kernel's loss epilogue does
+        # not apply, and the three loops run as the autograd MappingLoop (drop-in rasterizer + torch loss) instead
+        from splat_slam_amd.losses import uses_ssim
+        self.autograd_fallback = uses_ssim(config["mapping"])
         self.lib = nat.lib()
         self.check_every = check_every
         self.fuse_tail = True            # gather + Adam + next activations in one pass (single GPU, regular iterations)
@@ -181,6 +186,7 @@ class FusedMappingLoop(MappingLoop):
         self._scratch = None
         self._since_check = 0
         self._pair_hint = {}       # camera uid -> (measured pair count, map size it was measured at)
+        self._list_hint = {}       # camera uid -> longest per-tile list measured (header word 10): picks the tile kernels' sort build
         self._exp = None
         self._exp_rows = []
         self._cap = 0
@@ -194,7 +200,7 @@ class FusedMappingLoop(MappingLoop):
         self.comm = None
         self._zero = None            # parallel.Zero1Plan + flat parameter / moment / shard buffers (sync == "zero1")
         self._replicated = 0         # > 0: every rank runs the identical iteration, no exchange (initialize_map, final_refine)
-        self._acc_ids = None        # id() of the five parameter tensors the sinks belong to
+        self._acc_ids = None        # the five parameter tensors the sinks belong to (held, so that identity checks are sound)
         self._stale_iso = 0.0       # isotropy weight whose gradient a prune pass left on the current `_scaling` tensor
         self.max_pairs = 1 << 28    # a view with more (tile, Gaussian) pairs than this is a degenerate map: fail loudly, not by OOM
 
@@ -202,7 +208,7 @@ class FusedMappingLoop(MappingLoop):
         super().reset()
         self._views, self._acc, self._acc_key, self._acc_ids, self._acc_clean = {}, None, None, None, True
         self._exp, self._exp_rows, self._cap, self._stale_iso = None, [], 0, 0.0
-        self._pair_hint = {}
+        self._pair_hint, self._list_hint = {}, {}
         self._plan_key = self._plan_obj = None
 
     # ------------------------------------------------------------------------------------------------ state
@@ -235,13 +241,14 @@ class FusedMappingLoop(MappingLoop):
     def _ensure_state(self):
         gm = self.gaussians
         key = gm._xyz.shape[0]
-        ids = tuple(id(p) for p in (gm._xyz, gm._features_dc, gm._opacity, gm._scaling, gm._rotation))
-        if self._acc_key == key and self._acc_ids == ids:
+        ids = (gm._xyz, gm._features_dc, gm._opacity, gm._scaling, gm._rotation)     # the objects, compared with `is`: an id()
+        same = self._acc_ids is not None and all(a is b for a, b in zip(self._acc_ids, ids))   # can be reused once its owner died
+        if self._acc_key == key and same:
             return
         if self._acc_key == key and self._acc is not None:
             # same N, some tensors replaced (opacity reset, map deformation: replace_tensor_to_optimizer): the new
             # Parameters have no .grad in the reference, i.e. whatever a prune pass left for THOSE groups is gone
-            changed = [k for k, (old, new) in enumerate(zip(self._acc_ids, ids)) if old != new]
+            changed = [k for k, (old, new) in enumerate(zip(self._acc_ids, ids)) if old is not new]
             for k in changed:
                 if not self._acc_clean:
                     self._acc[_GROUPS[k]].zero_()
@@ -298,6 +305,7 @@ class FusedMappingLoop(MappingLoop):
                     dst = zr["plan"].view(buf, name, zr["shapes"][name])
                     dst.copy_(src.reshape(dst.shape))
                     put(dst.view(src.shape))
+        gm.invalidate_activations()             # (p.data was re-pointed: no _version bump)
         self._plan_key = None
 
     def _sync_moments(self):
@@ -396,7 +404,31 @@ class FusedMappingLoop(MappingLoop):
         if vb.scratch is None or vb.scratch.numel() < tb:
             vb.scratch = torch.empty(tb, dtype=torch.uint8, device=self.device)
         return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), cap,
-                                int(vb.clean), 0)
+                                int(vb.clean), self._max_list())
+
+    def _max_list(self):
+        """Longest per-tile list measured on any camera of this map (0: nothing measured yet): the library picks the sort
+        build of the tile kernels from it -- a deterministic function of measurements (the capacity-derived guess it
+        replaces depended on the probe history and flipped the build between two runs of the same scene)."""
+        return max(self._list_hint.values()) if self._list_hint else 0
+
+    def _read_header(self, uid, vb):
+        """One synchronous header read of a camera's last forward: pair count, overflow word, longest list."""
+        w = (C.c_uint32 * 16)()
+        nat.check(self.lib.sgr_query_header(vb.saved.data_ptr(), w, self._stream()), "sgr_query_header")
+        R, ov, longest = int(w[0]), int(w[1]), int(w[10])
+        vb.pairs, vb.estimated = R, False
+        self._pair_hint[uid] = (R, self.gaussians._xyz.shape[0])
+        if longest != self._list_hint.get(uid):
+            old = self._build_class()
+            self._list_hint[uid] = longest
+            if self._build_class() != old:
+                self._views_dirty()            # the cached SgrMapViews carry the hint
+        return R, ov
+
+    def _build_class(self):
+        m = self._max_list()
+        return 0 if m <= 768 else (1 if m <= 1536 else 2)
 
     def _estimate_pairs(self, cam, vb):
         """Pair count of a camera whose buffers are new.  A synchronous probe forward per camera and map size cost a converged
@@ -409,7 +441,7 @@ class FusedMappingLoop(MappingLoop):
         if est is None:
             self._probe(cam, vb)
             return
-        vb.pairs = est
+        vb.pairs, vb.estimated = est, True
         self._since_check = max(self._since_check, self.check_every - 2)      # measure soon
 
     def _probe(self, cam, vb):
@@ -433,9 +465,8 @@ class FusedMappingLoop(MappingLoop):
                 continue
             nat.check(rc, "sgr_forward")
             break
-        vb.pairs = int(R.value)
-        self._pair_hint[cam.uid] = (vb.pairs, N)
         vb.clean = True
+        self._read_header(cam.uid, vb)            # (also the longest list: the sort build of the tile kernels)
         if vb.pairs > self.max_pairs:
             gm = self.gaussians
             with torch.no_grad():
@@ -512,8 +543,8 @@ class FusedMappingLoop(MappingLoop):
         """Structs that only change when the parameter tensors do (new N, opacity reset, ...)."""
         gm, a = self.gaussians, self._acc
         by_name = {g["name"]: g for g in gm.optimizer.param_groups}
-        key = tuple(id(by_name[n]["params"][0]) for n in _GROUPS) + (id(a["xyz"]),)
-        if self._plan_key != key:
+        key = tuple(by_name[n]["params"][0] for n in _GROUPS) + (a["xyz"],)        # objects, compared with `is` (see _ensure_state)
+        if self._plan_key is None or len(self._plan_key) != len(key) or any(x is not y for x, y in zip(self._plan_key, key)):
             pl = _Plan()
             pl.inp = self._inputs()
             pl.step = nat.SgrMapStep()
@@ -583,14 +614,25 @@ class FusedMappingLoop(MappingLoop):
                 st.exp_lr, st.exp_beta1, st.exp_beta2, st.exp_eps = 0.01, 0.9, 0.999, 1e-8
         return st
 
-    def _run_span(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True, initialization=False):
+    def _run_span(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True, initialization=False, verified=False):
         """len(lrs) regular iterations with ONE host call (sgr_map_run): iteration k renders window_cams plus
-        pool_cams[picks[k]] and steps Adam with the xyz learning rate lrs[k]."""
+        pool_cams[picks[k]] and steps Adam with the xyz learning rate lrs[k].
+        A view whose workspace is sized by a carried-over ESTIMATE of its pair count (buffers are new after the map changed
+        size) could be truncated for the whole span without anybody looking: the first iteration then runs on its own and
+        the headers of its views are read back before the rest of the span is enqueued (one synchronisation per span that
+        follows a change of the map; views that only appear later in the span are covered by the periodic check, which warns)."""
         n_it = len(lrs)
         if self._parallel() or n_it == 0:
             raise RuntimeError("_run_span is the single-GPU fast path")
         pl = self._plan()
         self._views_array(list(window_cams) + list(pool_cams), initialization)   # probes new cameras, settles the capacity
+        per0 = len(picks) // n_it if picks else 0
+        if n_it > 1 and not verified and any(self._views[c.uid].estimated for c in
+                                             list(window_cams) + [pool_cams[k] for k in picks[:per0]]):
+            self._run_span(window_cams, pool_cams, picks[:per0], lrs[:1], iso_weight, exposure, stats, initialization, verified=True)
+            self.check_overflow()
+            return self._run_span(window_cams, pool_cams, picks[per0:], lrs[1:], iso_weight, exposure, stats, initialization,
+                                  verified=True)
         win = self._views_array(window_cams, initialization, images=False) if window_cams else None
         pool = self._views_array(pool_cams, initialization, images=False) if pool_cams else None
         st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
@@ -614,6 +656,7 @@ class FusedMappingLoop(MappingLoop):
             run.pool_exp_row = rows
         rc = self.lib.sgr_map_run(C.byref(run), self._stream())
         nat.check(rc, "sgr_map_run")
+        self.gaussians.invalidate_activations()    # parameters changed through raw pointers: cached torch activations are stale
         self._acc_clean = True
         self._mark_clean(list(window_cams) + [pool_cams[k] for k in set(picks)])
         for g, stt in pl.states:                 # the library advanced pl.groups[k].step; mirror it in torch's state
@@ -667,6 +710,7 @@ class FusedMappingLoop(MappingLoop):
         for g, stt in pl.states:
             stt["step"] += n_it
         pl.frest_state["step"] += n_it
+        self.gaussians.invalidate_activations()
         self._acc_clean = True
         self._mark_clean([used[i] for i in pos])
 
@@ -710,6 +754,7 @@ class FusedMappingLoop(MappingLoop):
         self._mark_clean(cams)
         if not forward_only:
             if adam:
+                self.gaussians.invalidate_activations()
                 self._acc_clean = True
             elif len(cams):
                 self._acc_clean = False
@@ -733,25 +778,21 @@ class FusedMappingLoop(MappingLoop):
 
     def render_forward(self, viewpoint):
         """Forward-only render used for keyframe selection (mapper.py:972-978): buffers of the camera, no autograd."""
+        if self.autograd_fallback:
+            return MappingLoop.render_forward(self, viewpoint)
         self._ensure_state()
         self._step([viewpoint], adam=False, forward_only=True)
         vb = self._views[viewpoint.uid]
         if viewpoint.uid not in self._pair_hint or self._pair_hint[viewpoint.uid][1] != self.gaussians._xyz.shape[0]:
             # the caller reads the images right away (keyframe selection): one read-back more measures this camera's pair count,
             # so that the mapping iterations that follow size their workspaces from a measurement, not an estimate
-            R, ov = C.c_int64(0), C.c_int32(0)
-            nat.check(self.lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), self._stream()), "sgr_query")
-            if ov.value:                              # the estimate was short: grow and render again
-                vb.pairs = int(R.value)
-                self._pair_hint[viewpoint.uid] = (vb.pairs, self.gaussians._xyz.shape[0])
+            R, ov = self._read_header(viewpoint.uid, vb)
+            if ov:                                    # the estimate was short: grow and render again
                 self._cap = max(self._cap, 2 * vb.pairs)
                 self._views_dirty()
                 self.overflow_events += 1
                 self._step([viewpoint], adam=False, forward_only=True)
                 vb = self._views[viewpoint.uid]
-            else:
-                vb.pairs = int(R.value)
-                self._pair_hint[viewpoint.uid] = (vb.pairs, self.gaussians._xyz.shape[0])
         return {"render": vb.color, "depth": vb.depth, "opacity": vb.opacity, "radii": vb.radii, "n_touched": vb.n_touched,
                 "visibility_filter": vb.radii > 0}
 
@@ -759,6 +800,8 @@ class FusedMappingLoop(MappingLoop):
     def build_keyframe_optimizers(self):
         """mapper.py:1067-1111.  Exposure parameters live in a device slab (Camera.exposure_a/b are views of their
         row); a fresh optimiser per keyframe = moments and step counters of the window rows reset."""
+        if self.autograd_fallback:
+            return MappingLoop.build_keyframe_optimizers(self)
         if self._exp is None:
             self._exp = _ExposureSlab(self.device)
         rows = []
@@ -819,17 +862,16 @@ class FusedMappingLoop(MappingLoop):
     def check_overflow(self):
         """One synchronisation: did any camera's forward exceed the pair capacity since the last check?"""
         self._since_check = 0
-        worst = 0
+        worst, overflowed = 0, []
         for uid, vb in self._views.items():
             if vb.saved is None or not vb.mv or not vb.clean:      # (a block no forward has run on yet holds no header)
                 continue
-            R, ov = C.c_int64(0), C.c_int32(0)
-            nat.check(self.lib.sgr_query(vb.saved.data_ptr(), C.byref(R), C.byref(ov), self._stream()), "sgr_query")
-            self.overflow_events += int(bool(ov.value))
-            if ov.value == 2:
+            R, ov = self._read_header(uid, vb)
+            if ov == 2:
                 raise RuntimeError(f"camera {uid}: more than 65280 splats on one 8x8 tile -- the map has degenerated")
-            vb.pairs = int(R.value)
-            self._pair_hint[uid] = (vb.pairs, self.gaussians._xyz.shape[0])
+            if ov:
+                self.overflow_events += 1
+                overflowed.append(uid)
             if vb.pairs > self.max_pairs:
                 raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
                                    "the map has degenerated")
@@ -837,6 +879,12 @@ class FusedMappingLoop(MappingLoop):
         if worst * 1.5 > self._cap:
             self._cap = max(1 << 16, 2 * worst)
             self._views_dirty()
+        if overflowed:
+            import warnings
+            warnings.warn(f"FusedMappingLoop: the forward of camera(s) {overflowed} exceeded the (tile, Gaussian) pair capacity; those "
+                          "views took no part in the optimiser steps since the previous check (the workspace has been grown)",
+                          RuntimeWarning, stacklevel=2)
+        return overflowed
 
     def _tick(self):
         self._since_check += 1
@@ -847,6 +895,8 @@ class FusedMappingLoop(MappingLoop):
     def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
         """mapper.py:303-398.  One view per iteration: with several ranks every rank runs the identical iterations
         (deterministic kernels keep the replicas bit-identical; there is nothing to exchange)."""
+        if self.autograd_fallback:
+            return MappingLoop.initialize_map(self, cur_frame_idx, viewpoint, iters)
         self._sync_moments()
         self._replicated += 1
         try:
@@ -914,6 +964,8 @@ class FusedMappingLoop(MappingLoop):
     def map(self, current_window, prune=False, iters=1):
         if len(current_window) == 0:
             return
+        if self.autograd_fallback:
+            return MappingLoop.map(self, current_window, prune=prune, iters=iters)
         viewpoint_stack = [self.viewpoints[kf_idx] for kf_idx in current_window]
         frames_to_optimize = self.config["mapping"]["Training"]["pose_window"]
         cw = set(current_window)
@@ -1054,20 +1106,51 @@ class FusedMappingLoop(MappingLoop):
             if g["name"] == "xyz":
                 return g
 
-    def final_refine(self, iters=26000):
-        """mapper.py:656-708: ONE random view per optimiser step -- running several views per step would change the
-        optimisation, so with several ranks every rank runs the identical iterations."""
+    def final_refine(self, iters=26000, views_per_step=None):
+        """mapper.py:656-708.  views_per_step = 1 (default; config mapping.final_refine_views_per_step): the reference's
+        step -- ONE random view, Adam on all N -- which several ranks can only run replicated (deterministic kernels keep
+        the replicas bit-identical; nothing to exchange, nothing gained).
+        views_per_step = G > 1 ("world": one per rank): G DISTINCT random views per optimiser step and iters / G steps --
+        the same number of renders, a G times larger batch per Adam step (SURVEY.md 8e "semantics caveat"; configs[4]).
+        The G picks of a step come from ONE numpy stream that every rank draws identically; rank r renders picks r, r + world,
+        ...; gradients meet in the ZeRO-1 exchange exactly like the views of a map() iteration.  A single process runs all
+        G views of a step as one batched launch: the same optimisation up to fp32 summation order, which is how the PSNR of
+        1 x iters against G x (iters / G) is measured on one GPU (scripts/refine_batch_psnr.py)."""
+        if self.autograd_fallback:
+            return MappingLoop.final_refine(self, iters)
+        if views_per_step is None:
+            views_per_step = self.config["mapping"].get("final_refine_views_per_step", 1)
+        if views_per_step == "world":
+            views_per_step = self.world
+        views_per_step = max(1, min(int(views_per_step), len(self.viewpoints)))
         self._sync_moments()
+        if views_per_step == 1:
+            self._replicated += 1
+            try:
+                return self._final_refine(iters)
+            finally:
+                self._replicated -= 1
+        split, self.split_views = self.split_views, True       # (a rank renders ITS picks of the step whatever map() does)
+        try:
+            self._final_refine_views(iters, views_per_step)
+        finally:
+            self.split_views = split
+
+    def _final_refine_views(self, iters, views_per_step):
+        # what a prune pass left behind is consumed by the reference's kind of step first (replicated: the stale sums are
+        # identical on every rank and must enter the optimiser once)
         self._replicated += 1
         try:
-            return self._final_refine(iters)
+            done = self._final_refine_stale(iters)
         finally:
             self._replicated -= 1
+        self._final_refine_multi(iters - done, views_per_step)
+        self._sync_moments()
 
-    def _final_refine(self, iters=26000):
+    def _final_refine_stale(self, iters):
         stack = list(self.viewpoints.values())
         done = 0
-        while done < iters and self._has_stale():        # what the last prune pass left behind goes into this step
+        while done < iters and self._has_stale():
             self.iteration_count += 1
             self._ensure_state()
             cam = stack[np.random.randint(0, len(stack))]
@@ -1077,6 +1160,33 @@ class FusedMappingLoop(MappingLoop):
             self.last_used = [cam]
             self._tick()
             done += 1
+        return done
+
+    def _final_refine_multi(self, iters, G):
+        """ceil(iters / G) optimiser steps of G distinct random views each; `iteration_count` (the lr schedule's clock,
+        mapper.py:705) advances by the number of renders."""
+        stack = list(self.viewpoints.values())
+        done = 0
+        while done < iters:
+            g = min(G, iters - done)
+            self.iteration_count += g
+            self._ensure_state()
+            picks = []
+            while len(picks) < g:                      # the reference's draw (mapper.py:668), repeated until distinct
+                p = int(np.random.randint(0, len(stack)))
+                if p not in picks:
+                    picks.append(p)
+            cams = [stack[p] for p in picks]
+            self._step(cams, adam=True, stats=False, exposure="none")
+            self._exposure_step(cams, only_rendered=True)
+            self.gaussians.update_learning_rate(self.iteration_count)
+            self.last_used = self._local(cams) or cams[:1]
+            self._tick()
+            done += g
+
+    def _final_refine(self, iters=26000):
+        stack = list(self.viewpoints.values())
+        done = self._final_refine_stale(iters)           # what the last prune pass left behind goes into these steps
         while self.span_calls and done < iters:
             n = min(iters - done, 512)           # (the overflow check runs between chunks)
             self._ensure_state()

@@ -103,21 +103,30 @@ class GaussianModel:
 
     # ---- activations (gaussian_model.py:53-61,76-101)
     def _activated(self, name, fn, *params):
+        """Shared activation of one parameter set: every render between two parameter updates sees the same tensor (and one
+        autograd node).  Consequence: ONE backward per set of renders, like the reference's iteration (mapper.py:426-490);
+        `render A, render B, lossA.backward(), lossB.backward()` needs share_activations = False (or retain_graph).
+        Kernels that write parameters through raw pointers (fused Adam, sgr_deform_points) do not bump `_version`:
+        they call invalidate_activations()."""
         if not self.share_activations or not torch.is_grad_enabled():
             return fn(*params)
-        key = tuple((id(p), p._version) for p in params)
+        vers = tuple(p._version for p in params)
         hit = self._act.get(name)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit[1] == vers and len(hit[0]) == len(params) and all(a is b for a, b in zip(hit[0], params)):
+            return hit[2]
         out = fn(*params)
         if out.requires_grad:
             # a backward frees this node's graph: whatever is rendered afterwards needs a fresh one
-            def drop(grad, n=name, k=key):
-                if self._act.get(n, (None,))[0] == k:
+            def drop(grad, n=name, o=out):
+                h = self._act.get(n)
+                if h is not None and h[2] is o:
                     del self._act[n]
             out.register_hook(drop)
-            self._act[name] = (key, out)
+            self._act[name] = (params, vers, out)      # (the Parameters are held: identity, not id(), decides a hit)
         return out
+
+    def invalidate_activations(self):
+        self._act.clear()
 
     @property
     def get_scaling(self):
@@ -215,7 +224,11 @@ class GaussianModel:
             {"params": [self._scaling], "lr": training_args.scaling_lr * self.spatial_lr_scale, "name": "scaling"},
             {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
         ]
-        self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
+        if self.device.type == "cuda":        # same groups, same state dict, one launch per tensor (splat_slam_amd/optim.py)
+            from splat_slam_amd.optim import FusedAdam
+            self.optimizer = FusedAdam(l, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
         self.lr_init = training_args.position_lr_init * self.spatial_lr_scale
         self.lr_final = training_args.position_lr_final * self.spatial_lr_scale
         self.lr_delay_mult = training_args.position_lr_delay_mult
@@ -506,6 +519,20 @@ class GaussianModel:
             too_wide_in_world = self.get_scaling.max(dim=1).values > 0.1 * extent
             doomed = doomed | too_wide_on_screen | too_wide_in_world
         self.prune_points(doomed)
+
+    def add_view_stats(self, viewspace_point_tensor, radii):
+        """add_densification_stats + the max_radii2D update of one view (gaussian_model.py:738-742, mapper.py:522-529) as ONE
+        launch on the GPU (sgr_densify_stats); returns False when the caller has to use the torch formulation."""
+        g = viewspace_point_tensor.grad
+        if (g is None or not g.is_cuda or g.dtype is not torch.float32 or not g.is_contiguous() or radii.dtype is not torch.int32
+                or self.max_radii2D.dtype is not torch.float32 or not radii.is_contiguous()):
+            return False
+        from splat_slam_amd import _native as nat
+        n = g.shape[0]
+        nat.check(nat.lib().sgr_densify_stats(n, g.data_ptr(), radii.data_ptr(), self.xyz_gradient_accum.data_ptr(),
+                                              self.denom.data_ptr(), self.max_radii2D.data_ptr(),
+                                              torch.cuda.current_stream(g.device).cuda_stream), "sgr_densify_stats")
+        return True
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         """accum[visible] += |dL/d(mean2D)|, denom[visible] += 1 (gaussian_model.py:738-742), mask-free (no nonzero() sync)."""

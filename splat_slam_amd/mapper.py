@@ -103,6 +103,8 @@ class MappingLoop:
         index is a nonzero() -- a host synchronisation and three extra kernels -- per statement, 36 of them per 12-view
         iteration on the GPU."""
         gm = self.gaussians
+        if gm.add_view_stats(viewspace_points, radii):          # GPU: one launch for the three updates
+            return
         gm.max_radii2D = torch.where(vis, torch.max(gm.max_radii2D, radii), gm.max_radii2D)
         gm.add_densification_stats(viewspace_points, vis)
 
@@ -148,7 +150,7 @@ class MappingLoop:
         random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in current_window_set]
         pose_opt = bool(self.config["mapping"]["BA"]) and not self.config["mapping"]["Training"].get("gt_camera", False)
         gaussian_split = False
-        for _ in range(iters):
+        for it in range(iters):
             gaussian_split = False                      # (per iteration, mapper.py:491: the LAST iteration decides the result)
             self.iteration_count += 1
             loss_mapping = 0
@@ -177,9 +179,12 @@ class MappingLoop:
             if self.grad_sync is not None and not prune:      # (the prune pass never steps: nothing to exchange)
                 self.grad_sync.reduce()
             with torch.no_grad():
-                self.occ_aware_visibility = {}
-                for idx in range(len(current_window)):
-                    self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
+                # the reference rebuilds this dict every iteration (mapper.py:494-498); it is only ever READ by the prune branch
+                # below and by the caller after map() returns: build it when it can be observed (20 launches per iteration saved)
+                if prune or it == iters - 1:
+                    self.occ_aware_visibility = {}
+                    for idx in range(len(current_window)):
+                        self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
                 if prune:
                     # the reference computes `to_prune` here and drops it (mapper.py:502-520): a pass that refreshes
                     # occ_aware_visibility and n_obs and returns before optimizer.step()/zero_grad()

@@ -1,0 +1,57 @@
+"""torch.optim.Adam for the Gaussian parameter groups with a fused step: same constructor, same param_groups, same
+state dict ({"step", "exp_avg", "exp_avg_sq"} per parameter -- densification / pruning reach into it,
+/root/reference/thirdparty/gaussian_splatting/scene/gaussian_model.py:519-593), but step() is ONE launch per parameter
+tensor (sgr_adam_step) instead of torch's multi-tensor sequence of ~12 launches per call plus Python dispatch: the
+optimiser step of the drop-in path (src/mapper.py:352,557,703) drops from ~0.6 ms to ~0.06 ms of host time.
+Falls back to torch's own step for anything but plain Adam on contiguous fp32 GPU tensors."""
+import torch
+
+from splat_slam_amd import _native as nat
+
+
+class FusedAdam(torch.optim.Adam):
+    def _plain(self):
+        for g in self.param_groups:
+            if (g.get("amsgrad") or g.get("weight_decay", 0) != 0 or g.get("maximize") or g.get("capturable")
+                    or g.get("differentiable") or g.get("fused") or g.get("decoupled_weight_decay")):
+                return False
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype is torch.float32 and p.is_contiguous()) or p.grad.is_sparse or p.grad.dtype is not torch.float32:
+                    return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self._plain():
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = nat.lib()
+        for g in self.param_groups:
+            b1, b2 = g["betas"]
+            lr, eps = float(g["lr"]), float(g["eps"])
+            for p in g["params"]:
+                grad = p.grad
+                if grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:                       # exactly what torch.optim.Adam._init_group creates
+                    st["step"] = torch.tensor(0.0, dtype=torch.get_default_dtype())
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                n = p.numel()
+                if n == 0:
+                    continue
+                if not grad.is_contiguous():
+                    grad = grad.contiguous()
+                if p.device.index is not None and p.device.index != torch.cuda.current_device():
+                    torch.cuda.set_device(p.device)
+                nat.check(lib.sgr_adam_step(n, p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                            lr, float(b1), float(b2), eps, int(st["step"].item()),
+                                            torch.cuda.current_stream().cuda_stream), "sgr_adam_step")
+        return loss

@@ -115,6 +115,66 @@ def test_tile_sort_network_index_arithmetic():
         assert a == want, n
 
 
+def test_register_blocked_tile_sort_network():
+    """csrc/sgr_blend.hip wave_sort_registers<KPL>: 64 lanes x KPL keys, element e = lane * KPL + r.  Stage (KK, J): J < KPL
+    compares registers r and r | J of one lane, J >= KPL exchanges register r with lane ^ (J / KPL); a block of KK elements is
+    descending iff (e & KK) != 0; ONE compare per exchange, the direction enters as an xor (keys are unique up to the ~0
+    padding).  Restated here lane by lane: it must sort any count <= 64 * KPL and push the padding to the end."""
+    import random
+    rnd = random.Random(11)
+    PAD = (1 << 64) - 1
+    for KPL in (2, 4, 8):
+        for count in [65, 64 * KPL - 1, 64 * KPL, 64 * KPL // 2 + 3, rnd.randrange(65, 64 * KPL)]:
+            vals = [rnd.getrandbits(63) for _ in range(count)]
+            k = [[vals[l * KPL + r] if l * KPL + r < count else PAD for r in range(KPL)] for l in range(64)]
+            KK = 2
+            while KK <= 64 * KPL:
+                J = KK >> 1
+                while J >= 1:
+                    if J < KPL:
+                        for lane in range(64):
+                            for r in range(KPL):
+                                if r & J:
+                                    continue
+                                down = ((r & KK) != 0) if KK < KPL else (((lane * KPL) & KK) != 0)
+                                a, b = k[lane][r], k[lane][r | J]
+                                if (b < a) != down:
+                                    k[lane][r], k[lane][r | J] = b, a
+                    else:
+                        M = J // KPL
+                        new = [row[:] for row in k]
+                        for lane in range(64):
+                            lower, up = (lane & M) == 0, ((lane * KPL) & KK) == 0
+                            keep_max = lower != up
+                            for r in range(KPL):
+                                mine, other = k[lane][r], k[lane ^ M][r]
+                                if (other < mine) != keep_max:
+                                    new[lane][r] = other
+                        k = new
+                    J >>= 1
+                KK <<= 1
+            flat = [k[l][r] for l in range(64) for r in range(KPL)]
+            assert flat[:count] == sorted(vals) and all(x == PAD for x in flat[count:]), (KPL, count)
+
+
+def test_backward_chunk_plan_covers_every_list_position_once():
+    """csrc/sgr_blend.hip tile_backward: a list of `eff` splats is cut from the far end into chunks of 64 / 32 / 16 / 8 / 4 lanes
+    (width rounded up when the chunk would be at least 3/4 full).  Every position belongs to exactly one chunk, chunks run
+    back to front, and the iteration count (32 * width / 64 per chunk) never exceeds the one-64-chunk-per-64-splats plan."""
+    for eff in range(1, 700):
+        end, seen, iters = eff, [], 0
+        while end > 0:
+            gw = 64 if end >= 48 else 32 if end >= 24 else 16 if end >= 12 else 8 if end >= 5 else 4
+            start = 0 if gw >= end else end - gw
+            assert end - start <= gw
+            seen = list(range(start, end)) + seen
+            iters += 32 * gw // 64
+            end = start
+        assert seen == list(range(eff))
+        old = 32 * ((eff + 63) // 64) if eff > 32 else (16 if eff > 16 else 8 if eff > 8 else 4 if eff > 4 else 2)
+        assert iters <= old + (2 if eff <= 32 else 0), (eff, iters, old)
+
+
 def test_footprint_bin_test_is_a_lower_bound_of_the_quadratic_form():
     """csrc/sgr_common.h footprint_qmin, restated: the minimum of q = A dx^2 + 2 B dx dy + C dy^2 over the bounding box of a
     bin's 8x8 pixel centres (0 if the centre is inside, else the smallest of the four edge minima).  It must never exceed q at
