@@ -515,6 +515,16 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, theta, rho, raster_settings, None)
 
 
+def saved_block_of(output):
+    """(saved workspace block, capacity) of the forward that produced `output` (one of the differentiable tensors a
+    GaussianRasterizer call returned) -- parity tooling: sgr_query_* read the forward's own depth keys / counters from it."""
+    fn = output.grad_fn
+    r = getattr(fn, "record", None)
+    if r is not None:
+        return r.lease.block, r.cap
+    return fn.saved_tensors[-1], fn.capacity
+
+
 def check_overflow():
     """Waits for the pair counts of all forwards issued so far and raises if any of them dropped pairs."""
     for st in _states.values():
@@ -528,14 +538,22 @@ class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         object.__setattr__(self, "raster_settings", raster_settings)
 
-    def __getattr__(self, name):           # only reached for attributes that are missing
+    def _late_init(self):
         d = object.__getattribute__(self, "__dict__")
-        if "_parameters" not in d:
-            rs = d.pop("raster_settings", None)
-            nn.Module.__init__(self)
-            object.__setattr__(self, "raster_settings", rs)
+        rs = d.pop("raster_settings", None)
+        nn.Module.__init__(self)
+        object.__setattr__(self, "raster_settings", rs)
+
+    def __getattr__(self, name):           # only reached for attributes that are missing
+        if "_parameters" not in object.__getattribute__(self, "__dict__"):
+            self._late_init()
             return getattr(self, name)
         return nn.Module.__getattr__(self, name)
+
+    def __setattr__(self, name, value):
+        if "_parameters" not in self.__dict__:
+            self._late_init()
+        nn.Module.__setattr__(self, name, value)
 
     def __call__(self, *args, **kwargs):
         if "_parameters" in self.__dict__:

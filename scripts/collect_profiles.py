@@ -118,4 +118,6 @@ for k, v in sq.items():
 json.dump({"command": c3, "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)",
            "note": "batched (largest-grid) launches only; 1024 SIMDs", "kernels": sq},
           open(os.path.join(out, tag + "_pmc_sq.json"), "w"), indent=1)
+for name in ("kernel_batched_avg", "pmc_hbm_bytes"):       # what bench.py quotes `roofline.traffic` from
+    shutil.copy(os.path.join(out, tag + "_" + name + ".json"), os.path.join(out, "latest_" + name + ".json"))
 print("done", os.listdir(out))

@@ -156,9 +156,10 @@ def make_views(params, K, intr, device, seed=43, perturb=True, config=None):
     for k in range(K):
         w2c = orbit_w2c(k, K)
         cam = make_camera(k, w2c, intr, torch.zeros(3, H, W, device=device), torch.zeros(H, W, device=device), device)
-        pkg = render(cam, gm, PipelineParams(), bg)
-        cam.original_image = pkg["render"].clamp(0, 1).contiguous()
-        cam.depth = pkg["depth"][0].contiguous()
+        with torch.no_grad():                 # (ground truth: no autograd graph -- and no saved block -- kept alive by the images)
+            pkg = render(cam, gm, PipelineParams(), bg)
+        cam.original_image = pkg["render"].detach().clamp(0, 1).contiguous()
+        cam.depth = pkg["depth"][0].detach().contiguous()
         cams.append(cam)
     return cams
 

@@ -46,8 +46,9 @@ def run_hip(inp, s, wc=None, wd=None, dev="cuda:0", want_depth_keys=False):
     grads = None
     keys = None
     if want_depth_keys:
-        fn = out[0].grad_fn
-        keys = hip_depth_keys(fn.saved_tensors[-1], fn.capacity, x["means3D"].shape[0], s.image_height, s.image_width, out[1])
+        from diff_gaussian_rasterization import saved_block_of
+        saved, cap = saved_block_of(out[0])
+        keys = hip_depth_keys(saved, cap, x["means3D"].shape[0], s.image_height, s.image_width, out[1])
     if wc is not None:
         loss = (out[0] * wc.to(dev).float()).sum() + (out[2] * wd.to(dev).float()).sum()
         loss.backward()

@@ -1,0 +1,415 @@
+"""-m gpu: what round 3 added.
+
+  * the drop-in package's batched backward (autograd collector + sgr_backward_views) against its own per-view path;
+  * FusedAdam against torch.optim.Adam, sgr_densify_stats against the torch formulation;
+  * multi-view final_refine (configs[4]'s loop): 2 ranks sharing the GPU, replicas bitwise, equal to the single-process form;
+  * `bench.py --gpus 2` on a 1-GPU box (self-launch, host-staged gloo);
+  * configs[3] / configs[4] workloads: 300 k Gaussians x 8 views over 2 ranks; 1.5 M Gaussians on one GPU;
+  * the SSIM loss branch falls back to the autograd loop.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PARAMS = ["_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"]
+
+
+def _scene(n=4000, views=4, seed=5, camera="tiny", scale_add=1.2):
+    from splat_slam_amd import synthetic as syn
+    intr = syn.INTRINSICS[camera]
+    params = syn.room_parameters(n, seed=seed, device=DEV)
+    params["scaling"] = params["scaling"] + scale_add
+    cams = syn.make_views(params, views, intr, DEV, seed=seed)
+    return syn, params, cams
+
+
+# ------------------------------------------------------------------------------------------------ drop-in: batched backward
+def _iteration(batch, share, passes=1, n=4000, views=4):
+    """`passes` x (render every camera through the drop-in API, sum the mapping losses, ONE backward)."""
+    import diff_gaussian_rasterization as drg
+    from splat_slam_amd.losses import get_loss_mapping_fused
+    from splat_slam_amd.mapper import PipelineParams
+    from splat_slam_amd.renderer import render
+    syn, params, cams = _scene(n=n, views=views)
+    gm = syn.model_from_parameters(params, device=DEV)
+    gm.share_activations = share
+    bg = torch.zeros(3, device=DEV)
+    old, drg.BATCH = drg.BATCH, batch
+    try:
+        m2 = []
+        for _ in range(passes):
+            loss, pk = 0.0, []
+            for k, c in enumerate(cams):
+                c.exposure_a.data.fill_(0.03 * k - 0.02)
+                pkg = render(c, gm, PipelineParams(), bg)
+                loss = loss + (1.0 + 0.25 * k) * get_loss_mapping_fused(syn.DEFAULT_CONFIG["mapping"], pkg["render"], pkg["depth"], c, pkg["opacity"])
+                pk.append(pkg)
+            loss.backward()
+            m2 = [p["viewspace_points"].grad.clone() for p in pk]
+        torch.cuda.synchronize()
+    finally:
+        drg.BATCH = old
+    out = {name: getattr(gm, name).grad.clone() for name in PARAMS}
+    out["m2"] = m2
+    out["tau"] = [torch.cat([c.cam_trans_delta.grad, c.cam_rot_delta.grad]).clone() for c in cams]
+    out["exp"] = [torch.cat([c.exposure_a.grad, c.exposure_b.grad]).clone() for c in cams]
+    out["radii"] = [p["radii"].clone() for p in pk]
+    return out
+
+
+def test_batched_backward_equals_per_view_backward():
+    """Shared activations -> ONE batch of 4 views: each view's own gradients (means2D, pose) are bitwise those of the per-view
+    path, the five summed gradients agree up to the order of the fp32 additions (in-kernel view order vs the autograd engine's
+    accumulation order).  Unshared activations -> batches of one: everything bitwise."""
+    ref = _iteration(batch=False, share=True)
+    got = _iteration(batch=True, share=True)
+    for k in range(4):
+        assert torch.equal(got["m2"][k], ref["m2"][k]), f"means2D grad of view {k}"
+        assert torch.equal(got["tau"][k], ref["tau"][k]), f"pose grad of view {k}"
+        assert torch.equal(got["exp"][k], ref["exp"][k]) and torch.equal(got["radii"][k], ref["radii"][k])
+        assert got["m2"][k].abs().max() > 0 and got["tau"][k].abs().max() > 0
+    for name in PARAMS:
+        a, b = got[name], ref[name]
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), name
+        assert b.abs().max() > 0
+    one = _iteration(batch=True, share=False)
+    ref1 = _iteration(batch=False, share=False)
+    for name in PARAMS:
+        assert torch.equal(one[name], ref1[name]), name
+    for k in range(4):
+        assert torch.equal(one["m2"][k], ref1["m2"][k]) and torch.equal(one["tau"][k], ref1["tau"][k])
+
+
+def test_batched_backward_accumulates_into_existing_grads():
+    """Two backward passes without zero_grad: parameter and pose `.grad`s accumulate (autograd adds the zero tensors the view
+    nodes return; the collector then adds the values): exactly twice the single pass."""
+    once = _iteration(batch=True, share=True, passes=1)
+    twice = _iteration(batch=True, share=True, passes=2)
+    for name in PARAMS:
+        assert torch.equal(twice[name], 2 * once[name]), name
+    for k in range(4):
+        assert torch.equal(twice["tau"][k], 2 * once["tau"][k]), f"pose grad of view {k}"
+        assert torch.equal(twice["m2"][k], once["m2"][k])          # (a fresh leaf per render)
+
+
+def test_forward_only_renders_release_their_workspaces_and_second_backward_raises():
+    import diff_gaussian_rasterization as drg
+    from splat_slam_amd.losses import get_loss_mapping_fused
+    from splat_slam_amd.mapper import PipelineParams
+    from splat_slam_amd.renderer import render
+    syn, params, cams = _scene(n=3000, views=2)
+    gm = syn.model_from_parameters(params, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    st = drg._state(torch.device(DEV))
+    pkg = render(cams[0], gm, PipelineParams(), bg)
+    del pkg
+    before = sum(len(p) for p in st.pools.values())     # (pools of other shapes may hold blocks of earlier tests)
+    for _ in range(40):                              # an evaluation loop: grad enabled, nothing differentiated (eval_utils.py:90)
+        pkg = render(cams[0], gm, PipelineParams(), bg)
+        del pkg
+    torch.cuda.synchronize()
+    assert sum(len(p) for p in st.pools.values()) <= before + 1, "saved blocks of dropped renders must return to the pool and be reused"
+    assert st.batch is None or len(st.batch.armed) == 0
+    pkg = render(cams[0], gm, PipelineParams(), bg)
+    loss = get_loss_mapping_fused(syn.DEFAULT_CONFIG["mapping"], pkg["render"], pkg["depth"], cams[0], pkg["opacity"])
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already run|second time"):
+        loss.backward()
+    drg.check_overflow()
+
+
+def test_rasterizer_module_keeps_the_module_interface():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    e = torch.eye(4, device=DEV)
+    r = GaussianRasterizer(raster_settings=GaussianRasterizationSettings(8, 8, 1.0, 1.0, torch.zeros(3, device=DEV), 1.0, e, e, e, 0,
+                                                                       torch.zeros(3, device=DEV), False, False))
+    assert isinstance(r, torch.nn.Module) and r.raster_settings.image_height == 8
+    assert list(r.parameters()) == [] and r.training is True and r.raster_settings.image_width == 8    # (deferred Module init)
+    r.eval()
+    assert r.training is False
+
+
+# ------------------------------------------------------------------------------------------------ FusedAdam, statistics
+def test_fused_adam_matches_torch_adam():
+    from splat_slam_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000, 3), (1000, 1, 3), (1000, 0, 3), (1000, 1), (1000, 4)]
+    lrs = [9.6e-4, 2.5e-3, 1.25e-4, 0.05, 1e-3]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    pb = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    oa = FusedAdam([{"params": [p], "lr": lr, "name": str(k)} for k, (p, lr) in enumerate(zip(pa, lrs))], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr, "name": str(k)} for k, (p, lr) in enumerate(zip(pb, lrs))], lr=0.0, eps=1e-15)
+    for step in range(4):
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            if step == 2 and k == 3:
+                x.grad = y.grad = None              # a parameter without a gradient is skipped (no state change)
+                continue
+            gr = torch.randn(x.shape, generator=g).to(DEV) * (10.0 ** (k - 2))
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for x, y, lr in zip(pa, pb, lrs):
+        if x.numel():
+            assert (x - y).abs().max().item() <= 1e-4 * lr * 4 + 2e-7 * y.abs().max().item(), lr
+        sa, sb = oa.state[x], ob.state[y]
+        assert float(sa["step"]) == float(sb["step"])
+        if x.numel():
+            assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=2e-5, atol=1e-9 * float(sb["exp_avg"].abs().max()))
+            assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-5, atol=1e-9 * float(sb["exp_avg_sq"].abs().max()))
+    assert set(oa.state_dict()["state"][0].keys()) == set(ob.state_dict()["state"][0].keys())
+
+
+def test_densify_stats_kernel_matches_torch_formulation():
+    from splat_slam_amd import _native as nat
+    g = torch.Generator().manual_seed(9)
+    n = 5000
+    m2 = torch.randn(n, 3, generator=g).to(DEV)
+    radii = (torch.randint(-2, 30, (n,), generator=g)).int().to(DEV)
+    accum, denom, maxr = torch.rand(n, 1, generator=g).to(DEV), torch.rand(n, 1, generator=g).to(DEV).round(), (30 * torch.rand(n, generator=g)).to(DEV)
+    a2, d2, r2 = accum.clone(), denom.clone(), maxr.clone()
+    nat.check(nat.lib().sgr_densify_stats(n, m2.data_ptr(), radii.data_ptr(), accum.data_ptr(), denom.data_ptr(), maxr.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "sgr_densify_stats")
+    vis = radii > 0
+    a2 += torch.where(vis[:, None], torch.norm(m2[:, :2], dim=-1, keepdim=True), torch.zeros(n, 1, device=DEV))
+    d2 += vis[:, None].float()
+    r2 = torch.where(vis, torch.max(r2, radii), r2)
+    assert torch.allclose(accum, a2, rtol=1e-6, atol=0) and torch.equal(denom, d2) and torch.equal(maxr, r2)
+
+
+# ------------------------------------------------------------------------------------------------ multi-view final_refine
+def _refine_state(f):
+    gm = f.gaussians
+    st = {g["name"]: gm.optimizer.state[g["params"][0]] for g in gm.optimizer.param_groups}
+    out = {k: getattr(gm, k).detach().cpu().clone() for k in PARAMS}
+    out.update({"m_" + k: st[k]["exp_avg"].detach().cpu().clone() for k in ["xyz", "f_dc", "opacity", "scaling", "rotation"]})
+    out.update({"v_" + k: st[k]["exp_avg_sq"].detach().cpu().clone() for k in ["xyz", "scaling"]})
+    out["exposure"] = f._exp.param[:8].detach().cpu().clone()
+    out["steps"] = torch.tensor([float(st[k]["step"]) for k in ["xyz", "f_dc", "opacity", "scaling", "rotation"]])
+    return out
+
+
+def _refine_worker(rank, world, port, out, views_per_step, iters):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from splat_slam_amd.fused import FusedMappingLoop
+    from splat_slam_amd.parallel import Comm
+    from test_gpu_fused import _loop
+    from test_gpu_fused import _scene as scene
+    syn, params, cams = scene(n=2000, views=6, seed=21)
+    f = _loop(FusedMappingLoop, syn, params, cams, [0, 1, 2, 3])
+    f.set_parallel(world, rank, split_views=True, sync="zero1", comm=Comm(staged=True))
+    f.iteration_count = 50
+    np.random.seed(7)
+    f.final_refine(iters=iters, views_per_step=views_per_step)
+    torch.cuda.synchronize()
+    out[rank] = _refine_state(f)
+    dist.destroy_process_group()
+
+
+def _spawn(fn, *args):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(fn, args=(2, port, out) + args, nprocs=2, join=True)
+    return out[0], out[1]
+
+
+def test_final_refine_one_view_per_rank_replicas_bitwise_and_equal_to_single_process():
+    """configs[4]'s loop (mapper.py:656-708) over 2 ranks: each optimiser step renders 2 distinct random views, one per rank
+    (same numpy stream on both), gradients meet in the ZeRO-1 exchange.  Replicas stay bit-identical; a single process that
+    renders both views of every step itself is the same optimisation up to fp32 summation order; 8 renders = 4 Adam steps."""
+    from splat_slam_amd.fused import FusedMappingLoop
+    from test_gpu_fused import _loop
+    from test_gpu_fused import _scene as scene
+    r0, r1 = _spawn(_refine_worker, "world", 8)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), ("ranks differ", k)
+    assert r0["steps"].tolist() == [4.0] * 5
+    syn, params, cams = scene(n=2000, views=6, seed=21)
+    f = _loop(FusedMappingLoop, syn, params, cams, [0, 1, 2, 3])
+    f.iteration_count = 50
+    np.random.seed(7)
+    f.final_refine(iters=8, views_per_step=2)
+    torch.cuda.synchronize()
+    single = _refine_state(f)
+    assert single["steps"].tolist() == [4.0] * 5
+    lr = {"_xyz": 9.6e-4, "_features_dc": 2.5e-3, "_opacity": 0.05, "_scaling": 6e-3, "_rotation": 1e-3}
+    for k, step in lr.items():        # same gradient sums up to summation order: a bounded few rounding-noise flips of Adam's sign
+        d = (r0[k] - single[k]).abs()
+        assert (d > 0.02 * step).float().mean().item() < 0.01, k
+    assert (r0["exposure"] - single["exposure"]).abs().max().item() < 2e-3
+    # the reference's step (one view, replicated on every rank) still works and keeps the replicas identical
+    a0, a1 = _spawn(_refine_worker, 1, 3)
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), ("replicated refine: ranks differ", k)
+    assert a0["steps"].tolist() == [3.0] * 5
+
+
+# ------------------------------------------------------------------------------------------------ bench.py --gpus 2 on one GPU
+def test_bench_gpus_2_starts_two_ranks_on_one_gpu():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gaussians", "20000", "--camera", "tiny", "--steps",
+                        "6", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--refine-iters", "8"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["transport"].startswith("gloo") and d["refine"]["views_per_step"] == 2 and d["refine"]["renders_per_s"] > 0
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"] / 61.0) / d["value"] < 0.01          # strong scaling: no factor N
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]: 8 views over 2 ranks
+def _c3_worker(rank, world, port, out, n):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from splat_slam_amd.fused import FusedMappingLoop
+    from splat_slam_amd.parallel import Comm
+    f = _c3_loop(FusedMappingLoop, n)
+    f.set_parallel(world, rank, split_views=True, sync="zero1", comm=Comm(staged=True))
+    torch.manual_seed(3)
+    f.map(f.current_window, iters=2)
+    torch.cuda.synchronize()
+    s = _refine_state(f)
+    s["overflow"] = torch.tensor([float(f.overflow_events)])
+    out[rank] = s
+    dist.destroy_process_group()
+
+
+def _c3_loop(cls, n):
+    from splat_slam_amd import synthetic as syn
+    intr = syn.INTRINSICS["metric"]
+    params = syn.room_parameters(n, seed=43, device=DEV)
+    cams = syn.make_views(params, 8, intr, DEV, seed=43)
+    f = cls(syn.DEFAULT_CONFIG, device=DEV)
+    f.gaussians = syn.model_from_parameters(params, device=DEV)
+    f.viewpoints = {c.uid: c for c in cams}
+    f.current_window = list(range(8))
+    f.build_keyframe_optimizers()
+    f.iteration_count = 50
+    return f
+
+
+def test_configs3_eight_keyframes_over_two_ranks_at_300k():
+    """configs[3] restated: 300 000 Gaussians, 640x480, the 8 window keyframes of an iteration dealt over the
+    ranks (2 here, sharing the GPU), ZeRO-1 exchange: replicas bitwise, equal to the single-process 8-view iteration up to
+    summation order, no capacity overflow."""
+    from splat_slam_amd.fused import FusedMappingLoop
+    n = 300000
+    r0, r1 = _spawn(_c3_worker, n)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), ("ranks differ", k)
+    assert r0["overflow"].item() == 0 and r0["steps"].tolist() == [2.0] * 5
+    f = _c3_loop(FusedMappingLoop, n)
+    torch.manual_seed(3)
+    f.map(f.current_window, iters=2)
+    torch.cuda.synchronize()
+    single = _refine_state(f)
+    lr = {"_xyz": 9.6e-4, "_features_dc": 2.5e-3, "_opacity": 0.05, "_scaling": 6e-3, "_rotation": 1e-3}
+    for k, step in lr.items():
+        d = (r0[k] - single[k]).abs()
+        assert (d > 0.02 * step).float().mean().item() < 0.01, k
+        assert d.max().item() <= 2 * 2 * step * 1.01, k
+    assert (r0["exposure"] - single["exposure"]).abs().max().item() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]: 1.5 M Gaussians
+def test_configs4_map_size_on_one_gpu_properties_at_full_resolution():
+    """1.5 M Gaussians (configs[4]'s map), 640x480, 2 views through sgr_map_views on ONE GPU: run-to-run determinism, no
+    capacity overflow, fused tile kernel == un-fused pair bit for bit, n_touched / radii consistency, every visible Gaussian
+    accounted for in the densification statistics.  (Oracle parity at this N: the 96x64 camera case below.)"""
+    from splat_slam_amd import _native as nat
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    n = 1500000
+    intr = syn.INTRINSICS["metric"]
+    params = syn.room_parameters(n, seed=43, device=DEV)
+    cams = syn.make_views(params, 2, intr, DEV, seed=43)
+    lib = nat.lib()
+
+    def run(fused_blend):
+        lib.sgr_set_option(nat.SGR_OPT_FUSED_BLEND, fused_blend)
+        try:
+            f = FusedMappingLoop(syn.DEFAULT_CONFIG, device=DEV)
+            f.gaussians = syn.model_from_parameters(params, device=DEV)
+            f.viewpoints = {c.uid: c for c in cams}
+            f.current_window = [0, 1]
+            f.build_keyframe_optimizers()
+            f._ensure_state()
+            f._activate()
+            f._run_views(cams, stats=True)
+            torch.cuda.synchronize()
+            assert f.check_overflow() == [] and f.overflow_events == 0
+        finally:
+            lib.sgr_set_option(nat.SGR_OPT_FUSED_BLEND, 1)
+        return f
+
+    a, b, c = run(1), run(1), run(0)
+    assert torch.equal(a._acc["flat"], b._acc["flat"]), "two identical runs differ"
+    assert torch.equal(a._acc["flat"], c._acc["flat"]), "fused tile kernel != un-fused pair"
+    assert a._acc["flat"].abs().max() > 0 and torch.isfinite(a._acc["flat"]).all()
+    for cam in cams:
+        va, vb, vc = a._views[cam.uid], b._views[cam.uid], c._views[cam.uid]
+        assert torch.equal(va.loss, vb.loss) and torch.equal(va.loss, vc.loss) and torch.equal(va.radii, vc.radii)
+        assert torch.equal(va.n_touched, vc.n_touched)
+        assert int(((va.n_touched > 0) & (va.radii <= 0)).sum()) == 0, "a Gaussian without a footprint was composited"
+        assert int((va.radii > 0).sum()) > 50000
+    gm = a.gaussians
+    seen = (a._views[0].radii > 0).float() + (a._views[1].radii > 0).float()
+    assert torch.equal(gm.denom.reshape(-1), seen)
+    assert float(gm.max_radii2D.max()) > 0 and torch.equal(gm.max_radii2D > 0, seen > 0)
+    assert a._max_list() > 0           # the header's longest list reached the build choice
+
+
+def test_configs4_map_size_oracle_parity_on_a_small_camera():
+    from test_gpu_fullsize import _run_batched_case
+    _run_batched_case(1500000, "tiny", 2)
+
+
+# ------------------------------------------------------------------------------------------------ ssim_loss: True
+def test_ssim_loss_falls_back_to_the_autograd_loop():
+    """`ssim_loss: True` (slam_utils.py:89-98; off by default): FusedMappingLoop runs the reference's loop through autograd (drop-in
+    rasterizer + torch loss) -- same trajectory as MappingLoop with the same config."""
+    import copy
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    from splat_slam_amd.mapper import MappingLoop
+    cfg = copy.deepcopy(syn.DEFAULT_CONFIG)
+    cfg["mapping"]["Training"]["ssim_loss"] = True
+    res = []
+    for cls in (FusedMappingLoop, MappingLoop):
+        s, params, cams = _scene(n=3000, views=4)
+        loop = cls(cfg, device=DEV)
+        loop.gaussians = s.model_from_parameters(params, config=cfg, device=DEV)
+        loop.viewpoints = {c.uid: c for c in cams}
+        loop.current_window = [0, 1, 2]
+        loop.build_keyframe_optimizers()
+        loop.iteration_count = 50
+        torch.manual_seed(1)
+        loop.map(loop.current_window, iters=2)
+        torch.cuda.synchronize()
+        res.append({k: getattr(loop.gaussians, k).detach().clone() for k in PARAMS})
+        if cls is FusedMappingLoop:
+            assert loop.autograd_fallback and loop._acc is None       # no fused state was ever built
+    lr = {"_xyz": 9.6e-4, "_features_dc": 2.5e-3, "_opacity": 0.05, "_scaling": 6e-3, "_rotation": 1e-3}
+    for k in PARAMS:      # (the same ops in the same order; MIOpen's convolution backward may use atomics: allow rounding-noise flips)
+        assert ((res[0][k] - res[1][k]).abs() > 0.02 * lr[k]).float().mean().item() < 0.01, k
