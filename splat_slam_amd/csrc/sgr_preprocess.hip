@@ -247,6 +247,44 @@ __device__ __forceinline__ bool maybe_visible(const float p[3], float trS, int H
   return (rx1 - rx0) * (ry1 - ry0) != 0;
 }
 
+// The same question as four half-space tests (what phase A of K1 runs per (view, Gaussian): ~30 instructions instead of ~100).
+// The rectangle of preprocess_view is non-empty only if  px + rad >= 1,  px - rad < 16 sgx  (and the same in y), with
+//   rad = ceil(3 sqrt(lam)) <= 3 sqrt(|T|_F^2 trS + 0.917) + 1 <= 3 sqrt(|T|_F^2 trS) + 3.88,
+//   |T|_F^2 = |J W|_F^2 <= gmax |J|_F^2,  |J|_F^2 <= (fx^2 (1 + limx^2) + fy^2 (1 + limy^2)) / z^2   (the clamped Jacobian),
+// gmax = a Gershgorin bound of the largest eigenvalue of W W^T (1 for a rigid view matrix).  So rad <= K sqrt(trS) / z + 3.88
+// with a per-view constant K, and with px = hx ph0 / w + hx - 1/2 (w = ph3 + 1e-7 > 0, z > 0) each condition becomes linear
+// after multiplying by w z:   (hx ph0 + (hx + 4.5) w) z + K s w >= 0   etc. (5 px of slack instead of 3.88 + rounding).
+// Conservative like maybe_visible (a few per cent more candidates near the image border); anything not finite passes.
+__device__ __forceinline__ float cull_radius_factor(const float* vm, int H, int W, float tanfovx, float tanfovy) {
+  float g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {       // G = W W^T, W[r][c] = vm[c*4+r]
+      const float gij = vm[i] * vm[j] + vm[4 + i] * vm[4 + j] + vm[8 + i] * vm[8 + j];
+      g[i] += fabsf(gij);
+    }
+  const float gmax = fmaxf(g[0], fmaxf(g[1], g[2]));
+  const float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy), limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+  return 3.f * sqrtf(gmax * (fx * fx * (1.f + limx * limx) + fy * fy * (1.f + limy * limy))) * 1.003f;
+}
+__device__ __forceinline__ bool maybe_visible_planes(const float p[3], float s, const float* vm, const float* pm, float K, int H, int W,
+                                                     int sgx, int sgy) {
+  const float z = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
+  if (!(z > kNearPlane * 0.999f)) return false;
+  const float w = pm[3] * p[0] + pm[7] * p[1] + pm[11] * p[2] + pm[15] + 1e-7f;
+  if (!(w > 0.f)) return true;                                   // let the exact path decide
+  const float ph0 = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
+  const float ph1 = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
+  const float hx = 0.5f * (float)W, hy = 0.5f * (float)H, ksw = K * s * w;
+  const float ax = hx * ph0, ay = hy * ph1;
+  const float l = (ax + (hx + 4.5f) * w) * z + ksw;                              // px + rad_b >= 0
+  const float r = (ax + (hx - 5.5f - (float)(sgx * kRefTile)) * w) * z - ksw;    // px - rad_b < 16 sgx
+  const float t = (ay + (hy + 4.5f) * w) * z + ksw;
+  const float b = (ay + (hy - 5.5f - (float)(sgy * kRefTile)) * w) * z - ksw;
+  return !(l < 0.f) && !(r >= 0.f) && !(t < 0.f) && !(b >= 0.f);
+}
+
 // K1.  grid = ceil(N/256) blocks of 256 threads; a block owns a SEGMENT of 256 consecutive Gaussians for ALL views of
 // the batch (<= 16):
 //   phase A  thread = Gaussian: its position / scale / rotation are loaded ONCE and tested against every view with
@@ -279,6 +317,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ uint4 op_rect[kSeg];                // ... its rectangle (x0 | x1 << 16, y0 | y1 << 16), view, Gaussian
   __shared__ uint32_t op_depth[kSeg];            // ... the depth half of its key
   __shared__ float4 op_foot[kSeg][2];            // ... and its footprint (exact bin test): px py A B | C 1/A 1/C thr
+  __shared__ float cullK[kMaxViews];             // per view: radius bound factor of the plane test (see cull_planes)
   __shared__ float seg_box[4][8];                // per wave: min xyz, max xyz, max trS of its 64 Gaussians
   __shared__ uint32_t seg_views;                 // bit v = some Gaussian of this segment MAY be visible in view v
   const int N = L.N;
@@ -298,6 +337,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   if (tid <= kMaxViews) { vbase_t[tid] = 0u; vbase_v[tid] = 0u; }
   if (tid == 0) seg_views = 0xffffffffu;         // (every view, unless the whole-segment test below says otherwise)
   vis_bits[tid] = 0u;
+  __syncthreads();
+  if (tid < nviews) cullK[tid] = cull_radius_factor(mats[tid], L.H, L.W, cm.tanfovx, cm.tanfovy);
   __syncthreads();
 
   // ---- phase A
@@ -405,6 +446,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       __syncthreads();
     }
     const uint32_t segv = seg_views;
+    const float sroot = __builtin_amdgcn_sqrtf(fmaxf(trS, 0.f)) * 1.0005f;      // (NaN stays NaN: the test then passes the Gaussian on)
 #pragma unroll 2
     for (int v = 0; v < nviews; ++v) {
       bool pass = false;
@@ -412,7 +454,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         p_radii[v][ia] = 0;                // outputs of the culled majority; phase B overwrites the visible ones
         if (p_ntouched[v]) p_ntouched[v][ia] = 0;
         if (L.dbg & 2) pass = (p[0] + trS == 12345.678f);
-        else if (segv & (1u << v)) pass = maybe_visible(p, trS, L.H, L.W, cm.tanfovx, cm.tanfovy, mats[v], mats[v] + 16, L.sgx, L.sgy);
+        else if (segv & (1u << v)) pass = (L.dbg & 8) ? maybe_visible(p, trS, L.H, L.W, cm.tanfovx, cm.tanfovy, mats[v], mats[v] + 16, L.sgx, L.sgy)
+                                                      : maybe_visible_planes(p, sroot, mats[v], mats[v] + 16, cullK[v], L.H, L.W, L.sgx, L.sgy);
       }
       const unsigned long long m = __ballot(pass);
       if (lane == 0) wtot[v][wv] = (uint32_t)__popcll(m);

@@ -175,6 +175,99 @@ def test_backward_chunk_plan_covers_every_list_position_once():
         assert iters <= old + (2 if eff <= 32 else 0), (eff, iters, old)
 
 
+def test_plane_cull_is_conservative_for_the_exact_rectangle_test():
+    """csrc/sgr_preprocess.hip maybe_visible_planes (phase A of K1), restated in fp32 numpy next to the exact decision of
+    preprocess_view (near plane + non-empty reference-tile rectangle): the cheap test may pass Gaussians the exact path rejects,
+    never the other way round -- for splats of every size, in front of / beside / behind the camera, any principal point."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    f32 = np.float32
+    near = f32(0.001)
+    n_vis = n_pass = 0
+    for trial in range(40):
+        W, H = [(640, 480), (640, 320), (96, 64), (321, 243)][trial % 4]
+        fx, fy = f32(rng.uniform(0.5, 1.2) * W), f32(rng.uniform(0.5, 1.2) * W)
+        cx, cy = f32(W / 2 + rng.uniform(-20, 20)), f32(H / 2 + rng.uniform(-20, 20))
+        tanfovx, tanfovy = f32(W / (2 * fx)), f32(H / (2 * fy))
+        # rigid W2C
+        a = rng.normal(size=3)
+        a /= np.linalg.norm(a)
+        th = rng.uniform(0, np.pi)
+        Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        t = rng.normal(size=3)
+        w2c = np.eye(4)
+        w2c[:3, :3], w2c[:3, 3] = R, t
+        P = np.zeros((4, 4))
+        zn, zf = 0.01, 100.0
+        P[0, 0], P[1, 1] = 2 * fx / W, 2 * fy / H
+        P[0, 2], P[1, 2] = 2 * (cx + 0.5) / W - 1.0, 2 * (cy + 0.5) / H - 1.0      # (principal-point offset: any value will do here)
+        P[3, 2], P[2, 2], P[2, 3] = 1.0, zf / (zf - zn), -(zf * zn) / (zf - zn)
+        vm = w2c.T.astype(f32).reshape(-1)                   # transposed layout: W2C[r][c] = vm[c*4+r]
+        pm = (w2c.T @ P.T).astype(f32).reshape(-1)
+        sgx, sgy = (W + 15) // 16, (H + 15) // 16
+        n = 4000
+        pc = np.concatenate([rng.normal(size=(n // 2, 3)) * [3, 3, 3] + [0, 0, 3], rng.normal(size=(n - n // 2, 3)) * 0.2 + [0, 0, 0.05]])
+        pts = ((pc - t) @ R).astype(f32)                     # world points spread around the frustum
+        scales = np.exp(rng.uniform(np.log(1e-3), np.log(0.8), size=(n, 3))).astype(f32)
+        q = rng.normal(size=(n, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        r_, x, y, z = q.T
+        Rq = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r_ * z), 2 * (x * z + r_ * y), 2 * (x * y + r_ * z), 1 - 2 * (x * x + z * z),
+                       2 * (y * z - r_ * x), 2 * (x * z - r_ * y), 2 * (y * z + r_ * x), 1 - 2 * (x * x + y * y)], 1).reshape(n, 3, 3)
+        M = Rq * scales[:, None, :]
+        Sig = (M @ M.transpose(0, 2, 1)).astype(f32)
+        trS = f32(1.01) * (scales ** 2).sum(1)
+        # ---- exact (preprocess_view)
+        Wm = vm.reshape(4, 4).T[:3, :3]
+        pv = pts @ Wm.T + vm.reshape(4, 4).T[:3, 3]
+        front = pv[:, 2] > near
+        ph = np.concatenate([pts, np.ones((n, 1), f32)], 1) @ pm.reshape(4, 4)
+        pw = f32(1) / (ph[:, 3] + f32(1e-7))
+        ndcx, ndcy = ph[:, 0] * pw, ph[:, 1] * pw
+        limx, limy = f32(1.3) * tanfovx, f32(1.3) * tanfovy
+        fxp, fyp = f32(W) / (2 * tanfovx), f32(H) / (2 * tanfovy)
+        tz = np.where(front, pv[:, 2], 1)
+        tx = np.clip(pv[:, 0] / tz, -limx, limx) * tz
+        ty = np.clip(pv[:, 1] / tz, -limy, limy) * tz
+        J = np.zeros((n, 2, 3), f32)
+        J[:, 0, 0], J[:, 0, 2], J[:, 1, 1], J[:, 1, 2] = fxp / tz, -fxp * tx / tz ** 2, fyp / tz, -fyp * ty / tz ** 2
+        T = J @ Wm
+        cov = T @ Sig @ T.transpose(0, 2, 1)
+        ca, cb, cc = cov[:, 0, 0] + f32(0.3), cov[:, 0, 1], cov[:, 1, 1] + f32(0.3)
+        det = ca * cc - cb * cb
+        mid = 0.5 * (ca + cc)
+        lam = mid + np.sqrt(np.maximum(0.1, mid * mid - det))
+        rad = np.ceil(3 * np.sqrt(lam))
+        px, py = ((ndcx + 1) * W - 1) * 0.5, ((ndcy + 1) * H - 1) * 0.5
+        tr = lambda v: np.trunc(v).astype(np.int64)
+        rx0 = np.clip(tr((px - rad) / 16), 0, sgx)
+        rx1 = np.clip(tr((px + rad + 15) / 16), 0, sgx)
+        ry0 = np.clip(tr((py - rad) / 16), 0, sgy)
+        ry1 = np.clip(tr((py + rad + 15) / 16), 0, sgy)
+        with np.errstate(all="ignore"):
+            exact = front & (det != 0) & np.isfinite(px) & np.isfinite(py) & np.isfinite(rad) & ((rx1 - rx0) * (ry1 - ry0) != 0)
+        # ---- plane test (fp32, the kernel's operation order)
+        G = np.abs(Wm.astype(f32) @ Wm.astype(f32).T).sum(1)
+        K = f32(3) * np.sqrt(G.max() * (fxp * fxp * (1 + limx * limx) + fyp * fyp * (1 + limy * limy))) * f32(1.003)
+        s = np.sqrt(np.maximum(trS, 0)).astype(f32) * f32(1.0005)
+        zc = vm[2] * pts[:, 0] + vm[6] * pts[:, 1] + vm[10] * pts[:, 2] + vm[14]
+        w = pm[3] * pts[:, 0] + pm[7] * pts[:, 1] + pm[11] * pts[:, 2] + pm[15] + f32(1e-7)
+        ph0 = pm[0] * pts[:, 0] + pm[4] * pts[:, 1] + pm[8] * pts[:, 2] + pm[12]
+        ph1 = pm[1] * pts[:, 0] + pm[5] * pts[:, 1] + pm[9] * pts[:, 2] + pm[13]
+        hx, hy, ksw = f32(0.5 * W), f32(0.5 * H), K * s * w
+        ax, ay = hx * ph0, hy * ph1
+        l = (ax + (hx + f32(4.5)) * w) * zc + ksw
+        r = (ax + (hx - f32(5.5) - f32(sgx * 16)) * w) * zc - ksw
+        tt = (ay + (hy + f32(4.5)) * w) * zc + ksw
+        b = (ay + (hy - f32(5.5) - f32(sgy * 16)) * w) * zc - ksw
+        planes = (zc > near * f32(0.999)) & (~(w > 0) | (~(l < 0) & ~(r >= 0) & ~(tt < 0) & ~(b >= 0)))
+        assert not bool((exact & ~planes).any()), f"trial {trial}: the plane test rejected {int((exact & ~planes).sum())} visible Gaussians"
+        n_vis += int(exact.sum())
+        n_pass += int(planes.sum())
+    assert n_vis > 10000 and n_pass < 2.0 * n_vis, (n_vis, n_pass)       # conservative, yet a real filter
+
+
 def test_footprint_bin_test_is_a_lower_bound_of_the_quadratic_form():
     """csrc/sgr_common.h footprint_qmin, restated: the minimum of q = A dx^2 + 2 B dx dy + C dy^2 over the bounding box of a
     bin's 8x8 pixel centres (0 if the centre is inside, else the smallest of the four edge minima).  It must never exceed q at
