@@ -41,27 +41,48 @@ class _Plan:
 
 
 class _ViewBuffers:
+    """Per-camera device buffers.  They SURVIVE changes of the map size (every keyframe appends Gaussians, every densification
+    changes N): re-making ~150 cameras' buffers -- and above all their ~250 MB workspaces, whose sizes never repeat exactly, so
+    the caching allocator went to hipMalloc for them -- cost a converged session 25-30 ms of host time per keyframe, during which
+    the GPU idled.  Images depend on (H, W) only; the per-Gaussian int buffers and the workspaces are allocated with head-room
+    and re-carved."""
+
     def __init__(self, H, W, N, dev):
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        self.dev = dev
         self.color, self.depth, self.opacity = f(3, H, W), f(1, H, W), f(1, H, W)
-        self.radii = torch.empty(N, dtype=torch.int32, device=dev)
-        self.n_touched = torch.empty(N, dtype=torch.int32, device=dev)
         self.d_color, self.d_depth = f(3, H, W), f(1, H, W)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.d_exp = torch.zeros(2, dtype=torch.float32, device=dev)
         self.d_tau = torch.zeros(6, dtype=torch.float32, device=dev)
         ntiles = ((H + 7) // 8) * ((W + 7) // 8)
         self.loss_scratch = torch.empty(max(1024, ntiles) * 16, dtype=torch.uint8, device=dev)   # one LossPart per 8x8 tile
+        self._ibuf, self._icap = None, 0
         self.saved = None
         self.scratch = None
-        self.clean = False         # the saved block went through a forward with its current layout (counters are zero)
-        self.pairs = -1            # (tile, Gaussian) pairs seen by the probe render; -1 = not probed at this map size
-        self.estimated = False     # `pairs` is a carried-over estimate, not yet confirmed by a header read at this map size
+        self.clean = False         # the saved block went through a forward (its per-tile counters are zero)
         self.capacity = 0
         self.gt_depth = None
         self.depth_src = None
+        self.new_map(N)
+
+    def new_map(self, N):
+        """The map changed size: counts measured at the old size are hints only, cached structs are stale."""
+        if N > self._icap:
+            self._icap = int(N * 1.3) + 4096
+            self._ibuf = torch.empty(2 * self._icap, dtype=torch.int32, device=self.dev)
+        self.radii, self.n_touched = self._ibuf[:N], self._ibuf[self._icap:self._icap + N]
+        self.n = N
+        self.pairs = -1            # (tile, Gaussian) pairs seen by the probe render; -1 = not probed at this map size
+        self.estimated = False     # `pairs` is a carried-over estimate, not yet confirmed by a header read at this map size
+        self.ran = False           # a forward has run on the saved block at THIS map size (its header is current)
         self.mv = None
         self.mv_key = None
+
+
+def _index(rows, device):
+    """Row indices on the device without a blocking pageable copy (torch.tensor(..., device=...) waits for the stream)."""
+    return torch.tensor(list(rows), dtype=torch.long).pin_memory().to(device, non_blocking=True)
 
 
 class _ExposureSlab:
@@ -118,7 +139,7 @@ class _ExposureSlab:
     def keep_stale(self, rows):
         """A prune pass wrote its exposure gradients into grad[rows]; like `.grad` in the reference they are ADDED to."""
         if rows:
-            idx = torch.tensor(sorted(set(rows)), dtype=torch.long, device=self.param.device)
+            idx = _index(sorted(set(rows)), self.param.device)
             self.stale[idx] += self.grad[idx]
             self.stale_rows.update(int(r) for r in rows)
 
@@ -126,7 +147,7 @@ class _ExposureSlab:
         """grad[rows] += stale[rows] for the rows an optimiser is about to step (and then zero_grad's): returns those rows."""
         hit = sorted(r for r in rows if r in self.stale_rows)
         if hit:
-            idx = torch.tensor(hit, dtype=torch.long, device=self.param.device)
+            idx = _index(hit, self.param.device)
             self.grad[idx] += self.stale[idx]
             self.stale[idx] = 0
             self.stale_rows.difference_update(hit)
@@ -135,7 +156,7 @@ class _ExposureSlab:
     def reset(self, rows):
         self.active.zero_()
         if rows:
-            idx = torch.tensor(rows, dtype=torch.long, device=self.param.device)
+            idx = _index(rows, self.param.device)
             self.m[idx] = 0
             self.v[idx] = 0
             self.step[idx] = 0
@@ -187,6 +208,7 @@ class FusedMappingLoop(MappingLoop):
         self._since_check = 0
         self._pair_hint = {}       # camera uid -> (measured pair count, map size it was measured at)
         self._list_hint = {}       # camera uid -> longest per-tile list measured (header word 10): picks the tile kernels' sort build
+        self._ws_bytes = {}        # (N, H, W, capacity) -> (saved bytes, scratch bytes)
         self._exp = None
         self._exp_rows = []
         self._cap = 0
@@ -274,7 +296,11 @@ class FusedMappingLoop(MappingLoop):
         self._acc_key, self._acc_ids = key, ids
         self._acc_clean = True     # the gradient sinks are all-zero (every Adam step leaves them so)
         self._stale_iso = 0.0      # (every tensor is new: nothing a prune pass left behind survives)
-        self._views = {}           # N changed: per-camera buffers are re-made lazily
+        # N changed: the per-camera buffers stay (see _ViewBuffers), cameras that left the map are dropped
+        live = set(self.viewpoints)
+        self._views = {uid: vb for uid, vb in self._views.items() if uid in live}
+        for vb in self._views.values():
+            vb.new_map(N)
         self._cap = 0
         if gm.active_sh_degree != 0 or gm._features_rest.numel() != 0:
             raise NotImplementedError("FusedMappingLoop supports the reference's default sh_degree 0 (mapper.py:85)")
@@ -396,13 +422,21 @@ class FusedMappingLoop(MappingLoop):
     def _workspace(self, vb, N, H, W, cap):
         """Saved + scratch blocks of one camera.  Scratch is private per camera: the views of an iteration run as ONE
         batched launch per stage (sgr_map_views), so they cannot share it."""
-        sb, tb = self.lib.sgr_saved_bytes(N, H, W, cap), self.lib.sgr_scratch_bytes(N, H, W, cap)
-        if vb.saved is None or vb.saved.numel() < sb or vb.capacity != cap:
-            vb.saved = torch.empty(sb, dtype=torch.uint8, device=self.device)
-            vb.capacity = cap
+        key = (N, H, W, cap)
+        sz = self._ws_bytes.get(key)
+        if sz is None:
+            if len(self._ws_bytes) > 64:
+                self._ws_bytes.clear()
+            sz = self._ws_bytes[key] = (self.lib.sgr_saved_bytes(N, H, W, cap), self.lib.sgr_scratch_bytes(N, H, W, cap))
+        sb, tb = sz
+        # blocks are kept across map sizes and capacities (head-room: a map grows by a few per cent per keyframe).  The per-tile
+        # counters sit at a fixed offset for a given (H, W), so a block that went through a forward stays clean whatever N is
+        if vb.saved is None or vb.saved.numel() < sb:
+            vb.saved = torch.empty(int(sb * 1.3) + (1 << 20), dtype=torch.uint8, device=self.device)
             vb.clean = False       # per-tile counters of a fresh block are garbage: the library zeroes them once
+        vb.capacity = cap
         if vb.scratch is None or vb.scratch.numel() < tb:
-            vb.scratch = torch.empty(tb, dtype=torch.uint8, device=self.device)
+            vb.scratch = torch.empty(int(tb * 1.3) + (1 << 20), dtype=torch.uint8, device=self.device)
         return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), cap,
                                 int(vb.clean), self._max_list())
 
@@ -465,7 +499,7 @@ class FusedMappingLoop(MappingLoop):
                 continue
             nat.check(rc, "sgr_forward")
             break
-        vb.clean = True
+        vb.clean = vb.ran = True
         self._read_header(cam.uid, vb)            # (also the longest list: the sort build of the tile kernels)
         if vb.pairs > self.max_pairs:
             gm = self.gaussians
@@ -478,7 +512,10 @@ class FusedMappingLoop(MappingLoop):
         """A completed forward leaves the per-tile counters of a saved block zero: later calls skip the zeroing launch."""
         for c in cams:
             vb = self._views.get(c.uid)
-            if vb is not None and not vb.clean:
+            if vb is None:
+                continue
+            vb.ran = True
+            if not vb.clean:
                 vb.clean = True
                 for _, mv in (vb.mv or {}).values():
                     mv.ws.counters_clean = 1
@@ -841,7 +878,7 @@ class FusedMappingLoop(MappingLoop):
             rendered = [r for r in rows if r in self._exp_rows]
             stale_only = [r for r in self._exp_rows if r in self._exp.stale_rows and r not in rows]
             if stale_only:
-                self._exp.grad[torch.tensor(stale_only, dtype=torch.long, device=self.device)] = 0
+                self._exp.grad[_index(stale_only, self.device)] = 0
             self._exp.add_stale(self._exp_rows)
             self._exposure_exchange(self._exp_rows)
             for row in sorted(set(rendered) | set(stale_only)):
@@ -864,7 +901,7 @@ class FusedMappingLoop(MappingLoop):
         self._since_check = 0
         worst, overflowed = 0, []
         for uid, vb in self._views.items():
-            if vb.saved is None or not vb.mv or not vb.clean:      # (a block no forward has run on yet holds no header)
+            if vb.saved is None or not vb.mv or not vb.ran:        # (no forward at this map size yet: the header is an old one)
                 continue
             R, ov = self._read_header(uid, vb)
             if ov == 2:
