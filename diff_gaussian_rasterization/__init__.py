@@ -20,8 +20,10 @@ batching off (every view returns its own dense gradients, as upstream does).
 # flake8: noqa: E501
 from typing import NamedTuple
 
+import collections
 import ctypes as C
 import os
+import time
 import weakref
 
 import torch
@@ -70,6 +72,11 @@ class GaussianRasterizationSettings(NamedTuple):
 # ----------------------------------------------------------------------------------------------------------------
 SYNC = os.environ.get("SPLAT_RASTER_SYNC", "0") == "1"
 BATCH = os.environ.get("SPLAT_RASTER_BATCH", "1") != "0"
+# The camera-pose gradients (theta, rho: 3 floats each per view) of a batch are written into `.grad` by the collector -- set, or
+# added in ONE multi-tensor launch -- instead of travelling through 2 AccumulateGrad nodes (+ 2 tiny launches) per view:
+# `loss.backward()` leaves the same `.grad`s as upstream.  0: strict autograd semantics also for torch.autograd.grad / tensor
+# hooks on the pose deltas (the nodes then return the pose gradients themselves).
+DEFER_POSE_GRADS = os.environ.get("SPLAT_RASTER_DEFER_POSE_GRADS", "1") != "0"
 _RING = 64
 _SENTINEL = 0xFFFFFFFF
 _CAP_FLOOR = 1 << 20
@@ -152,7 +159,13 @@ class _DeviceState:
             if self.ring_np[slot, 15] == _SENTINEL:            # the copy has not landed yet
                 if not wait:
                     break
-                torch.cuda.current_stream(self.dev).synchronize()
+                # the copy was enqueued right behind its forward: it lands long before later work on the stream finishes, so
+                # poll the pinned word for a while before falling back to a stream synchronisation
+                t_end = time.perf_counter() + 200e-6
+                while self.ring_np[slot, 15] == _SENTINEL and time.perf_counter() < t_end:
+                    pass
+                if self.ring_np[slot, 15] == _SENTINEL:
+                    torch.cuda.current_stream(self.dev).synchronize()
             R = int(self.ring_np[slot, 0])
             if int(self.ring_np[slot, 1]) == 2:                # header.overflow == 2: a 16-bit tile counter saturated
                 self.pending.pop(0)
@@ -227,7 +240,7 @@ def _stream_of(dev):
 class _ViewRecord:
     """What the collector needs from one forward to run its backward later."""
     __slots__ = ("settings", "keep", "radii", "lease", "cap", "saved_bytes", "H", "W", "grad_color", "grad_depth", "arena",
-                 "means2D", "theta", "rho", "armed", "__weakref__")
+                 "means2D", "theta", "rho", "armed", "strict_pose", "__weakref__")
 
 
 class _Batch:
@@ -264,7 +277,17 @@ class _Collect(torch.autograd.Function):
         return (None,) + out
 
 
+_PROF = collections.Counter() if os.environ.get("SPLAT_RASTER_PROF") else None      # phase timers of the collector (scripts/profile_dropin.py)
+
+
+def _tick(name, t0):
+    t1 = time.perf_counter()
+    _PROF[name] += t1 - t0
+    return t1
+
+
 def _batched_backward(batch):
+    t_ = time.perf_counter() if _PROF is not None else 0.0
     if batch.closed:
         raise RuntimeError("diff_gaussian_rasterization: backward through the renders of this parameter set a second time "
                            "(their workspaces were released by the first backward; render again, or set SPLAT_RASTER_BATCH=0)")
@@ -279,6 +302,8 @@ def _batched_backward(batch):
     N, M = batch.N, batch.M
     # every forward of this iteration has its header on the way: make sure none of them dropped pairs BEFORE producing gradients
     st.report(wait=True)
+    if _PROF is not None:
+        t_ = _tick("collector: wait for the forwards' headers", t_)
     # ONE arena for the five summed gradients (each written in full by the gather pass)
     widths = (3, 3 * M, 1, 3, 4)
     arena = torch.empty(N * sum(widths), dtype=torch.float32, device=dev)
@@ -292,35 +317,56 @@ def _batched_backward(batch):
     gi = nat.SgrGradInputs(d_means3D.data_ptr(), None, d_opac.data_ptr(), d_sh.data_ptr(), None, d_scales.data_ptr(), d_rot.data_ptr(),
                            None, None)
     nv = len(views)
-    arr = (nat.SgrBackwardView * max(1, nv))()
-    keep = []
+    keep, items = [], []
+    dtau = torch.zeros((max(1, nv), 6), dtype=torch.float32, device=dev)       # (rho[3], theta[3]) of every view
+    dtau_ptr = dtau.data_ptr()
     for k, r in enumerate(views):
         _, scratch_bytes = st.bytes_for(N, r.H, r.W, r.cap)
         sc = st.scratch_block(k, scratch_bytes)
         keep.append(sc)
-        bv = arr[k]
-        bv.settings = r.settings
-        bv.radii = r.radii.data_ptr()
-        bv.ws = nat.SgrWorkspace(r.lease.block.data_ptr(), r.saved_bytes, sc.data_ptr(), sc.numel(), r.cap)
-        bv.dL_dcolor = r.grad_color.data_ptr()
-        bv.dL_ddepth = None if r.grad_depth is None else r.grad_depth.data_ptr()
-        bv.dL_dmeans2D = r.arena.data_ptr()
-        bv.dL_dtau = r.arena.data_ptr() + 12 * N
+        base = r.arena.data_ptr()
+        items.append(nat.SgrBackwardView(r.settings, r.radii.data_ptr(),
+                                         nat.SgrWorkspace(r.lease.block.data_ptr(), r.saved_bytes, sc.data_ptr(), sc.numel(), r.cap, 0, 0),
+                                         r.grad_color.data_ptr(), None if r.grad_depth is None else r.grad_depth.data_ptr(), base,
+                                         (base + 12 * N) if r.strict_pose else (dtau_ptr + 24 * k)))
+    if _PROF is not None:
+        t_ = _tick("collector: buffers + structs", t_)
     if nv == 0:
         arena.zero_()
     else:
+        arr = (nat.SgrBackwardView * nv)(*items)
         nat.check(lib.sgr_backward_views(nv, arr, C.byref(inp), C.byref(gi), stream), "sgr_backward_views")
-    # the per-view gradients (means2D, pose) were RETURNED by the views' own backward nodes as zero tensors before this launch
-    # filled them.  Where autograd kept that very tensor as `.grad` (a fresh leaf: it steals a gradient nobody else references)
-    # the values are in place now; where it copied or accumulated (an existing `.grad`, a retained non-leaf), the copy holds
-    # zeros + whatever was there before: add the values.
-    for r in views:
-        for p, off, n in ((r.means2D, 0, 3 * N), (r.rho, 3 * N, 3), (r.theta, 3 * N + 3, 3)):
+    if _PROF is not None:
+        t_ = _tick("collector: sgr_backward_views (launches)", t_)
+    # the per-view gradients (means2D; pose in strict mode) were RETURNED by the views' own backward nodes as zero tensors before
+    # this launch filled them.  Where autograd kept that very tensor as `.grad` (a fresh leaf: it steals a gradient nobody else
+    # references) the values are in place now; where it copied or accumulated (an existing `.grad`, a retained non-leaf), the
+    # copy holds zeros + whatever was there before: add the values (all of them in one multi-tensor launch).
+    fix_g, fix_v = [], []
+    for k, r in enumerate(views):
+        base = r.arena.data_ptr()
+        todo = ((r.means2D, 0, 3 * N), (r.rho, 3 * N, 3), (r.theta, 3 * N + 3, 3)) if r.strict_pose else ((r.means2D, 0, 3 * N),)
+        for p, off, n in todo:
             if p is None:
                 continue
             g = p.grad
-            if g is not None and g.data_ptr() != r.arena.data_ptr() + 4 * off:
-                g.add_(r.arena[off:off + n].view(g.shape))
+            if g is not None and g.data_ptr() != base + 4 * off:
+                fix_g.append(g)
+                fix_v.append(r.arena[off:off + n].view(g.shape))
+        if not r.strict_pose:          # deferred pose gradients: this function IS their accumulation step
+            for p, lo in ((r.rho, 0), (r.theta, 3)):
+                if p is None:
+                    continue
+                v = dtau[k, lo:lo + 3].view(p.shape)
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    fix_g.append(p.grad)
+                    fix_v.append(v)
+    if fix_g:
+        torch._foreach_add_(fix_g, fix_v)
+    if _PROF is not None:
+        _tick("collector: per-view leaf gradients", t_)
     return d_means3D.view(means3D.shape), d_sh.view(sh.shape), d_opac.view(opacities.shape), d_scales.view(scales.shape), d_rot.view(rotations.shape)
 
 
@@ -332,16 +378,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         if not means3D.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization (MI355X build): `means3D` must be a GPU tensor; there is no CPU path")
-        means3D = _f32c(means3D)
+        if batch is None:            # (the shared inputs of a batch were checked by _batchable: fp32, contiguous, on the GPU)
+            means3D = _f32c(means3D)
+            sh = _f32c(_empty_to_none(sh))
+            colors_precomp = _f32c(_empty_to_none(colors_precomp))
+            opacities = _f32c(opacities)
+            scales = _f32c(_empty_to_none(scales))
+            rotations = _f32c(_empty_to_none(rotations))
+            cov3Ds_precomp = _f32c(_empty_to_none(cov3Ds_precomp))
         dev = means3D.device
         N = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
-        sh = _f32c(_empty_to_none(sh))
-        colors_precomp = _f32c(_empty_to_none(colors_precomp))
-        opacities = _f32c(opacities)
-        scales = _f32c(_empty_to_none(scales))
-        rotations = _f32c(_empty_to_none(rotations))
-        cov3Ds_precomp = _f32c(_empty_to_none(cov3Ds_precomp))
         bg, view, proj, praw, campos = (_f32c(rs.bg), _f32c(rs.viewmatrix), _f32c(rs.projmatrix), _f32c(rs.projmatrix_raw),
                                         _f32c(rs.campos))
         if not (opacities.is_cuda and bg.is_cuda and view.is_cuda and proj.is_cuda and praw.is_cuda and campos.is_cuda):
@@ -401,6 +448,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             r.theta = theta if (ctx.has_theta and theta.requires_grad) else None
             r.rho = rho if (ctx.has_rho and rho.requires_grad) else None
             r.armed = False
+            r.strict_pose = not DEFER_POSE_GRADS
             ctx.record, ctx.batch = r, batch
             ctx.pose_like = (theta if ctx.has_theta else None, rho if ctx.has_rho else None)
             return color, radii, depth, opac, n_touched
@@ -432,9 +480,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             if not r.armed:
                 r.armed = True
                 batch.armed.append(r)
-            theta_like, rho_like = ctx.pose_like
-            g_rho = r.arena[3 * N:3 * N + 3].view(rho_like.shape) if ctx.has_rho else None
-            g_theta = r.arena[3 * N + 3:].view(theta_like.shape) if ctx.has_theta else None
+            g_rho = g_theta = None
+            if r.strict_pose:
+                theta_like, rho_like = ctx.pose_like
+                g_rho = r.arena[3 * N:3 * N + 3].view(rho_like.shape) if ctx.has_rho else None
+                g_theta = r.arena[3 * N + 3:].view(theta_like.shape) if ctx.has_theta else None
             return (None, r.arena[:3 * N].view(N, 3), None, None, None, None, None, None, g_theta, g_rho, None, None)
 
         lib = nat.lib()

@@ -268,6 +268,19 @@ int sgr_mapping_loss(int32_t H, int32_t W, const float* image, const float* dept
 int sgr_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* The same step for MANY SMALL tensors that share lr / betas / eps, in one launch per 48 tensors (block = tensor): the keyframe
+ * optimiser of src/mapper.py:1096-1111 holds two one-element exposure parameters (and two 3-vectors of pose deltas) per window
+ * keyframe.  Each tensor carries its own step count (AFTER increment). */
+typedef struct SgrAdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;                   /* elements (<= 2^20) */
+  int64_t step;
+} SgrAdamTensor;
+int sgr_adam_step_multi(int32_t count, const SgrAdamTensor* tensors, float lr, float beta1, float beta2, float eps, void* stream);
+
 /* Activations of the GaussianModel getters (gaussian_model.py:76-101) in one pass:
  * scales_out = exp(scaling), rot_out = rotation / max(|rotation|, 1e-12), opac_out = sigmoid(opacity). */
 int sgr_activate(int64_t n, const float* scaling, const float* rotation, const float* opacity,

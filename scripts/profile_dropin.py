@@ -3,6 +3,8 @@ Python entry points: no profiler overhead) over map() iterations of splat_slam_a
 configuration, then a cProfile listing of the same loop.
 
     python scripts/profile_dropin.py [--iters 20] [--no-batch] [--out gpurun_out/dropin_phases.json]"""
+import os
+os.environ["SPLAT_RASTER_PROF"] = "1"
 import argparse
 import cProfile
 import collections
@@ -45,6 +47,7 @@ res = {"batched_backward": drg.BATCH, "ms_per_iteration_host_enqueue": round(1e3
 
 T = collections.Counter()
 CNT = collections.Counter()
+SAMPLES = collections.defaultdict(list)
 
 
 def timed(name, fn):
@@ -53,8 +56,11 @@ def timed(name, fn):
         try:
             return fn(*args, **kw)
         finally:
-            T[name] += time.perf_counter() - t
+            dt = time.perf_counter() - t
+            T[name] += dt
             CNT[name] += 1
+            if len(SAMPLES[name]) < 40:
+                SAMPLES[name].append(round(1e6 * dt))
     return w
 
 
@@ -77,7 +83,10 @@ torch.cuda.synchronize()
 res["phases_ms_per_iteration"] = {k: round(1e3 * v / a.iters, 4) for k, v in sorted(T.items(), key=lambda kv: -kv[1])}
 res["calls_per_iteration"] = {k: round(v / a.iters, 2) for k, v in CNT.items()}
 res["instrumented_ms_per_iteration_host"] = round(1e3 * wall / a.iters, 3)
-print(json.dumps(res, indent=1))
+res["collector_ms_per_iteration"] = {k: round(1e3 * v / (a.iters * 2 + 3), 4) for k, v in drg._PROF.items()}
+res["first_calls_us"] = {k: v for k, v in SAMPLES.items()}
+print(json.dumps({k: v for k, v in res.items() if k != "first_calls_us"}, indent=1))
+print("first calls (us):", json.dumps(res["first_calls_us"]))
 if a.out:
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)

@@ -65,6 +65,10 @@ class SgrAdamGroup(C.Structure):
                 ("step", C.c_int64)]
 
 
+class SgrAdamTensor(C.Structure):
+    _fields_ = [("param", _fp), ("grad", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp), ("n", C.c_int64), ("step", C.c_int64)]
+
+
 class SgrMapStep(C.Structure):
     _fields_ = [("num_gaussians", C.c_int64), ("scaling", _fp), ("rotation", _fp), ("opacity", _fp), ("scales_out", _fp),
                 ("rot_out", _fp), ("opac_out", _fp), ("num_views", C.c_int32), ("forward_only", C.c_int32),
@@ -119,6 +123,7 @@ SIGNATURES = {
                                    C.c_float, _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "sgr_adam_step": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int64, _fp]),
+    "sgr_adam_step_multi": (C.c_int, [C.c_int32, C.POINTER(SgrAdamTensor), C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
     "sgr_activate": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "sgr_gaussian_adam_step": (C.c_int, [C.c_int64, C.POINTER(SgrAdamGroup), C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
     "sgr_gaussian_adam_shard": (C.c_int, [C.c_int64, C.POINTER(SgrAdamGroup), C.POINTER(C.c_int64), C.POINTER(C.c_int64),

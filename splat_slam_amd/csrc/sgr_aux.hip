@@ -127,6 +127,29 @@ __global__ void __launch_bounds__(256) adam_kernel(int64_t n, float* __restrict_
   }
 }
 
+// up to kAdamMulti small tensors in ONE launch (block = tensor): the keyframe optimiser of the drop-in path holds ~20 one-element
+// exposure parameters, for which torch's multi-tensor Adam issues ~12 launches and a per-tensor launch would issue 20
+constexpr int kAdamMulti = 48;
+struct AdamMulti {
+  float* p[kAdamMulti]; const float* g[kAdamMulti]; float* m[kAdamMulti]; float* v[kAdamMulti];
+  int32_t n[kAdamMulti]; float step_size[kAdamMulti], bc2_sqrt[kAdamMulti];
+};
+__global__ void __launch_bounds__(256) adam_multi_kernel(AdamMulti t, float b1, float b2, float eps) {
+  const int k = blockIdx.x;
+  float* __restrict__ p = t.p[k]; const float* __restrict__ g = t.g[k]; float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
+  const float step_size = t.step_size[k], bc2_sqrt = t.bc2_sqrt[k];
+  for (int i = threadIdx.x; i < t.n[k]; i += blockDim.x) {
+    float gi = g[i];
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 __device__ __forceinline__ void masked_adam_row(int r, int width, float* __restrict__ p, const float* __restrict__ g,
                                                 float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ step,
                                                 float lr, float b1, float b2, float eps) {
@@ -827,6 +850,24 @@ int sgr_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq,
                      beta1, beta2, eps, step_size, bc2_sqrt);
   return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "adam launch failed");
+}
+
+int sgr_adam_step_multi(int32_t count, const SgrAdamTensor* tensors, float lr, float beta1, float beta2, float eps, void* stream) {
+  if (count < 0 || (count > 0 && !tensors)) return set_error(SGR_ERR_INVALID, "adam_multi: bad argument");
+  for (int base = 0; base < count; base += kAdamMulti) {
+    const int nb = count - base < kAdamMulti ? count - base : kAdamMulti;
+    AdamMulti t = {};
+    for (int k = 0; k < nb; ++k) {
+      const SgrAdamTensor& a = tensors[base + k];
+      if (a.n < 0 || a.n > (1 << 20) || a.step < 1 || (a.n > 0 && (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq)))
+        return set_error(SGR_ERR_INVALID, "adam_multi: bad tensor %d", base + k);
+      const double bc1 = 1.0 - std::pow((double)beta1, (double)a.step), bc2 = 1.0 - std::pow((double)beta2, (double)a.step);
+      t.p[k] = a.param; t.g[k] = a.grad; t.m[k] = a.exp_avg; t.v[k] = a.exp_avg_sq; t.n[k] = (int32_t)a.n;
+      t.step_size[k] = (float)((double)lr / bc1); t.bc2_sqrt[k] = (float)std::sqrt(bc2);
+    }
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, t, beta1, beta2, eps);
+  }
+  return hipGetLastError() == hipSuccess ? SGR_OK : set_error(SGR_ERR_HIP, "adam_multi launch failed");
 }
 
 int sgr_activate(int64_t n, const float* scaling, const float* rotation, const float* opacity, float* scales_out,

@@ -95,7 +95,11 @@ class MappingLoop:
             exposures += [viewpoint.exposure_a, viewpoint.exposure_b]
         if exposures:
             groups.append({"params": exposures, "lr": 0.01, "name": "exposure"})
-        self.keyframe_optimizers = torch.optim.Adam(groups) if groups else None
+        if groups and self.device.type == "cuda":      # same groups and state; all exposure tensors step in ONE launch
+            from splat_slam_amd.optim import FusedAdam
+            self.keyframe_optimizers = FusedAdam(groups)
+        else:
+            self.keyframe_optimizers = torch.optim.Adam(groups) if groups else None
 
     def _visible_stats(self, viewspace_points, vis, radii):
         """max_radii2D[vis] = max(max_radii2D[vis], radii[vis]) and add_densification_stats (mapper.py:332-335,523-529,

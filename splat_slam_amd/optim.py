@@ -31,9 +31,11 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = nat.lib()
+        stream = None
         for g in self.param_groups:
             b1, b2 = g["betas"]
             lr, eps = float(g["lr"]), float(g["eps"])
+            small = []                                 # tensors of <= kSmall elements of this group go out in ONE launch
             for p in g["params"]:
                 grad = p.grad
                 if grad is None:
@@ -49,9 +51,17 @@ class FusedAdam(torch.optim.Adam):
                     continue
                 if not grad.is_contiguous():
                     grad = grad.contiguous()
-                if p.device.index is not None and p.device.index != torch.cuda.current_device():
-                    torch.cuda.set_device(p.device)
+                if stream is None:
+                    if p.device.index is not None and p.device.index != torch.cuda.current_device():
+                        torch.cuda.set_device(p.device)
+                    stream = torch.cuda.current_stream().cuda_stream
+                if n <= 4096 and len(g["params"]) > 1:
+                    small.append((nat.SgrAdamTensor(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n,
+                                                    int(st["step"].item())), grad))       # (grad kept alive until the launch)
+                    continue
                 nat.check(lib.sgr_adam_step(n, p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                            lr, float(b1), float(b2), eps, int(st["step"].item()),
-                                            torch.cuda.current_stream().cuda_stream), "sgr_adam_step")
+                                            lr, float(b1), float(b2), eps, int(st["step"].item()), stream), "sgr_adam_step")
+            if small:
+                arr = (nat.SgrAdamTensor * len(small))(*[t for t, _ in small])
+                nat.check(lib.sgr_adam_step_multi(len(small), arr, lr, float(b1), float(b2), eps, stream), "sgr_adam_step_multi")
         return loss

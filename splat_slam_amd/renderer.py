@@ -24,10 +24,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         projmatrix_raw=viewpoint_camera.projection_matrix, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-    means3D = pc.get_xyz
+    means3D = xyz
     means2D = screenspace_points
     opacity = pc.get_opacity
-    scales = pc.get_scaling.repeat(1, 3) if pc.get_scaling.shape[-1] == 1 else pc.get_scaling
+    scales = pc.get_scaling
+    if scales.shape[-1] == 1:
+        scales = scales.repeat(1, 3)
     rotations = pc.get_rotation
     shs, colors_precomp = None, None
     if override_color is not None:

@@ -123,13 +123,36 @@ def _strict_rel(a, b, knife_rows, width):
     return strict, loose, int((e[knife_rows] > REL).sum())
 
 
+def _per_gaussian_report(soft, what, a, b, knife_rows, width, visible=None):
+    """Per-Gaussian relative error (normalised by the tensor's largest reference value): quantiles over the visible Gaussians,
+    and the two facts a tolerance on a norm cannot show: no Gaussian OFF the oracle's knife-edge list is beyond REL, and the
+    Gaussians beyond REL are a subset of that list (a real defect could not hide behind it)."""
+    a, b = a.double().reshape(-1, width), b.double().reshape(-1, width)
+    m = b.abs().max().clamp_min(1e-30)
+    e = (a - b).abs().max(dim=1).values / m
+    rows = visible if visible is not None else (b.abs().max(dim=1).values > 0) | (a.abs().max(dim=1).values > 0)
+    ev = e[rows]
+    if ev.numel() == 0:
+        return
+    q = torch.quantile(ev, torch.tensor([0.5, 0.9, 0.99, 0.999], dtype=torch.float64)).tolist()
+    beyond = e > REL
+    off_list = beyond & ~knife_rows
+    soft.check(int(off_list.sum()) == 0, f"{what}: per-Gaussian rel err quantiles 50/90/99/99.9 % = {q[0]:.1e}/{q[1]:.1e}/{q[2]:.1e}/{q[3]:.1e}, max "
+                                         f"{ev.max().item():.1e}; {int(beyond.sum())} Gaussians beyond {REL} of which {int(off_list.sum())} are NOT on "
+                                         f"the oracle's knife-edge list ({int(knife_rows.sum())} listed)")
+    soft.check(q[0] <= 1e-5, f"{what}: median per-Gaussian rel err {q[0]:.1e}")
+
+
 WIDTH = {"means3D": 3, "means2D": 3, "opacities": 1, "shs": 3, "scales": 3, "rotations": 4}
 
 
 @pytest.mark.parametrize("case", [("configs0", 20000, "replica", 0.0, True), ("configs1", 300000, "metric", 0.0, True),
-                                  ("configs1_opaque", 150000, "metric", 1.6, False)], ids=lambda c: c[0])
+                                  ("configs1_raw", 300000, "metric", 0.0, "raw"), ("configs1_opaque", 150000, "metric", 1.6, False)],
+                         ids=lambda c: c[0])
 def test_autograd_api_matches_oracle_at_config_size(case):
     name, n, camera, scale_add, deknife = case
+    raw = deknife == "raw"          # the scene as generated: knife-edge Gaussians stay, and must be the ONLY ones beyond the tolerance
+    deknife = deknife is True
     syn, intr, params, cams = _room(n, camera, 1, scale_add=scale_add)
     gm = syn.model_from_parameters(params, device=DEV)
     inp = _activated_inputs(gm)
@@ -164,11 +187,23 @@ def test_autograd_api_matches_oracle_at_config_size(case):
             _check_image(soft, hip_out[i], ref_out[i], f"{name}/{what}")
         nt, rnt = hip_out[4].long(), ref_out[4].long()
         soft.check((nt - rnt).abs().sum().item() <= max(2, nt.numel() // 500), f"{name}: n_touched differs by {(nt - rnt).abs().sum().item()} counts")
+    vis_rows = ref_out[1] > 0
     for k in GRAD_KEYS:
-        if not deknife:
+        if raw and k in WIDTH:
+            # every Gaussian the oracle does NOT list is held to REL; the listed ones are bounded and few of them may exceed REL
+            strict, loose, n_loose = _strict_rel(hip_g[k], ref_g[k], on_edge, WIDTH[k])
+            soft.check(strict <= REL, f"{name}: grad {k} rel err {strict:.3e} over the {int((~on_edge & vis_rows).sum())} visible Gaussians off the list")
+            soft.check(loose <= 2e-2 and n_loose <= int(on_edge.sum()), f"{name}: grad {k}: {n_loose} of {int(on_edge.sum())} listed Gaussians beyond {REL}, worst {loose:.3e}")
+            _per_gaussian_report(soft, f"{name}: grad {k}", hip_g[k], ref_g[k], on_edge, WIDTH[k], vis_rows)
+        elif raw:
+            r = rel_linf(hip_g[k].reshape(-1), ref_g[k].reshape(-1))
+            soft.check(r <= 3 * REL, f"{name}: grad {k} rel err {r:.3e}")
+        elif not deknife:
             a, b = hip_g[k].double().reshape(-1), ref_g[k].double().reshape(-1)
             l2, linf = ((a - b).norm() / b.norm()).item(), rel_linf(a, b)
             soft.check(l2 <= 2 * REL and linf <= 5e-3, f"{name}: grad {k} rel L2 err {l2:.3e}, rel max err {linf:.3e}")
+            if k in WIDTH:
+                _per_gaussian_report(soft, f"{name}: grad {k}", hip_g[k], ref_g[k], on_edge, WIDTH[k], vis_rows)
         elif k in WIDTH:
             strict, loose, n_loose = _strict_rel(hip_g[k], ref_g[k], on_edge, WIDTH[k])
             soft.check(strict <= REL, f"{name}: grad {k} rel err {strict:.3e} (Gaussians off the knife edges)")
@@ -317,6 +352,7 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
         if by_l2:      # long lists: (almost) every Gaussian has some pixel on a knife edge -- see the opaque autograd case
             l2, linf = ((a - b).norm() / b.norm()).item(), rel_linf(a, b)
             soft.check(l2 <= 2 * REL and linf <= 5e-3, f"accumulated grad {mine}: rel L2 err {l2:.3e}, rel max err {linf:.3e}")
+            _per_gaussian_report(soft, f"accumulated grad {mine}", a, b, on_edge, w, seen)
             continue
         strict, loose, n_loose = _strict_rel(a, b, on_edge, w)
         e = (a - b).abs().max(dim=1).values / b.abs().max()
