@@ -42,8 +42,8 @@ def build_native(force=False, verbose=True):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and os.path.getmtime(obj) > hdr_t):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+            os.environ.get("SGR_CXXFLAGS", "").split() + ["-c", src, "-o", obj]       # (SGR_CXXFLAGS: build-time experiments, e.g. -DSGR_TILE_WAVES=4)
         if verbose:
             print("[build]", " ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd)))

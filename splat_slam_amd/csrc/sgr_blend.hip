@@ -24,6 +24,13 @@
 
 #include "sgr_common.h"
 
+#ifndef SGR_TILE_WAVES
+#define SGR_TILE_WAVES 5      // fused tile kernel / forward: 95 VGPRs; 4 waves per SIMD measured 10 % slower (no spills either way)
+#endif
+#ifndef SGR_BWD_WAVES
+#define SGR_BWD_WAVES 5       // stand-alone backward
+#endif
+
 namespace sgr {
 
 // Lists the wave sorts on chip: three builds of the forward kernel, picked per launch from the LONGEST list the caller has
@@ -324,6 +331,9 @@ __device__ __forceinline__ void bwd_chunk2(
     int lane, int start, int end, bool carry, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
     const LOff& L, float halfW, float halfH, float4* __restrict__ partials) {
   constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
+  // (opaque to the optimiser: the five instantiations sit in one loop, and hoisting each one's lane arithmetic out of it
+  //  cost more live registers than the kernel has at 5 waves per SIMD -- they were spilled to scratch: +37 MB of writes per launch)
+  asm volatile("" : "+v"(lane));
   const int sub = lane / GW;                     // which of them this lane works on
   const int sl = lane % GW;
   const int idx = start + (GW - 1 - sl);         // list position of this lane's splat
@@ -419,7 +429,7 @@ __device__ __forceinline__ void bwd_chunk2(
       float dmy = (-(Cc * t_gy) - B * t_gx) * halfH;
       partials[(size_t)slot * 3 + 0] = make_float4(dmx, dmy, -0.5f * t_gxx, -t_gxy);
       partials[(size_t)slot * 3 + 1] = make_float4(-0.5f * t_gyy, t_o, t_r, t_g);
-      partials[(size_t)slot * 3 + 2] = make_float4(t_b, t_d, 0.f, 0.f);
+      *(float2*)&partials[(size_t)slot * 3 + 2] = make_float2(t_b, t_d);      // (the slot's last 8 bytes are padding: never read)
     }
   }
 }
@@ -442,8 +452,10 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  const float halfW = 0.5f * (float)L.W, halfH = 0.5f * (float)L.H;
-  const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+  // wave-uniform floats are pinned to SGPRs (the compiler keeps converted integers in VGPRs: at 96 registers every one counts)
+  auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  const float halfW = uniform(0.5f * (float)L.W), halfH = uniform(0.5f * (float)L.H);
+  const float tx0 = uniform((float)(tx * kTile)), ty0 = uniform((float)(ty * kTile));
   // The list is cut into chunks of 64 / 32 / 16 / 8 / 4 splats from the far end: a lane = a splat, and a chunk of width GW works
   // on 64 / GW pixel pairs at once, so a chunk costs 32 * GW / 64 iterations of the loop above whatever part of its lanes is
   // filled.  One 64-wide chunk per started 64 splats left the lists of a converged map (33-256) at 55-75 % lane use; the
@@ -477,7 +489,7 @@ __device__ __forceinline__ float sign_code(uint32_t c, float k) { return (c & 1u
 // registers and the tile's sorted splats are still staged in LDS, so the wave goes straight on with tile_backward():
 // no final_T / n_contrib / code-byte / index-list round trip through HBM, no second launch, one tile prologue.
 template <int SORT_MAX, bool FUSED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TILE_WAVES))) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
                                                         LossCoef lc) {
   const int vw = blockIdx.y;
   char* saved = tab.saved[vw];
@@ -774,7 +786,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) b
 }
 
 template <bool PACKED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES))) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
   const int vw = blockIdx.y;
   const char* saved = tab.saved[vw];
   const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
