@@ -31,14 +31,6 @@ def run(args, d):
     return " ".join(cmd[:len(args) + 1]) + " -- python bench.py " + " ".join(BENCH[2:])
 
 
-# ---- 0. the plain bench line (defaults), for tests/test_bench_contract.py and BASELINE.md
-r0 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], cwd=ROOT, env=env, capture_output=True, text=True)
-line = [l for l in r0.stdout.splitlines() if l.startswith("{")]
-if line:
-    open(os.path.join(out, tag + "_bench_line.json"), "w").write(line[-1] + "\n")
-else:
-    print("bench.py failed", r0.stderr[-1500:])
-
 # ---- 1. kernel trace + stats
 cmd = run(["--kernel-trace", "--stats"], "/tmp/prof_kt")
 for f in glob.glob("/tmp/prof_kt/*kernel_stats.csv") + glob.glob("/tmp/prof_kt/*domain_stats.csv"):
@@ -120,4 +112,15 @@ json.dump({"command": c3, "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_
           open(os.path.join(out, tag + "_pmc_sq.json"), "w"), indent=1)
 for name in ("kernel_batched_avg", "pmc_hbm_bytes"):       # what bench.py quotes `roofline.traffic` from
     shutil.copy(os.path.join(out, tag + "_" + name + ".json"), os.path.join(out, "latest_" + name + ".json"))
+    shutil.copy(os.path.join(out, tag + "_" + name + ".json"), os.path.join(ROOT, "profiles", "latest_" + name + ".json"))
+
+# ---- 3. the plain bench line (defaults), for tests/test_bench_contract.py and BASELINE.md -- LAST, so that its `roofline.traffic`
+# is quoted from the PMC passes above
+r0 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], cwd=ROOT, env=env, capture_output=True, text=True)
+line = [l for l in r0.stdout.splitlines() if l.startswith("{")]
+if line:
+    open(os.path.join(out, tag + "_bench_line.json"), "w").write(line[-1] + "\n")
+else:
+    print("bench.py failed", r0.stderr[-1500:])
+
 print("done", os.listdir(out))
