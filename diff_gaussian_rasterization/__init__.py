@@ -292,6 +292,10 @@ def _batched_backward(batch):
         raise RuntimeError("diff_gaussian_rasterization: backward through the renders of this parameter set a second time "
                            "(their workspaces were released by the first backward; render again, or set SPLAT_RASTER_BATCH=0)")
     batch.closed = True
+    if any(t._version != v for t, v in zip(batch.inputs, batch.versions)):
+        # (what autograd's saved-tensor check says for upstream's save_for_backward; the batch holds aliases, not saved tensors)
+        raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                           "the Gaussian parameters handed to the rasterizer changed between render and backward")
     lib = nat.lib()
     dev = batch.dev
     st = _state(dev)

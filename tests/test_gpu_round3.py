@@ -105,6 +105,47 @@ def test_batched_backward_strict_pose_gradient_mode():
         assert torch.equal(got[name], ref[name]), name
 
 
+def test_batched_backward_of_views_with_different_image_sizes_and_inplace_check():
+    """One batch whose views do not share a layout (two resolutions): sgr_backward_views runs them one after the other into the
+    same gradient buffers -- same sums as independent per-view backward passes.  And: parameters modified in place between
+    render and backward raise, like autograd's saved-tensor check does for upstream."""
+    import diff_gaussian_rasterization as drg
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.losses import get_loss_mapping_fused
+    from splat_slam_amd.mapper import PipelineParams
+    from splat_slam_amd.renderer import render
+    params = syn.room_parameters(4000, seed=5, device=DEV)
+    params["scaling"] = params["scaling"] + 1.2
+    cams = syn.make_views(params, 2, syn.INTRINSICS["tiny"], DEV, seed=5) + syn.make_views(params, 2, syn.INTRINSICS["replica"], DEV, seed=6)
+    res = []
+    for batch in (True, False):
+        gm = syn.model_from_parameters(params, device=DEV)
+        bg = torch.zeros(3, device=DEV)
+        old, drg.BATCH = drg.BATCH, batch
+        try:
+            loss, pk = 0.0, []
+            for c in cams:
+                pkg = render(c, gm, PipelineParams(), bg)
+                loss = loss + get_loss_mapping_fused(syn.DEFAULT_CONFIG["mapping"], pkg["render"], pkg["depth"], c, pkg["opacity"])
+                pk.append(pkg)
+            loss.backward()
+        finally:
+            drg.BATCH = old
+        res.append(({n: getattr(gm, n).grad.clone() for n in PARAMS}, [p["viewspace_points"].grad.clone() for p in pk]))
+    for n in PARAMS:
+        a, b = res[0][0][n], res[1][0][n]
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() and b.abs().max() > 0, n
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    gm = syn.model_from_parameters(params, device=DEV)
+    pkg = render(cams[0], gm, PipelineParams(), torch.zeros(3, device=DEV))
+    loss = get_loss_mapping_fused(syn.DEFAULT_CONFIG["mapping"], pkg["render"], pkg["depth"], cams[0], pkg["opacity"])
+    with torch.no_grad():
+        gm._xyz.add_(1e-3)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+
+
 def test_batched_backward_accumulates_into_existing_grads():
     """Two backward passes without zero_grad: parameter and pose `.grad`s accumulate (autograd adds the zero tensors the view
     nodes return; the collector then adds the values): exactly twice the single pass."""
