@@ -154,26 +154,25 @@ class MappingLoop:
         random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in current_window_set]
         pose_opt = bool(self.config["mapping"]["BA"]) and not self.config["mapping"]["Training"].get("gt_camera", False)
         gaussian_split = False
+        mapping_cfg = self.config["mapping"]
+
+        def view_pass(cam):
+            """render + mapping loss of one keyframe (mapper.py:426-456 / :458-485): the loss term and what the statistics need."""
+            pkg = render(cam, self.gaussians, self.pipeline_params, self.background)
+            term = self.loss_fn(mapping_cfg, pkg["render"], pkg["depth"], cam, pkg["opacity"])
+            return term, (pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]), pkg["n_touched"]
+
         for it in range(iters):
             gaussian_split = False                      # (per iteration, mapper.py:491: the LAST iteration decides the result)
             self.iteration_count += 1
+            # the window keyframes, then two keyframes drawn from the rest (torch RNG, mapper.py:470)
+            extra = [random_viewpoint_stack[k] for k in torch.randperm(len(random_viewpoint_stack))[:2]]
+            passes = [view_pass(cam) for cam in viewpoint_stack + extra]
             loss_mapping = 0
-            vsp_acm, vis_acm, radii_acm, n_touched_acm = [], [], [], []
-            for cam_idx in range(len(current_window)):
-                viewpoint = viewpoint_stack[cam_idx]
-                pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
-                loss_mapping += self.loss_fn(self.config["mapping"], pkg["render"], pkg["depth"], viewpoint, pkg["opacity"])
-                vsp_acm.append(pkg["viewspace_points"])
-                vis_acm.append(pkg["visibility_filter"])
-                radii_acm.append(pkg["radii"])
-                n_touched_acm.append(pkg["n_touched"])
-            for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2]:
-                viewpoint = random_viewpoint_stack[cam_idx]
-                pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
-                loss_mapping += self.loss_fn(self.config["mapping"], pkg["render"], pkg["depth"], viewpoint, pkg["opacity"])
-                vsp_acm.append(pkg["viewspace_points"])
-                vis_acm.append(pkg["visibility_filter"])
-                radii_acm.append(pkg["radii"])
+            for term, _, _ in passes:
+                loss_mapping += term
+            per_view = [p[1] for p in passes]
+            n_touched_acm = [p[2] for p in passes[:len(current_window)]]
             scaling = self.gaussians.get_scaling
             isotropic_loss = torch.abs(scaling - scaling.mean(dim=1).view(-1, 1))
             # multi-GPU (grad_sync set): the view losses are summed over the ranks, the isotropy term must enter that sum ONCE
@@ -194,15 +193,15 @@ class MappingLoop:
                     # occ_aware_visibility and n_obs and returns before optimizer.step()/zero_grad()
                     self._count_observations(current_window)
                     return False
-                for idx in range(len(vsp_acm)):
-                    self._visible_stats(vsp_acm[idx], vis_acm[idx], radii_acm[idx])
+                for vsp, vis, radii in per_view:
+                    self._visible_stats(vsp, vis, radii)
                 update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
                 if update_gaussian:
                     self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
                                                      self.gaussian_extent, self.size_threshold)
                     gaussian_split = True
                 if (self.iteration_count % self.gaussian_reset) == 0 and (not update_gaussian):
-                    self.gaussians.reset_opacity_nonvisible(vis_acm)
+                    self.gaussians.reset_opacity_nonvisible([v[1] for v in per_view])
                     gaussian_split = True
                 self.gaussians.optimizer.step()
                 self.gaussians.optimizer.zero_grad(set_to_none=True)

@@ -31,21 +31,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     if scales.shape[-1] == 1:
         scales = scales.repeat(1, 3)
     rotations = pc.get_rotation
-    shs, colors_precomp = None, None
-    if override_color is not None:
-        colors_precomp = override_color
-    else:
-        shs = pc.get_features
-    if mask is not None:
-        rendered_image, radii, depth, opacity, n_touched = rasterizer(
-            means3D=means3D[mask], means2D=means2D[mask], shs=shs[mask] if shs is not None else None,
-            colors_precomp=colors_precomp[mask] if colors_precomp is not None else None, opacities=opacity[mask],
-            scales=scales[mask], rotations=rotations[mask], cov3D_precomp=None,
-            theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta)
-    else:
-        rendered_image, radii, depth, opacity, n_touched = rasterizer(
-            means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
-            rotations=rotations, cov3D_precomp=None, theta=viewpoint_camera.cam_rot_delta,
-            rho=viewpoint_camera.cam_trans_delta)
+    shs, colors_precomp = (None, override_color) if override_color is not None else (pc.get_features, None)
+    # `mask` (a boolean over the Gaussians) renders a subset; the rasterizer sees ordinary tensors either way
+    pick = (lambda t: t) if mask is None else (lambda t: None if t is None else t[mask])
+    rendered_image, radii, depth, opacity, n_touched = rasterizer(
+        means3D=pick(means3D), means2D=pick(means2D), shs=pick(shs), colors_precomp=pick(colors_precomp), opacities=pick(opacity),
+        scales=pick(scales), rotations=pick(rotations), cov3D_precomp=None, theta=viewpoint_camera.cam_rot_delta,
+        rho=viewpoint_camera.cam_trans_delta)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "depth": depth, "opacity": opacity, "n_touched": n_touched}
