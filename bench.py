@@ -237,9 +237,9 @@ class Bench:
         stats, per_view = (C.c_int64 * 4)(), []
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         for cam in loop.last_used:
-            vb = loop._views[cam.uid]
+            vb = loop.workspace_of(cam)            # (the random picks of a span render in shared workspace slots)
             ws = nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), loop._cap)
-            nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], vb.radii.data_ptr(), stats, stream), "sgr_query_stats")
+            nat.check(lib.sgr_query_stats(C.byref(ws), N, intr["H"], intr["W"], loop._views[cam.uid].radii.data_ptr(), stats, stream), "sgr_query_stats")
             per_view.append([int(x) for x in stats])
         hist = (C.c_int64 * 8)()
         nat.check(lib.sgr_query_list_histogram(C.byref(ws), N, intr["H"], intr["W"], hist, stream), "sgr_query_list_histogram")

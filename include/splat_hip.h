@@ -405,6 +405,10 @@ typedef struct SgrMapRun {
   SgrAdamGroup* adam_groups;    /* host, [5] or NULL */
   const int32_t* pool_exp_row;  /* host, [pool_size] or NULL */
   int32_t n_touched_last_only;  /* != 0: n_touched is only produced by the last iteration (nobody can observe the others) */
+  const SgrWorkspace* pick_ws;  /* host, [picks_per_iter] or NULL.  Non-NULL: pick j of every iteration renders in pick_ws[j]
+                                   instead of its pool entry's own workspace -- a map holds hundreds of keyframes, an iteration
+                                   touches picks_per_iter of them (src/mapper.py:458-485), and a workspace is ~300 MB.  The
+                                   pool entries' `ws` are then ignored. */
 } SgrMapRun;
 int sgr_map_run(const SgrMapRun* run, void* stream);
 

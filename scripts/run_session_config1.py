@@ -126,7 +126,7 @@ def main():
                      for i, n in enumerate(names) if int(cnt[i])}
         from splat_slam_amd import _native as nat
         cam = loop.last_used[0]
-        vb = loop._views[cam.uid]
+        vb = loop.workspace_of(cam)
         ws = nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), loop._cap)
         hist = (C.c_int64 * 8)()
         nat.check(loop.lib.sgr_query_list_histogram(C.byref(ws), int(loop.gaussians.get_xyz.shape[0]), intr["H"], intr["W"], hist,

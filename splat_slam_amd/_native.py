@@ -84,7 +84,7 @@ class SgrMapRun(C.Structure):
     _fields_ = [("step", SgrMapStep), ("num_iters", C.c_int32), ("num_window", C.c_int32), ("window", C.POINTER(SgrMapView)),
                 ("pool_size", C.c_int32), ("picks_per_iter", C.c_int32), ("pool", C.POINTER(SgrMapView)),
                 ("picks", C.POINTER(C.c_int32)), ("lr0", C.POINTER(C.c_float)), ("adam_groups", C.POINTER(SgrAdamGroup)),
-                ("pool_exp_row", C.POINTER(C.c_int32)), ("n_touched_last_only", C.c_int32)]
+                ("pool_exp_row", C.POINTER(C.c_int32)), ("n_touched_last_only", C.c_int32), ("pick_ws", C.POINTER(SgrWorkspace))]
 
 
 class SgrDeformFrame(C.Structure):

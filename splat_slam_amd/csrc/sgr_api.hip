@@ -163,8 +163,9 @@ static void tab_set_view(ViewTab& t, int v, const SgrSettings* s, const SgrOutpu
 
 // forward of a batch that shares N, H, W, capacity and the view-independent settings
 static int forward_batch(const ViewTab& tab, int nviews, const Layout& L, const Common& cm, const SgrInputs& in, hipStream_t st,
-                         bool counters_clean = false) {
+                         bool counters_clean = false, int max_list_hint = 0) {
   LOff d = L.dev();
+  d.mean_hint = max_list_hint;
   // header + per-tile pair counters; tile_scan re-zeroes the counters after reading them, so only blocks that never
   // went through a forward (or the caller does not vouch for) need this launch
   if (!counters_clean) launch_zero_heads(tab, nviews, d, L.zero_bytes, st);
@@ -198,7 +199,7 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
   ViewTab tab = {};
   tab_set_view(tab, 0, s, out, ws);
   Common cm = make_common(s);
-  if (int rc = forward_batch(tab, 1, L, cm, *in, st, ws->counters_clean != 0)) return rc;
+  if (int rc = forward_batch(tab, 1, L, cm, *in, st, ws->counters_clean != 0, ws->max_list_hint)) return rc;
   if (num_rendered_host) {
     uint32_t h2[2] = {0u, 0u};        // num_rendered, overflow
     HIP_TRY(hipMemcpyAsync(h2, (char*)ws->saved + L.o_hdr, 8, hipMemcpyDeviceToHost, st));
@@ -420,7 +421,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
         lt.parts[v] = m.loss_scratch;
       }
     }
-    if (int rc = forward_batch(tab, nv, L, cm, *in, st, all_clean)) return rc;
+    if (int rc = forward_batch(tab, nv, L, cm, *in, st, all_clean, d.mean_hint)) return rc;
     if (forward_only) {
       launch_blend_fwd(tab, nv, d, f.settings.bg, nullptr, nullptr, st);
       continue;
@@ -559,6 +560,7 @@ int sgr_map_run(const SgrMapRun* r, void* stream) {
   SgrMapView views[64];
   for (int v = 0; v < r->num_window; ++v) views[v] = r->window[v];
   std::vector<char> pool_used((size_t)(r->pool_size > 0 ? r->pool_size : 0), 0);   // a block is clean after its first forward
+  std::vector<char> slot_used((size_t)(r->picks_per_iter > 0 ? r->picks_per_iter : 0), 0);
   SgrMapStep st = r->step;
   st.views = views;
   st.num_views = nv;
@@ -570,7 +572,13 @@ int sgr_map_run(const SgrMapRun* r, void* stream) {
       const int32_t k = r->picks[(size_t)it * r->picks_per_iter + j];
       if (k < 0 || k >= r->pool_size) return set_error(SGR_ERR_INVALID, "map_run: pick %d outside the pool", k);
       views[r->num_window + j] = r->pool[k];
-      if (pool_used[k]) views[r->num_window + j].ws.counters_clean = 1;
+      if (r->pick_ws) {                   // shared workspace slots: pick j renders in slot j whichever camera it is
+        views[r->num_window + j].ws = r->pick_ws[j];
+        if (slot_used[j]) views[r->num_window + j].ws.counters_clean = 1;
+        slot_used[j] = 1;
+      } else if (pool_used[k]) {
+        views[r->num_window + j].ws.counters_clean = 1;
+      }
       pool_used[k] = 1;
     }
     if (it == 1)

@@ -37,11 +37,40 @@ __device__ uint32_t block1024_scan(LOAD in, uint32_t* __restrict__ out, int n, u
   return carry;
 }
 
-// K2: three independent scans per view, one 1024-thread block each (grid = (3, views)): (0) tile starts, (1) segment
-// bases of the partial-slot offsets, (2) segment bases of the compact visible list.  ranges[t] = (start, end) of the tile's
-// run; for tiles with more than kBucket pairs .x carries kOverfull and .y starts as scatter's fill cursor (= end after K3).
-__global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
+// the exactly sized runs of over-full tiles: the overflow list (tile, rank, key) is filed at start(tile) + rank, and the first
+// kBucket keys of every over-full tile are copied over from its bucket.  `first` / `stride`: this caller's share of the work.
+__device__ __forceinline__ void file_overfull_runs(char* saved, char* scratch, const LOff& L, size_t novf, size_t first, size_t stride) {
+  const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
+  uint64_t* __restrict__ entries = (uint64_t*)(scratch + L.o_entries);
+  const OvfEntry* __restrict__ ovf = (const OvfEntry*)(scratch + L.o_ovf);
+  for (size_t e = first; e < novf; e += stride) {
+    const OvfEntry o = ovf[e];
+    const uint64_t pos = (uint64_t)(ranges[(size_t)o.tile * kRngStride].x & ~kOverfull) + o.rank;
+    if ((int64_t)pos < L.cap) entries[pos] = o.key;
+  }
+  const uint64_t* __restrict__ bucket = (const uint64_t*)(scratch + L.o_bucket);
+  const size_t nslots = (size_t)L.ntiles * kBucket;
+  for (size_t e = first; e < nslots; e += stride) {
+    const uint32_t x = ranges[(e / kBucket) * kRngStride].x;
+    if (!(x & kOverfull)) continue;
+    const uint64_t pos = (uint64_t)(x & ~kOverfull) + (e % kBucket);
+    if ((int64_t)pos < L.cap) entries[pos] = bucket[e];
+  }
+}
+
+// K2: independent jobs per view, one 1024-thread block each (grid = (3 + ceil(nseg / 64), views)):
+//   (0) tile starts: ranges[t] = (start, end) of the tile's run; for tiles with more than kBucket pairs .x carries kOverfull.
+//       When no scatter launch follows (`k3_follows` == 0: the caller's measured longest list fits the buckets) this block also
+//       files the overflow list, should there be one after all -- correct for any map, just not parallel;
+//   (1) segment bases of the partial-slot offsets;
+//   (2) the number of visible Gaussians;  (3 + j) the compact visible list: the segments' visible lists (K1) concatenated
+//       (absolute position = segment base + position in the segment list), 64 segments per block.
+// The later of blocks 0 and 1 folds the two pair counts into the header.  A fresh map (lists within the 64-entry buckets)
+// therefore needs no third binning launch at all.
+__global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, int k3_follows) {
   __shared__ uint32_t red[16];
+  __shared__ uint32_t red_max[16];
+  __shared__ uint32_t s_flag;
   char* saved = tab.saved[blockIdx.y];
   SavedHeader* hdr = (SavedHeader*)(saved + L.o_hdr);
   if (blockIdx.x == 0) {
@@ -60,14 +89,13 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
       saturated |= c >= kTileCountLimit ? 1u : 0u;
       longest = c > longest ? c : longest;
       // <= kBucket pairs: K1 already binned them in the tile's bucket, the run [s0, s0+c) only addresses point_list.
-      // more: scatter_kernel fills the run; .y is its fill cursor and ends at s0 + c as well.
+      // more: the run is completed below / by scatter_kernel; .y ends at s0 + c as well.
       ranges[(size_t)t * kRngStride] = make_uint2(c <= (uint32_t)kBucket ? s0 : (s0 | kOverfull), s0 + c);
       over += c > (uint32_t)kBucket ? 1u : 0u;
     }
     over = wave_scan_add_u32(over);
     saturated = __syncthreads_or((int)saturated) ? 1u : 0u;
     longest = (uint32_t)wave_max_i32((int)longest);
-    __shared__ uint32_t red_max[16];
     if ((threadIdx.x & 63) == 0) red_max[threadIdx.x >> 6] = longest;
     // consumed: leave the counters clean for the next forward
     for (int w = threadIdx.x; w < ((L.gy + 1) / 2) * L.gxp; w += 1024) tile_count[(size_t)w * (kCntSlotWords / 2)] = 0ull;
@@ -87,79 +115,83 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L) {
       hdr->overflow = (saturated || hdr->count_saturated) ? 2u : ((int64_t)R > L.cap ? 1u : 0u);
       hdr->count_saturated = 0u;
       hdr->sorted_count = (uint32_t)((int64_t)R > L.cap ? L.cap : (int64_t)R);
+      s_flag = tot;
+    }
+    __syncthreads();                              // (also: every thread's `ranges` are visible to the block)
+    if (!k3_follows && s_flag != 0u) {
+      const size_t novf = hdr->ovf_count < (uint64_t)L.cap ? hdr->ovf_count : (size_t)L.cap;
+      file_overfull_runs(saved, tab.scratch[blockIdx.y], L, novf, threadIdx.x, 1024);
     }
   } else if (blockIdx.x == 1) {
     const uint32_t* bt = (const uint32_t*)(saved + L.o_block_touched);
     const uint32_t slots = block1024_scan([&](int i) { return bt[i]; }, (uint32_t*)(saved + L.o_block_base_t), L.nseg, red);
     if (threadIdx.x == 0) hdr->slot_total = slots;
-  } else {
+  } else if (blockIdx.x == 2) {
     const uint32_t* bv = (const uint32_t*)(saved + L.o_block_vis);
     uint32_t V = block1024_scan([&](int i) { return bv[i]; }, (uint32_t*)(saved + L.o_block_base_v), L.nseg, red);
     if (threadIdx.x == 0) hdr->num_visible = V;
+    return;
+  } else {
+    // (3 + j) the compact visible list of segments [64 j, 64 j + 64): the block adds up the visible counts of the segments in
+    // front of its own (<= a few thousand values: cheaper than waiting for block 2's scan), scans its own 64 counts, and 16
+    // lanes per segment copy that segment's list in one trip (a segment holds ~15 visible Gaussians of a SLAM view, at most 256)
+    __shared__ uint32_t s_base[64];
+    const uint32_t* __restrict__ bv = (const uint32_t*)(saved + L.o_block_vis);
+    const int seg0 = ((int)blockIdx.x - 3) * 64;
+    uint32_t before = 0;
+    for (int i = threadIdx.x; i < seg0; i += 1024) before += bv[i];
+    before = wave_scan_add_u32(before);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = before;
+    const int ls = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const uint32_t c = seg0 + ls < L.nseg ? bv[seg0 + ls] : 0u;
+    __syncthreads();
+    if (threadIdx.x < 64) {                     // exclusive scan of the 64 counts by one wave
+      uint32_t pre = 0;
+      for (int wv = 0; wv < 16; ++wv) pre += red[wv];
+      const uint32_t mine = seg0 + (int)threadIdx.x < L.nseg ? bv[seg0 + threadIdx.x] : 0u;
+      s_base[threadIdx.x] = pre + wave_scan_add_u32(mine) - mine;
+    }
+    __syncthreads();
+    const uint32_t* __restrict__ seg_list = (const uint32_t*)(saved + L.o_seg_list);
+    uint32_t* __restrict__ vis_list = (uint32_t*)(saved + L.o_vis_list);
+    GRec* __restrict__ grec = (GRec*)(saved + L.o_grec);
+    const uint32_t b = s_base[ls];
+    for (uint32_t k = sub; k < c; k += 16) {
+      const uint32_t i = seg_list[(size_t)(seg0 + ls) * kSeg + k];
+      grec[i].vis_pos = b + k;
+      vis_list[b + k] = i;
+    }
+    return;
+  }
+  // the later of blocks 0 and 1 folds the two pair counts: what a caller sizes the workspace by is the larger of the pairs
+  // binned and the partial slots reserved (bins the exact footprint test dropped keep their slot)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&hdr->k2_tickets, 1u) == 1u) {
+      __threadfence();
+      hdr->k2_tickets = 0u;
+      const uint32_t binned = *(volatile uint32_t*)&hdr->num_rendered, slots = *(volatile uint32_t*)&hdr->slot_total;
+      hdr->num_binned = binned;
+      if (slots > binned) hdr->num_rendered = slots;
+      if ((int64_t)slots > L.cap && hdr->overflow == 0u) hdr->overflow = 1u;
+    }
   }
 }
 
-// K3: grid = (ceil(N/1024), views); the block concatenates the visible lists of its four 256-Gaussian segments (K1)
-// into the view's compact visible list (absolute position = segment base from K2 + position in the segment list).
-// Binning is normally finished by then (K1's buckets).  Tiles with more than kBucket pairs get their exactly sized run
-// completed here WITHOUT atomics: K1 appended every pair whose rank in its tile was >= kBucket to the view's overflow list
-// (tile, rank, key); with the tile starts of K2 its place is start(tile) + rank, and the first kBucket keys are copied over
-// from the bucket.  (The first version re-scattered all pairs of such tiles with a returning atomic per pair from a loop over
-// each Gaussian's rectangle: 1.3 ms per launch on a converged map, where splats cover tens to hundreds of tiles.)
-// Order inside a run / bucket is arbitrary; K4 sorts it.
+// K3 (only launched when long lists are expected): the exactly sized runs of over-full tiles, completed in parallel WITHOUT
+// atomics: K1 appended every pair whose rank in its tile was >= kBucket to the view's overflow list (tile, rank, key); with the
+// tile starts of K2 its place is start(tile) + rank, and the first kBucket keys are copied over from the bucket.  (The first
+// version re-scattered all pairs of such tiles with a returning atomic per pair from a loop over each Gaussian's rectangle:
+// 1.3 ms per launch on a converged map, where splats cover tens to hundreds of tiles.)  Order inside a run / bucket is
+// arbitrary; K4 sorts it.
 __global__ void __launch_bounds__(256) scatter_kernel(ViewTab tab, LOff L) {
   const int v = blockIdx.y;
   char* saved = tab.saved[v];
-  const uint32_t* block_vis = (const uint32_t*)(saved + L.o_block_vis);
-  const uint32_t* base_v = (const uint32_t*)(saved + L.o_block_base_v);
-  const int s0 = blockIdx.x * 4;
-  uint32_t c[4], b[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool in = s0 + j < L.nseg;
-    c[j] = in ? block_vis[s0 + j] : 0u;
-    b[j] = in ? base_v[s0 + j] : 0u;
-  }
-  const uint32_t e1 = c[0], e2 = e1 + c[1], e3 = e2 + c[2], nvis = e3 + c[3];
-#pragma unroll 1
-  for (uint32_t t = threadIdx.x; t < nvis; t += 256) {
-    const int j = (t >= e1) + (t >= e2) + (t >= e3);
-    const uint32_t k = t - (j == 0 ? 0u : (j == 1 ? e1 : (j == 2 ? e2 : e3)));
-    const uint32_t i = ((const uint32_t*)(saved + L.o_seg_list))[(s0 + j) * kSeg + k];
-    const uint32_t vp = (j == 0 ? b[0] : (j == 1 ? b[1] : (j == 2 ? b[2] : b[3]))) + k;
-    ((GRec*)(saved + L.o_grec) + i)->vis_pos = vp;
-    ((uint32_t*)(saved + L.o_vis_list))[vp] = i;
-  }
   SavedHeader* hdr = (SavedHeader*)(saved + L.o_hdr);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // K2's two scans are folded here (they ran in different blocks): what a caller sizes the workspace by is the larger of
-    // the pairs binned and the partial slots reserved (bins the exact footprint test dropped keep their slot)
-    const uint32_t binned = hdr->num_rendered, slots = hdr->slot_total;
-    hdr->num_binned = binned;
-    if (slots > binned) hdr->num_rendered = slots;
-    if ((int64_t)slots > L.cap && hdr->overflow == 0u) hdr->overflow = 1u;
-  }
   if (hdr->num_overfull == 0) return;
-  const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
-  uint64_t* __restrict__ entries = (uint64_t*)(tab.scratch[v] + L.o_entries);
-  const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // (a) the overflow list
-  const OvfEntry* __restrict__ ovf = (const OvfEntry*)(tab.scratch[v] + L.o_ovf);
   const size_t novf = hdr->ovf_count < (uint64_t)L.cap ? hdr->ovf_count : (size_t)L.cap;
-  for (size_t e = first; e < novf; e += stride) {
-    const OvfEntry o = ovf[e];
-    const uint64_t pos = (uint64_t)(ranges[(size_t)o.tile * kRngStride].x & ~kOverfull) + o.rank;
-    if ((int64_t)pos < L.cap) entries[pos] = o.key;
-  }
-  // (b) the bucket part of every over-full tile
-  const uint64_t* __restrict__ bucket = (const uint64_t*)(tab.scratch[v] + L.o_bucket);
-  const size_t nslots = (size_t)L.ntiles * kBucket;
-  for (size_t e = first; e < nslots; e += stride) {
-    const uint32_t x = ranges[(e / kBucket) * kRngStride].x;
-    if (!(x & kOverfull)) continue;
-    const uint64_t pos = (uint64_t)(x & ~kOverfull) + (e % kBucket);
-    if ((int64_t)pos < L.cap) entries[pos] = bucket[e];
-  }
+  file_overfull_runs(saved, tab.scratch[v], L, novf, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
 // header + per-tile pair counters of every view of the batch in one launch (replaces one memset per view)
@@ -176,11 +208,14 @@ void launch_zero_heads(const ViewTab& tab, int nviews, const LOff& L, size_t zer
 }
 
 void launch_binning(const ViewTab& tab, int nviews, const LOff& L, hipStream_t st) {
+  // the scatter launch is only worth its dispatch when lists beyond the buckets are expected: L.mean_hint = the caller's measured
+  // longest list (0: unknown -> launch it).  Without it K2's first block files whatever overflowed (correct, not parallel).
+  const int k3 = (L.N > 0 && (L.mean_hint == 0 || L.mean_hint > kBucket)) ? 1 : 0;
   {
     ProfScope prof(PK_SCAN, st);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(3, nviews), dim3(1024), 0, st, tab, L);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(3 + (L.nseg + 63) / 64, nviews), dim3(1024), 0, st, tab, L, k3);
   }
-  if (L.N > 0) {
+  if (k3) {
     ProfScope prof(PK_SCATTER, st);
     hipLaunchKernelGGL(scatter_kernel, dim3((L.nseg + 3) / 4, nviews), dim3(256), 0, st, tab, L);
   }

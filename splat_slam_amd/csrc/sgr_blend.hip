@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
   // same round trip as the range -- the first half of the bucket, which covers 98 % of the tiles of a SLAM view; the
   // rest follows once the count is known (entries behind the tile's count are ignored).
   const uint64_t* __restrict__ bucket = (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
-  static_assert(kBucket == kWave, "one bucket entry per lane");
+  static_assert(kBucket >= kWave, "the first 64 entries of a bucket are fetched one per lane");
   uint64_t key_spec = lane < 32 ? bucket[lane] : ~0ull;
   const uint2 rng = ranges[(size_t)tile * kRngStride];
   const int64_t begin = rng.x & ~kOverfull;

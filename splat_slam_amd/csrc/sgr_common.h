@@ -111,7 +111,8 @@ struct SavedHeader {
                            // rectangle that the exact footprint test dropped keep their slot); K2 writes it, K3 folds it into num_rendered
   uint32_t num_binned;     // pairs actually binned (K3; num_rendered then holds the capacity-relevant max(pairs binned, slot_total))
   uint32_t max_tile_count; // longest per-tile list of this forward (K2): what the caller picks the tile kernels' sort build by
-  uint32_t pad[5];
+  uint32_t k2_tickets;     // K2's blocks 0 and 1 take a ticket when done; the later one folds the header and resets this
+  uint32_t pad[4];
 };
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

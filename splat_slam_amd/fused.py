@@ -24,6 +24,7 @@ optimizer.step() / zero_grad(): its gradients stay on every parameter tensor tha
 leaves its gradients in the sinks, its isotropy term and exposure gradients are carried as "stale" state and consumed by
 the first optimiser step that follows (tests/test_gpu_fused.py replays the reference fixture through it).
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -64,6 +65,7 @@ class _ViewBuffers:
         self.capacity = 0
         self.gt_depth = None
         self.depth_src = None
+        self.mv = None
         self.new_map(N)
 
     def new_map(self, N):
@@ -76,13 +78,23 @@ class _ViewBuffers:
         self.pairs = -1            # (tile, Gaussian) pairs seen by the probe render; -1 = not probed at this map size
         self.estimated = False     # `pairs` is a carried-over estimate, not yet confirmed by a header read at this map size
         self.ran = False           # a forward has run on the saved block at THIS map size (its header is current)
-        self.mv = None
-        self.mv_key = None
+        # (the cached SgrMapViews stay: FusedMappingLoop._map_view re-fills what depends on N)
 
 
 def _index(rows, device):
     """Row indices on the device without a blocking pageable copy (torch.tensor(..., device=...) waits for the stream)."""
     return torch.tensor(list(rows), dtype=torch.long).pin_memory().to(device, non_blocking=True)
+
+
+class _Slot:
+    """A workspace that belongs to no camera: pick j of every iteration of a span renders in slot j."""
+    is_slot = True
+
+    def __init__(self):
+        self.saved = self.scratch = None
+        self.clean = self.ran = False
+        self.capacity = 0
+        self.mv = None
 
 
 class _ExposureSlab:
@@ -209,6 +221,13 @@ class FusedMappingLoop(MappingLoop):
         self._pair_hint = {}       # camera uid -> (measured pair count, map size it was measured at)
         self._list_hint = {}       # camera uid -> longest per-tile list measured (header word 10): picks the tile kernels' sort build
         self._ws_bytes = {}        # (N, H, W, capacity) -> (saved bytes, scratch bytes)
+        # Workspaces (~300 MB each) are not a per-keyframe resource: a map holds hundreds of keyframes, an iteration renders 12.
+        # Cameras that are rendered as REGULAR views (the window, special iterations) hold a private one, taken from the least
+        # recently used owner once `max_live_ws` are out; the random picks of a span share `picks_per_iter` SLOTS (SgrMapRun.pick_ws).
+        self._ws_owners = collections.OrderedDict()       # id(vb) -> vb, least recently used first
+        self._ws_protect = set()                          # id(vb) of the views of the call being built
+        self.max_live_ws = 32
+        self._slots = []
         self._exp = None
         self._exp_rows = []
         self._cap = 0
@@ -232,6 +251,8 @@ class FusedMappingLoop(MappingLoop):
         self._exp, self._exp_rows, self._cap, self._stale_iso = None, [], 0, 0.0
         self._pair_hint, self._list_hint = {}, {}
         self._plan_key = self._plan_obj = None
+        self._ws_owners.clear()
+        self._slots = []
 
     # ------------------------------------------------------------------------------------------------ state
     def set_parallel(self, world, rank, split_views=True, sync="zero1", comm=None):
@@ -301,7 +322,6 @@ class FusedMappingLoop(MappingLoop):
         self._views = {uid: vb for uid, vb in self._views.items() if uid in live}
         for vb in self._views.values():
             vb.new_map(N)
-        self._cap = 0
         if gm.active_sh_degree != 0 or gm._features_rest.numel() != 0:
             raise NotImplementedError("FusedMappingLoop supports the reference's default sh_degree 0 (mapper.py:85)")
         for g in gm.optimizer.param_groups:          # make sure Adam state exists exactly like torch would create it
@@ -431,14 +451,36 @@ class FusedMappingLoop(MappingLoop):
         sb, tb = sz
         # blocks are kept across map sizes and capacities (head-room: a map grows by a few per cent per keyframe).  The per-tile
         # counters sit at a fixed offset for a given (H, W), so a block that went through a forward stays clean whatever N is
-        if vb.saved is None or vb.saved.numel() < sb:
-            vb.saved = torch.empty(int(sb * 1.3) + (1 << 20), dtype=torch.uint8, device=self.device)
-            vb.clean = False       # per-tile counters of a fresh block are garbage: the library zeroes them once
+        if vb.saved is None or vb.saved.numel() < sb or vb.scratch is None or vb.scratch.numel() < tb:
+            self._acquire_blocks(vb, sb, tb)
+        elif id(vb) in self._ws_owners:
+            self._ws_owners.move_to_end(id(vb))
         vb.capacity = cap
-        if vb.scratch is None or vb.scratch.numel() < tb:
-            vb.scratch = torch.empty(int(tb * 1.3) + (1 << 20), dtype=torch.uint8, device=self.device)
         return nat.SgrWorkspace(vb.saved.data_ptr(), vb.saved.numel(), vb.scratch.data_ptr(), vb.scratch.numel(), cap,
                                 int(vb.clean), self._max_list())
+
+    def _acquire_blocks(self, vb, sb, tb):
+        """Gives `vb` a (saved, scratch) pair of at least (sb, tb) bytes: its own if large enough, else the pair of the least
+        recently used owner that the call being built does not need, else new blocks (with head-room)."""
+        me = id(vb)
+        self._ws_owners.pop(me, None)
+        if not getattr(vb, "is_slot", False) and len(self._ws_owners) >= self.max_live_ws:
+            for k, old in self._ws_owners.items():
+                if k not in self._ws_protect:
+                    del self._ws_owners[k]
+                    if old.saved is not None and old.saved.numel() >= sb and old.scratch.numel() >= tb and (vb.saved is None):
+                        vb.saved, vb.scratch, vb.clean = old.saved, old.scratch, False     # (another (H, W) may have used it)
+                    old.saved = old.scratch = None
+                    old.clean = old.ran = False
+                    old.mv = None
+                    break
+        if vb.saved is None or vb.saved.numel() < sb:
+            vb.saved = torch.empty((int(sb * 1.3) + (1 << 20)) // 256 * 256, dtype=torch.uint8, device=self.device)
+            vb.clean = False       # per-tile counters of a fresh block are garbage: the library zeroes them once
+        if vb.scratch is None or vb.scratch.numel() < tb:
+            vb.scratch = torch.empty((int(tb * 1.3) + (1 << 20)) // 256 * 256, dtype=torch.uint8, device=self.device)
+        if not getattr(vb, "is_slot", False):
+            self._ws_owners[me] = vb
 
     def _max_list(self):
         """Longest per-tile list measured on any camera of this map (0: nothing measured yet): the library picks the sort
@@ -452,7 +494,8 @@ class FusedMappingLoop(MappingLoop):
         nat.check(self.lib.sgr_query_header(vb.saved.data_ptr(), w, self._stream()), "sgr_query_header")
         R, ov, longest = int(w[0]), int(w[1]), int(w[10])
         vb.pairs, vb.estimated = R, False
-        self._pair_hint[uid] = (R, self.gaussians._xyz.shape[0])
+        if not getattr(vb, "is_slot", False):         # (a slot's count belongs to whichever camera rendered in it last)
+            self._pair_hint[uid] = (R, self.gaussians._xyz.shape[0])
         if longest != self._list_hint.get(uid):
             old = self._build_class()
             self._list_hint[uid] = longest
@@ -461,8 +504,10 @@ class FusedMappingLoop(MappingLoop):
         return R, ov
 
     def _build_class(self):
+        """What the library derives from the hint: -1 nothing measured yet, 0 lists within the 64-entry buckets (no scatter launch),
+        1 / 2 / 3 the light / mid / heavy sort build of the tile kernels."""
         m = self._max_list()
-        return 0 if m <= 768 else (1 if m <= 1536 else 2)
+        return -1 if m == 0 else (0 if m <= 64 else (1 if m <= 768 else (2 if m <= 1536 else 3)))
 
     def _estimate_pairs(self, cam, vb):
         """Pair count of a camera whose buffers are new.  A synchronous probe forward per camera and map size cost a converged
@@ -517,8 +562,8 @@ class FusedMappingLoop(MappingLoop):
             vb.ran = True
             if not vb.clean:
                 vb.clean = True
-                for _, mv in (vb.mv or {}).values():
-                    mv.ws.counters_clean = 1
+                for ent in (vb.mv or {}).values():
+                    ent[1].ws.counters_clean = 1
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _inputs(self):
@@ -533,23 +578,35 @@ class FusedMappingLoop(MappingLoop):
                                  gm.xyz_gradient_accum.data_ptr() if stats else None,
                                  gm.denom.data_ptr() if stats else None, gm.max_radii2D.data_ptr() if stats else None)
 
-    def _map_view(self, cam, initialization=False, images=True):
+    def _map_view(self, cam, initialization=False, images=True, slot=False):
         """The cached SgrMapView of a camera: pointers into its persistent buffers, sized for the shared capacity.
-        images=False: loss + gradients only (the rendered colour / depth / opacity are not written to HBM)."""
+        images=False: loss + gradients only (the rendered colour / depth / opacity are not written to HBM).
+        slot=True: a pool entry of a span whose picks render in shared workspace slots: no workspace of its own."""
         vb = self._view(cam)
         key = (cam._version, self._cap, id(cam.exposure_a), id(cam.original_image), vb.gt_depth.data_ptr(), initialization,
                self.keyframe_optimizers is not None)
         if vb.mv is None:
             vb.mv = {}
-        hit = vb.mv.get(images)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        hit = vb.mv.get((images, slot))
         gm = self.gaussians
         N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
+        if hit is not None and hit[0] == key:
+            mv = hit[1]
+            if hit[2] != N:          # the map changed size: same buffers, same camera -- only what depends on N is re-filled
+                mv.settings.num_gaussians = N
+                mv.out.radii, mv.out.n_touched = vb.radii.data_ptr(), vb.n_touched.data_ptr()
+                if not slot:
+                    mv.ws = self._workspace(vb, N, H, W, self._cap)
+                hit[2] = N
+            elif not slot and (vb.saved is None or id(vb) not in self._ws_owners):
+                mv.ws = self._workspace(vb, N, H, W, self._cap)         # (its blocks went to another camera meanwhile)
+            elif not slot:
+                self._ws_owners.move_to_end(id(vb))
+            return mv
         s = self._settings(cam, N)
         out = nat.SgrOutputs(vb.color.data_ptr() if images else None, vb.depth.data_ptr() if images else None,
                              vb.opacity.data_ptr() if images else None, vb.radii.data_ptr(), vb.n_touched.data_ptr())
-        ws = self._workspace(vb, N, H, W, self._cap)
+        ws = nat.SgrWorkspace() if slot else self._workspace(vb, N, H, W, self._cap)
         mv = nat.SgrMapView()
         mv.settings, mv.out, mv.ws = s, out, ws
         mv.gt_image, mv.gt_depth = cam.original_image.data_ptr(), vb.gt_depth.data_ptr()
@@ -560,21 +617,37 @@ class FusedMappingLoop(MappingLoop):
         mv.dL_dexposure = vb.d_exp.data_ptr() if row is None else self._exp.grad.data_ptr() + 8 * row
         mv.dL_dtau = vb.d_tau.data_ptr() if self.keyframe_optimizers is not None else None
         mv.loss_scratch, mv.loss_scratch_bytes = vb.loss_scratch.data_ptr(), vb.loss_scratch.numel()
-        vb.mv[images] = (key, mv)
+        vb.mv[(images, slot)] = [key, mv, N]
         return mv
 
-    def _views_array(self, cams, initialization, images=True):
-        n = len(cams)
+    def _settle_capacity(self, cams):
+        """Pair-count estimates of cameras whose buffers are new, and ONE capacity for all cameras (batched launches share a
+        layout).  It only grows, in steps: the workspaces and the cached structs keep their shape from keyframe to keyframe
+        (check_overflow shrinks it when it is far off)."""
         need = self._cap
         for c in cams:
             vb = self._view(c)
             if vb.pairs < 0:                          # buffers are new (camera, or every camera after the map changed size)
                 self._estimate_pairs(c, vb)
             need = max(need, 1 << 16, 2 * vb.pairs)
-        if need != self._cap:                         # ONE capacity for all cameras: batched launches share a layout
-            self._cap = need
+        if need > self._cap:
+            self._cap = int(need * 1.25)
             self._views_dirty()
-        return (nat.SgrMapView * n)(*[self._map_view(c, initialization, images) for c in cams])
+
+    def _views_array(self, cams, initialization, images=True, slot=False):
+        n = len(cams)
+        self._settle_capacity(cams)
+        if not slot:
+            self._ws_protect = {id(self._view(c)) for c in cams}
+            self.max_live_ws = max(self.max_live_ws, n + 8)
+        return (nat.SgrMapView * n)(*[self._map_view(c, initialization, images, slot) for c in cams])
+
+    def _slot_workspaces(self, count, N, H, W):
+        """`count` shared workspace slots at the current capacity (SgrMapRun.pick_ws)."""
+        while len(self._slots) < count:
+            sl = _Slot()
+            self._slots.append(sl)
+        return (nat.SgrWorkspace * max(1, count))(*[self._workspace(sl, N, H, W, self._cap) for sl in self._slots[:count]])
 
     def _plan(self):
         """Structs that only change when the parameter tensors do (new N, opacity reset, ...)."""
@@ -662,16 +735,18 @@ class FusedMappingLoop(MappingLoop):
         if self._parallel() or n_it == 0:
             raise RuntimeError("_run_span is the single-GPU fast path")
         pl = self._plan()
-        self._views_array(list(window_cams) + list(pool_cams), initialization)   # probes new cameras, settles the capacity
+        self._settle_capacity(list(window_cams) + list(pool_cams))               # estimates for new cameras, ONE capacity
         per0 = len(picks) // n_it if picks else 0
         if n_it > 1 and not verified and any(self._views[c.uid].estimated for c in
                                              list(window_cams) + [pool_cams[k] for k in picks[:per0]]):
             self._run_span(window_cams, pool_cams, picks[:per0], lrs[:1], iso_weight, exposure, stats, initialization, verified=True)
-            self.check_overflow()
+            if not self.check_overflow():
+                for k in picks[:per0]:               # (rendered in the slots that were just read back: their estimates held)
+                    self._views[pool_cams[k].uid].estimated = False
             return self._run_span(window_cams, pool_cams, picks[per0:], lrs[1:], iso_weight, exposure, stats, initialization,
                                   verified=True)
         win = self._views_array(window_cams, initialization, images=False) if window_cams else None
-        pool = self._views_array(pool_cams, initialization, images=False) if pool_cams else None
+        pool = self._views_array(pool_cams, initialization, images=False, slot=True) if pool_cams else None
         st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
         per = len(picks) // n_it if picks else 0
         run = nat.SgrMapRun()
@@ -685,6 +760,11 @@ class FusedMappingLoop(MappingLoop):
         lr = (C.c_float * n_it)(*lrs)
         run.picks, run.lr0, run.adam_groups = pk, lr, pl.groups
         run.n_touched_last_only = 1
+        slots = None
+        if pool_cams and per:
+            c0 = pool_cams[0]
+            slots = self._slot_workspaces(per, self.gaussians._xyz.shape[0], int(c0.image_height), int(c0.image_width))
+            run.pick_ws = slots
         rows = None
         if exposure == "per_pick":
             rows = (C.c_int32 * max(1, len(pool_cams)))(*[
@@ -695,7 +775,10 @@ class FusedMappingLoop(MappingLoop):
         nat.check(rc, "sgr_map_run")
         self.gaussians.invalidate_activations()    # parameters changed through raw pointers: cached torch activations are stale
         self._acc_clean = True
-        self._mark_clean(list(window_cams) + [pool_cams[k] for k in set(picks)])
+        self._mark_clean(list(window_cams))
+        for sl in self._slots[:per]:
+            sl.clean = sl.ran = True
+        self._last_pick_slots = {pool_cams[k].uid: j for j, k in enumerate(picks[len(picks) - per:])} if per else {}
         for g, stt in pl.states:                 # the library advanced pl.groups[k].step; mirror it in torch's state
             stt["step"] += n_it
         pl.frest_state["step"] += n_it
@@ -714,7 +797,7 @@ class FusedMappingLoop(MappingLoop):
         del mine_w
         cams_needed = [c for i, c in enumerate(window_cams) if i in pos] + (list(pool_cams) if any(i >= nw for i in pos) else [])
         if cams_needed:
-            self._views_array(cams_needed, False)                          # probes new cameras, settles the capacity
+            self._settle_capacity(cams_needed)                             # estimates for new cameras, ONE capacity
         st = self._setup(pl, iso_weight, True, (), stats, False, "none", bump=False)
         views_st = nat.SgrMapStep()
         C.memmove(C.byref(views_st), C.byref(st), C.sizeof(st))
@@ -731,6 +814,7 @@ class FusedMappingLoop(MappingLoop):
         used = []
         for k in range(n_it):
             used = list(window_cams) + [pool_cams[picks[k * per + j]] for j in range(per)]
+            self._ws_protect = {id(self._view(used[i])) for i in pos}      # (workspaces are handed out lazily, least recently used first)
             for slot, i in enumerate(pos):
                 arr[slot] = self._map_view(used[i], False, images=False)
             if exp_rows:
@@ -900,9 +984,9 @@ class FusedMappingLoop(MappingLoop):
         """One synchronisation: did any camera's forward exceed the pair capacity since the last check?"""
         self._since_check = 0
         worst, overflowed = 0, []
-        for uid, vb in self._views.items():
-            if vb.saved is None or not vb.mv or not vb.ran:        # (no forward at this map size yet: the header is an old one)
-                continue
+        todo = [(uid, vb) for uid, vb in self._views.items() if vb.saved is not None and vb.mv and vb.ran]
+        todo += [(("slot", j), sl) for j, sl in enumerate(self._slots) if sl.saved is not None and sl.ran]
+        for uid, vb in todo:                          # (no forward at this map size yet: the header would be an old one)
             R, ov = self._read_header(uid, vb)
             if ov == 2:
                 raise RuntimeError(f"camera {uid}: more than 65280 splats on one 8x8 tile -- the map has degenerated")
@@ -913,8 +997,8 @@ class FusedMappingLoop(MappingLoop):
                 raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
                                    "the map has degenerated")
             worst = max(worst, vb.pairs)
-        if worst * 1.5 > self._cap:
-            self._cap = max(1 << 16, 2 * worst)
+        if worst * 1.5 > self._cap or (worst > 0 and 8 * worst < self._cap and self._cap > (1 << 16)):
+            self._cap = max(1 << 16, int(2.5 * worst))
             self._views_dirty()
         if overflowed:
             import warnings
@@ -1247,6 +1331,15 @@ class FusedMappingLoop(MappingLoop):
             self.gaussians.update_learning_rate(self.iteration_count)
             self.last_used = [cam]
             self._tick()
+
+    def workspace_of(self, cam):
+        """The object (per-camera buffers or a shared slot) whose saved / scratch blocks hold the LAST forward of `cam` --
+        counters and histograms of bench.py / the session script read them."""
+        j = getattr(self, "_last_pick_slots", {}).get(cam.uid)
+        vb = self._views.get(cam.uid)
+        if j is not None and (vb is None or vb.saved is None or not vb.ran):
+            return self._slots[j]
+        return vb
 
     # convenience for evaluation / tests
     @property
