@@ -535,7 +535,7 @@ def test_views_that_overflow_the_pair_capacity_take_no_part_in_the_step():
     f.check_every = 1 << 30                         # no host check in between
     f.map(f.current_window, iters=2)
     torch.cuda.synchronize()
-    real = max(vb.pairs for vb in f._views.values() if not vb.estimated)      # (measured counts: the window keyframes)
+    real = max(h[0] for h in f._pair_hint.values())                 # (MEASURED counts: header reads of the window keyframes)
     assert real > (1 << 16), real                   # the scene really needs more than the floor capacity
     gm = f.gaussians
     for vb in f._views.values():                    # pretend the probes had seen a nearly empty map
