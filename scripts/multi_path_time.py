@@ -65,8 +65,23 @@ for world in (1, 2, 4, 8):
         if t < tot:
             tot, host = t, h
     N = 300000
+    kern = None
+    if "--kernels" in sys.argv:                      # HIP-event time per kernel kind (serialises the kernels: shares, not a sum)
+        import ctypes as C
+        import bench
+        from splat_slam_amd import _native as nat
+        lib = nat.lib()
+        lib.sgr_profile_enable((1 << len(bench.KINDS)) - 1)
+        loop.iteration_count = 50
+        loop.map(loop.current_window, iters=40)
+        torch.cuda.synchronize()
+        ms, cnt = (C.c_float * len(bench.KINDS))(), (C.c_int64 * len(bench.KINDS))()
+        lib.sgr_profile_read(ms, cnt)
+        lib.sgr_profile_enable(0)
+        kern = {bench.KINDS[i]: [round(float(ms[i]) / 40, 5), int(cnt[i]) // 40] for i in range(len(bench.KINDS)) if cnt[i]}
     print(json.dumps({"world": world, "views_of_rank0_per_iteration": len(range(0, 12, world)), "ms_per_iteration_rank0_no_collective_time":
                       round(1e3 * tot / 80, 4), "host_enqueue_ms_per_iteration": round(1e3 * host / 80, 4),
-                      "bytes_reduce_scatter_plus_all_gather": 2 * 56 * N if world > 1 else 0}), flush=True)
+                      "bytes_reduce_scatter_plus_all_gather": 2 * 56 * N if world > 1 else 0,
+                      **({"kernel_ms_per_iteration_and_launches": kern} if kern else {})}), flush=True)
     del loop
     torch.cuda.empty_cache()

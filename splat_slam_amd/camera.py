@@ -64,8 +64,9 @@ class Camera(nn.Module):
         self.image_height, self.image_width = image_height, image_width
         self.cam_rot_delta = nn.Parameter(torch.zeros(3, requires_grad=True, device=device))
         self.cam_trans_delta = nn.Parameter(torch.zeros(3, requires_grad=True, device=device))
-        self.exposure_a = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
-        self.exposure_b = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
+        # (zeros(): a fill on the device; tensor([0.0], device=...) is a pageable host-to-device copy that waits for the stream)
+        self.exposure_a = nn.Parameter(torch.zeros(1, requires_grad=True, device=device))
+        self.exposure_b = nn.Parameter(torch.zeros(1, requires_grad=True, device=device))
         self.projection_matrix = projection_matrix.to(device=device).contiguous()   # raw pointers are handed to the C ABI
         self._cache = None
         self._version = 0

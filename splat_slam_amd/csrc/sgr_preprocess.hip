@@ -451,8 +451,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     for (int v = 0; v < nviews; ++v) {
       bool pass = false;
       if (ia < N && (v % nparts) == part) {
+        if (!(L.dbg & 16)) {
         p_radii[v][ia] = 0;                // outputs of the culled majority; phase B overwrites the visible ones
         if (p_ntouched[v]) p_ntouched[v][ia] = 0;
+        }
         if (L.dbg & 2) pass = (p[0] + trS == 12345.678f);
         else if (segv & (1u << v)) pass = (L.dbg & 8) ? maybe_visible(p, trS, L.H, L.W, cm.tanfovx, cm.tanfovy, mats[v], mats[v] + 16, L.sgx, L.sgy)
                                                       : maybe_visible_planes(p, sroot, mats[v], mats[v] + 16, cullK[v], L.H, L.W, L.sgx, L.sgy);
@@ -523,7 +525,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
     const uint32_t cnt = o.visible ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
     const uint32_t vis = o.visible ? 1u : 0u;
-    if (o.visible) {
+    if (o.visible && !(L.dbg & 128)) {
       atomicOr(&vis_bits[i - seg0], 1u << v);
       p_radii[v][i] = (int32_t)o.rad;
       float4* rec = (float4*)((GRec*)(saved + L.o_grec) + i);          // q3 (prefix, list slot) follows after the scans
@@ -575,12 +577,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     // ... and its counting atomic: the old word holds the rank of this splat in each covered tile
     auto issue = [&](int view, uint32_t geo) -> unsigned long long {
       const uint32_t cover = geo >> 28;
-      if (cover == 0u) return 0ull;                  // (every bin of this block dropped)
+      if (cover == 0u || (L.dbg & 32)) return 0ull;  // (every bin of this block dropped)
       const unsigned long long inc = (unsigned long long)(cover & 1u) | ((unsigned long long)((cover >> 1) & 1u) << 16) |
                                      ((unsigned long long)((cover >> 2) & 1u) << 32) | ((unsigned long long)((cover >> 3) & 1u) << 48);
       unsigned long long* c = (unsigned long long*)(p_saved[view] + L.o_tile_count) +
                               tile_counter_word((int)(geo & 0x3fffu), (int)((geo >> 14) & 0x3fffu), L.gxp);
-      return atomicAdd(c, inc);
+      return atomicAdd(c, (L.dbg & 64) ? 0ull : inc);
     };
     // Binning of a batch of (up to) four operations per lane; desc(jj) -> (on, view, key) of operation jj, geo[jj] its block.
     // A pair whose rank fits the tile's bucket is written there; the others join their view's overflow list.  On a converged
@@ -594,6 +596,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
       return Desc{(int)vz.x, ((uint64_t)op_depth[owner] << 32) | vz.y};
     };
     auto consume4 = [&](const unsigned long long old[4], const uint32_t geo[4], const int owner[4]) {
+      if (L.dbg & 64) return;
       uint32_t sp = 0u;                         // 4 bits per operation: which of its four tiles overflow
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {

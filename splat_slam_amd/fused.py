@@ -81,9 +81,48 @@ class _ViewBuffers:
         # (the cached SgrMapViews stay: FusedMappingLoop._map_view re-fills what depends on N)
 
 
+class _IndexStage:
+    """Row-index tensors on the device without a host wait.  torch.tensor(rows, device=...) is a pageable copy (waits for the
+    stream); .pin_memory() per call allocates a fresh pinned block whenever the previous ones are still referenced by copies
+    in flight -- with the GPU tens of milliseconds behind the host that is every call, ~0.7 ms each with the GPU idle behind it.
+    Here: ONE pinned ring written in place (a slot is reused 1 << 15 entries later: long after its copy ran) + the last few
+    index tensors kept by value (the window's rows repeat from iteration to iteration)."""
+    RING = 1 << 15
+
+    def __init__(self):
+        self.ring = None
+        self.pos = 0
+        self.cache = collections.OrderedDict()
+
+    def get(self, rows, device):
+        key = (tuple(rows), str(device))
+        hit = self.cache.get(key)
+        if hit is not None:
+            self.cache.move_to_end(key)
+            return hit
+        n = len(key[0])
+        if n == 0 or n > self.RING // 8:
+            return torch.tensor(list(rows), dtype=torch.long, device=device)
+        if self.ring is None:
+            self.ring = torch.empty(self.RING, dtype=torch.long, pin_memory=True)
+        if self.pos + n > self.RING:
+            self.pos = 0
+        src = self.ring[self.pos:self.pos + n]
+        self.pos += n
+        src.copy_(torch.tensor(key[0], dtype=torch.long))
+        out = src.to(device, non_blocking=True)
+        self.cache[key] = out
+        if len(self.cache) > 64:
+            self.cache.popitem(last=False)
+        return out
+
+
+_INDEX_STAGE = _IndexStage()
+
+
 def _index(rows, device):
-    """Row indices on the device without a blocking pageable copy (torch.tensor(..., device=...) waits for the stream)."""
-    return torch.tensor(list(rows), dtype=torch.long).pin_memory().to(device, non_blocking=True)
+    """Row indices on the device (see _IndexStage).  The result may be shared between callers: never written to."""
+    return _INDEX_STAGE.get(list(rows), device)
 
 
 class _Slot:
@@ -218,6 +257,10 @@ class FusedMappingLoop(MappingLoop):
         self._acc_clean = True
         self._scratch = None
         self._since_check = 0
+        self.async_checks = True   # the PERIODIC capacity check posts its header read-back and looks at it one check later (no host wait)
+        self._pending_check = None
+        self._hdr_pinned = None
+        self._gen = 0              # bumped whenever cached launch structs go stale (capacity, hints, buffers)
         self._pair_hint = {}       # camera uid -> (measured pair count, map size it was measured at)
         self._list_hint = {}       # camera uid -> longest per-tile list measured (header word 10): picks the tile kernels' sort build
         self._ws_bytes = {}        # (N, H, W, capacity) -> (saved bytes, scratch bytes)
@@ -253,6 +296,7 @@ class FusedMappingLoop(MappingLoop):
         self._plan_key = self._plan_obj = None
         self._ws_owners.clear()
         self._slots = []
+        self._pending_check = None
 
     # ------------------------------------------------------------------------------------------------ state
     def set_parallel(self, world, rank, split_views=True, sync="zero1", comm=None):
@@ -492,6 +536,9 @@ class FusedMappingLoop(MappingLoop):
         """One synchronous header read of a camera's last forward: pair count, overflow word, longest list."""
         w = (C.c_uint32 * 16)()
         nat.check(self.lib.sgr_query_header(vb.saved.data_ptr(), w, self._stream()), "sgr_query_header")
+        return self._apply_header(uid, vb, w)
+
+    def _apply_header(self, uid, vb, w):
         R, ov, longest = int(w[0]), int(w[1]), int(w[10])
         vb.pairs, vb.estimated = R, False
         if not getattr(vb, "is_slot", False):         # (a slot's count belongs to whichever camera rendered in it last)
@@ -740,11 +787,23 @@ class FusedMappingLoop(MappingLoop):
         if n_it > 1 and not verified and any(self._views[c.uid].estimated for c in
                                              list(window_cams) + [pool_cams[k] for k in picks[:per0]]):
             self._run_span(window_cams, pool_cams, picks[:per0], lrs[:1], iso_weight, exposure, stats, initialization, verified=True)
+            # the launch structs of the rest are built while that iteration runs; the read-back then only decides whether they stand
+            rest = (window_cams, pool_cams, picks[per0:], lrs[1:], iso_weight, exposure, stats, initialization)
+            prep = self._prepare_span(*rest)
+            gen = self._gen
             if not self.check_overflow():
                 for k in picks[:per0]:               # (rendered in the slots that were just read back: their estimates held)
                     self._views[pool_cams[k].uid].estimated = False
-            return self._run_span(window_cams, pool_cams, picks[per0:], lrs[1:], iso_weight, exposure, stats, initialization,
-                                  verified=True)
+            if self._gen != gen:                     # capacity / sort build changed: the structs are stale
+                prep = self._prepare_span(*rest)
+            return self._launch_span(prep)
+        return self._launch_span(self._prepare_span(window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats, initialization))
+
+    def _prepare_span(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats, initialization):
+        """Everything sgr_map_run needs, as ctypes objects (kept alive by the returned tuple)."""
+        n_it = len(lrs)
+        pl = self._plan()
+        self._settle_capacity(list(window_cams) + list(pool_cams))               # ONE capacity for the window and the pool
         win = self._views_array(window_cams, initialization, images=False) if window_cams else None
         pool = self._views_array(pool_cams, initialization, images=False, slot=True) if pool_cams else None
         st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
@@ -771,11 +830,15 @@ class FusedMappingLoop(MappingLoop):
                 (self._exp.row_of(c) if self._exp is not None and self._exp.row_of(c) in self._exp_rows else -1)
                 for c in pool_cams])
             run.pool_exp_row = rows
+        return run, pl, n_it, per, list(window_cams), list(pool_cams), list(picks), (win, pool, pk, lr, slots, rows)
+
+    def _launch_span(self, prep):
+        run, pl, n_it, per, window_cams, pool_cams, picks, _keep = prep
         rc = self.lib.sgr_map_run(C.byref(run), self._stream())
         nat.check(rc, "sgr_map_run")
         self.gaussians.invalidate_activations()    # parameters changed through raw pointers: cached torch activations are stale
         self._acc_clean = True
-        self._mark_clean(list(window_cams))
+        self._mark_clean(window_cams)
         for sl in self._slots[:per]:
             sl.clean = sl.ran = True
         self._last_pick_slots = {pool_cams[k].uid: j for j, k in enumerate(picks[len(picks) - per:])} if per else {}
@@ -951,6 +1014,7 @@ class FusedMappingLoop(MappingLoop):
             self.keyframe_optimizers = torch.optim.Adam(groups) if groups else None
 
     def _views_dirty(self):
+        self._gen += 1
         for vb in self._views.values():
             vb.mv = None
 
@@ -980,37 +1044,96 @@ class FusedMappingLoop(MappingLoop):
             self.keyframe_optimizers.step()
             self.keyframe_optimizers.zero_grad(set_to_none=True)
 
-    def check_overflow(self):
-        """One synchronisation: did any camera's forward exceed the pair capacity since the last check?"""
-        self._since_check = 0
-        worst, overflowed = 0, []
+    def _check_targets(self):
         todo = [(uid, vb) for uid, vb in self._views.items() if vb.saved is not None and vb.mv and vb.ran]
         todo += [(("slot", j), sl) for j, sl in enumerate(self._slots) if sl.saved is not None and sl.ran]
-        for uid, vb in todo:                          # (no forward at this map size yet: the header would be an old one)
-            R, ov = self._read_header(uid, vb)
+        return todo                                   # (no forward at this map size yet: the header would be an old one)
+
+    def _post_headers(self, todo):
+        """The 64-byte headers of the workspaces in `todo`, gathered on the device and copied to pinned host memory with ONE
+        transfer (a read-back per camera cost a converged session ~30 host round trips per check with the GPU idle)."""
+        n = len(todo)
+        if self._hdr_pinned is None or self._hdr_pinned.numel() < 64 * n:
+            self._hdr_pinned = torch.empty(64 * max(64, 2 * n), dtype=torch.uint8, pin_memory=True)
+        host = self._hdr_pinned[: 64 * n]
+        host.copy_(torch.cat([vb.saved[:64] for _, vb in todo]), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return host, ev
+
+    def _apply_headers(self, todo, host, fresh):
+        """What a capacity check does with the headers it read.  fresh: the map has not changed size since the read was posted
+        (otherwise the counts describe workspaces that no longer exist: only the overflow words still mean something)."""
+        words = host.numpy().view(np.uint32).reshape(-1, 16)
+        worst, overflowed = 0, []
+        for (uid, vb), w in zip(todo, words):
+            ov = int(w[1])
+            if fresh:
+                self._apply_header(uid, vb, w)
+                if vb.pairs > self.max_pairs:
+                    raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
+                                       "the map has degenerated")
+                worst = max(worst, vb.pairs)
             if ov == 2:
                 raise RuntimeError(f"camera {uid}: more than 65280 splats on one 8x8 tile -- the map has degenerated")
             if ov:
                 self.overflow_events += 1
                 overflowed.append(uid)
-            if vb.pairs > self.max_pairs:
-                raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
-                                   "the map has degenerated")
-            worst = max(worst, vb.pairs)
         if worst * 1.5 > self._cap or (worst > 0 and 8 * worst < self._cap and self._cap > (1 << 16)):
             self._cap = max(1 << 16, int(2.5 * worst))
+            self._views_dirty()
+        elif overflowed and not fresh:
+            self._cap = int(1.5 * self._cap)           # (stale counts: grow blindly, the next check measures)
             self._views_dirty()
         if overflowed:
             import warnings
             warnings.warn(f"FusedMappingLoop: the forward of camera(s) {overflowed} exceeded the (tile, Gaussian) pair capacity; those "
                           "views took no part in the optimiser steps since the previous check (the workspace has been grown)",
-                          RuntimeWarning, stacklevel=2)
+                          RuntimeWarning, stacklevel=3)
         return overflowed
+
+    def _harvest(self, wait):
+        """Looks at the read-back a periodic check posted earlier.  Returns the overflowed cameras ([] if nothing was pending or
+        the transfer has not finished and wait is False)."""
+        pend = self._pending_check
+        if pend is None:
+            return []
+        todo, host, ev, n_posted, bufs = pend
+        if not wait and not ev.query():
+            return []
+        ev.synchronize()
+        self._pending_check = None
+        fresh = n_posted == self.gaussians._xyz.shape[0] and all(vb.saved is not None and vb.saved.data_ptr() == b for (_, vb), b in zip(todo, bufs))
+        return self._apply_headers(todo, host, fresh)
+
+    def check_overflow(self, wait=True):
+        """Did any camera's forward exceed the pair capacity since the last check?  wait=True: one synchronisation, the answer
+        covers everything enqueued so far.  wait=False (the periodic check of the loops): the read-back is posted behind the
+        enqueued work and looked at by the NEXT check -- the host never waits and the GPU never idles; an overflow is reported
+        (and the capacity corrected) one check interval later."""
+        self._since_check = 0
+        overflowed = self._harvest(wait=True) if wait else self._harvest(wait=False)
+        if self._pending_check is not None:           # (wait=False and the previous read-back is still in flight: keep it)
+            return overflowed
+        todo = self._check_targets()
+        if not todo:
+            return overflowed
+        host, ev = self._post_headers(todo)
+        if wait:
+            ev.synchronize()
+            return overflowed + self._apply_headers(todo, host, True)
+        self._pending_check = (todo, host, ev, self.gaussians._xyz.shape[0], [vb.saved.data_ptr() for _, vb in todo])
+        return overflowed
+
+    def _periodic_check(self, steady=False):
+        """steady: called from map() (a converged window: pair counts drift slowly, a check that reports one interval late is
+        fine); initialize_map / final_refine / single iterations keep the synchronous check."""
+        self.check_overflow(wait=not (steady and self.async_checks))
 
     def _tick(self):
         self._since_check += 1
         if self._since_check >= self.check_every:
-            self.check_overflow()
+            self._periodic_check()
 
     # ------------------------------------------------------------------------------------------------ loops
     def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
@@ -1049,7 +1172,7 @@ class FusedMappingLoop(MappingLoop):
                 nt = vb.n_touched
                 self._since_check += n
                 if self._since_check >= self.check_every:
-                    self.check_overflow()
+                    self._periodic_check()
                 continue
             self.iteration_count += 1
             self._ensure_state()
@@ -1120,7 +1243,7 @@ class FusedMappingLoop(MappingLoop):
                     self._sync_moments()
                 self._since_check += n
                 if self._since_check >= self.check_every:
-                    self.check_overflow()
+                    self._periodic_check(steady=True)
                 continue
             self.iteration_count += 1
             gaussian_split = False
@@ -1320,7 +1443,7 @@ class FusedMappingLoop(MappingLoop):
             self.last_used = [stack[picks[-1]]]
             self._since_check += n
             if self._since_check >= self.check_every:
-                self.check_overflow()
+                self._periodic_check()
             done += n
         for _ in range(iters - done):
             self.iteration_count += 1

@@ -50,7 +50,7 @@ class MappingSession:
         iou = self._shared(cur_vis, last_vis) / torch.logical_or(cur_vis, last_vis).count_nonzero()
         far = baseline > tr["kf_translation"] * self.median_depth
         moved = baseline > tr["kf_min_translation"] * self.median_depth
-        return bool(far or (moved and iou < tr["kf_overlap"]))
+        return bool(far | (moved & (iou < tr["kf_overlap"])))          # ONE read-back (the three tests as one device expression)
 
     def add_to_window(self, cur_frame_idx, cur_vis, occ_aware_visibility, window):
         """Pushes the new keyframe in front; the two newest entries are never evicted.  First the OLDEST window entry whose
@@ -62,8 +62,13 @@ class MappingSession:
         cut_off = self.config["mapping"]["Training"].get("kf_cutoff", 0.4)
         removed_frame = None
         n_cur = cur_vis.count_nonzero()
-        low_overlap = [k for k in window[keep_newest:]
-                       if self._shared(cur_vis, occ_aware_visibility[k]) / min(n_cur, occ_aware_visibility[k].count_nonzero()) <= cut_off]
+        older = window[keep_newest:]
+        low_overlap = []
+        if older:                                   # every window entry's overlap coefficient in one pass, ONE read-back
+            occ = torch.stack([occ_aware_visibility[k] for k in older]) != 0
+            shared = torch.logical_and(occ, (cur_vis != 0)[None]).count_nonzero(dim=1)
+            ratio = shared / torch.minimum(n_cur, occ.count_nonzero(dim=1))
+            low_overlap = [k for k, low in zip(older, (ratio <= cut_off).tolist()) if low]
         if low_overlap:
             removed_frame = low_overlap[-1]
             window.remove(removed_frame)
