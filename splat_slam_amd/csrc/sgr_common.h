@@ -159,6 +159,9 @@ struct Common {
 // SGR_DEBUG environment variable -- stage-cost experiments only (scripts/stage_times.py), results are wrong when set:
 //   bit 0: preprocess_fwd stops after the cull / compact phase     bit 1: ... and skips the visibility test's arithmetic
 //   bit 2: preprocess_fwd does NOT use the whole-segment test (results stay correct: A/B timing of that test)
+//   bit 3: the cull uses the old per-Gaussian projection test instead of the plane test (results stay correct)
+//   bit 4: the cull does not zero radii / n_touched     bit 5: no counting atomics (every rank 0)
+//   bit 6: counting atomics add 0 and nobody consumes the ranks (atomics issued, lists stay empty)     bit 7: no record writes
 int debug_flags();
 
 // Everything later stages gather BY GAUSSIAN for one view, as ONE 64-byte record (= one HBM sector pair, one L2 line
