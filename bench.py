@@ -115,7 +115,8 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({"metric": "mapping frames/sec + render ms @640x480, 300k Gaussians; PSNR vs ref", "value": None, "dry_run": True,
                           "n_gpus": world, "ranks_seen": int(seen.item()), "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(1e3 * float(t.item()) / max(1, args.steps), 6), "scaling": args.scaling}))
+                          "ms_per_step": round(1e3 * float(t.item()) / max(1, args.steps), 6),
+                          "scaling": args.scaling if world > 1 else "none", "scaling_when_sharded": args.scaling}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -378,7 +379,8 @@ def main():
         "metric": "mapping frames/sec + render ms @640x480, 300k Gaussians; PSNR vs ref",
         "value": round(value, 4), "unit": "mapped keyframes/s (61 map() iterations each)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "none", "scaling_when_sharded": args.scaling,
+        "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "configs[1]-shaped: synthetic room (SURVEY 8d), %d Gaussians, %dx%d, %d views/step "
                                "(10 window + 2 random) fwd+bwd + loss + isotropy + Adam%s"

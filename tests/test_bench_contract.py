@@ -17,7 +17,7 @@ def test_bench_line_has_the_contract_keys():
     for k in ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"]:
         assert k in d, k
-    assert d["higher_is_better"] is True and d["scaling"] in ("strong", "weak") and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["scaling"] == ("none" if d["n_gpus"] == 1 else d["scaling_when_sharded"]) and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert d["dtype"] == "f32" and d["n_gpus"] == 1 and "workload" in d["config"] and "model" not in d["config"]
     assert "640x480" in d["metric"] and d["config"]["gaussians"] == 300000 and d["config"]["width"] == 640 and d["config"]["height"] == 480
     r = d["roofline"]

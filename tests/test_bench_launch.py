@@ -27,4 +27,5 @@ def test_gpus_2_spawns_two_ranks_and_reports_them():
 
 def test_gpus_1_runs_in_process():
     d = _run("--gpus", "1", "--dry-run", "--steps", "2", "--scaling", "weak")
-    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["scaling"] == "weak"
+    # one rank scales nothing: the label says so; the mode the flags select is reported next to it
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["scaling"] == "none" and d["scaling_when_sharded"] == "weak"
