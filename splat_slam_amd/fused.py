@@ -1017,6 +1017,8 @@ class FusedMappingLoop(MappingLoop):
         self._gen += 1
         for vb in self._views.values():
             vb.mv = None
+        for sl in self._slots:          # (their headers describe forwards at the old capacity / hint: not to be read again)
+            sl.ran = False
 
     def _exposure_step(self, cams, only_rendered=False):
         if self._exp is None or not self._exp_rows:

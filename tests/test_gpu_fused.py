@@ -564,6 +564,50 @@ def test_views_that_overflow_the_pair_capacity_take_no_part_in_the_step():
         assert torch.isfinite(getattr(gm, n)).all(), n
 
 
+def test_asynchronous_capacity_check_reports_one_check_later_and_batched_read_equals_single_reads():
+    """check_overflow(wait=False) -- the periodic check of map() -- posts ONE transfer with every workspace header behind the
+    enqueued work and returns at once; the NEXT check looks at it: the overflow is reported (and the capacity corrected) one
+    interval late, never lost.  The batched read-back carries the same words as sgr_query_header per workspace."""
+    import ctypes as C
+    from splat_slam_amd import _native as nat
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    intr = syn.INTRINSICS["metric"]
+    params = syn.room_parameters(60000, seed=5, device=DEV)
+    params["scaling"] = params["scaling"] + 2.0
+    cams = syn.make_views(params, 4, intr, DEV, seed=5)
+    f = _loop(FusedMappingLoop, syn, params, cams, [0, 1, 2])
+    f.check_every = 1 << 30
+    f.map(f.current_window, iters=2)
+    assert f.check_overflow() == [] and f._pending_check is None
+    # the batched read == the per-workspace reads
+    todo = f._check_targets()
+    assert len(todo) >= 3
+    host, ev = f._post_headers(todo)
+    ev.synchronize()
+    words = host.numpy().view("uint32").reshape(-1, 16).copy()
+    for (uid, vb), w in zip(todo, words):
+        one = (C.c_uint32 * 16)()
+        nat.check(f.lib.sgr_query_header(vb.saved.data_ptr(), one, f._stream()), "sgr_query_header")
+        assert list(one) == [int(x) for x in w], uid
+    real = max(h[0] for h in f._pair_hint.values())
+    for vb in f._views.values():
+        vb.pairs = 1
+    f._cap = 1 << 16
+    f._views_dirty()
+    f.map(f.current_window, iters=2)                 # overflows, nobody looks
+    ev0 = f.overflow_events
+    assert f.check_overflow(wait=False) == []         # posted, not looked at
+    assert f._pending_check is not None and f.overflow_events == ev0
+    torch.cuda.synchronize()
+    with pytest.warns(RuntimeWarning, match="pair capacity"):
+        late = f.check_overflow(wait=False)           # harvests the posted read, posts the next one
+    assert late and f.overflow_events > ev0 and f._cap >= 1.5 * real
+    f.map(f.current_window, iters=2)
+    assert f.check_overflow() == []                   # synchronous form: waits for the pending one too
+    assert f._pending_check is None
+
+
 def test_exact_footprint_test_drops_bins_and_the_backward_skips_their_slots():
     """Large rotated splats: a good part of the bins of their rectangles are missed by the alpha >= 1/255 level set and are
     not binned (pairs binned < partial slots reserved); whatever the backward then sums must not depend on what the
