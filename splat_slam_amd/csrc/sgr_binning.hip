@@ -58,13 +58,13 @@ __device__ __forceinline__ void file_overfull_runs(char* saved, char* scratch, c
   }
 }
 
-// K2: independent jobs per view, one 1024-thread block each (grid = (3 + ceil(nseg / 64), views)):
+// K2: independent jobs per view, one 1024-thread block each (grid = (3, views)):
 //   (0) tile starts: ranges[t] = (start, end) of the tile's run; for tiles with more than kBucket pairs .x carries kOverfull.
 //       When no scatter launch follows (`k3_follows` == 0: the caller's measured longest list fits the buckets) this block also
 //       files the overflow list, should there be one after all -- correct for any map, just not parallel;
 //   (1) segment bases of the partial-slot offsets;
-//   (2) the number of visible Gaussians;  (3 + j) the compact visible list: the segments' visible lists (K1) concatenated
-//       (absolute position = segment base + position in the segment list), 64 segments per block.
+//   (2) the number of visible Gaussians (and the segments' bases in the compact visible list; the list itself is written by the
+//       first blocks of the tile kernel's launch, sgr_blend.hip: nothing before the backward reads it).
 // The later of blocks 0 and 1 folds the two pair counts into the header.  A fresh map (lists within the 64-entry buckets)
 // therefore needs no third binning launch at all.
 __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, int k3_follows) {
@@ -81,17 +81,44 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, in
       const int x = t % L.gx, y = t / L.gx;
       return (uint32_t)(tile_count[tile_counter_word(x, y, L.gxp)] >> tile_counter_shift(x, y)) & 0xffffu;
     };
-    uint32_t R = block1024_scan([&](int t) { return count_of(t); }, tmp, L.ntiles, red);
-    __syncthreads();
-    uint32_t over = 0, saturated = 0, longest = 0;
-    for (int t = threadIdx.x; t < L.ntiles; t += 1024) {
-      const uint32_t s0 = tmp[t], c = count_of(t);
-      saturated |= c >= kTileCountLimit ? 1u : 0u;
-      longest = c > longest ? c : longest;
-      // <= kBucket pairs: K1 already binned them in the tile's bucket, the run [s0, s0+c) only addresses point_list.
-      // more: the run is completed below / by scatter_kernel; .y ends at s0 + c as well.
-      ranges[(size_t)t * kRngStride] = make_uint2(c <= (uint32_t)kBucket ? s0 : (s0 | kOverfull), s0 + c);
-      over += c > (uint32_t)kBucket ? 1u : 0u;
+    // ONE pass, 8 tiles per thread (8192 per trip: a 640x480 view has 4800): the scanned values stay in registers and go straight
+    // into `ranges` (the first version scanned into a scratch array and read it back: a second trip through L2 on the critical
+    // path of every iteration -- this block is what the tile kernels wait for)
+    (void)tmp;
+    uint32_t R = 0, over = 0, saturated = 0, longest = 0;
+    {
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      for (int base = 0; base < L.ntiles; base += 8192) {
+        const int i0 = base + (int)threadIdx.x * 8;
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i0 + k) < L.ntiles ? count_of(i0 + k) : 0u;
+        uint32_t s8 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s8 += v[k];
+        const uint32_t inc = wave_scan_add_u32(s8);
+        if (lane == 63) red[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t r = red[w]; pre += (w < wv) ? r : 0u; tot += r; }
+        __syncthreads();
+        uint32_t run = R + pre + inc - s8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if ((i0 + k) < L.ntiles) {
+            const uint32_t c = v[k];
+            saturated |= c >= kTileCountLimit ? 1u : 0u;
+            longest = c > longest ? c : longest;
+            // <= kBucket pairs: K1 already binned them in the tile's bucket, the run [s0, s0+c) only addresses point_list.
+            // more: the run is completed below / by scatter_kernel; .y ends at s0 + c as well.
+            ranges[(size_t)(i0 + k) * kRngStride] = make_uint2(c <= (uint32_t)kBucket ? run : (run | kOverfull), run + c);
+            over += c > (uint32_t)kBucket ? 1u : 0u;
+          }
+          run += v[k];
+        }
+        R += tot;
+      }
     }
     over = wave_scan_add_u32(over);
     saturated = __syncthreads_or((int)saturated) ? 1u : 0u;
@@ -132,35 +159,6 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, in
     if (threadIdx.x == 0) hdr->num_visible = V;
     return;
   } else {
-    // (3 + j) the compact visible list of segments [64 j, 64 j + 64): the block adds up the visible counts of the segments in
-    // front of its own (<= a few thousand values: cheaper than waiting for block 2's scan), scans its own 64 counts, and 16
-    // lanes per segment copy that segment's list in one trip (a segment holds ~15 visible Gaussians of a SLAM view, at most 256)
-    __shared__ uint32_t s_base[64];
-    const uint32_t* __restrict__ bv = (const uint32_t*)(saved + L.o_block_vis);
-    const int seg0 = ((int)blockIdx.x - 3) * 64;
-    uint32_t before = 0;
-    for (int i = threadIdx.x; i < seg0; i += 1024) before += bv[i];
-    before = wave_scan_add_u32(before);
-    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = before;
-    const int ls = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    const uint32_t c = seg0 + ls < L.nseg ? bv[seg0 + ls] : 0u;
-    __syncthreads();
-    if (threadIdx.x < 64) {                     // exclusive scan of the 64 counts by one wave
-      uint32_t pre = 0;
-      for (int wv = 0; wv < 16; ++wv) pre += red[wv];
-      const uint32_t mine = seg0 + (int)threadIdx.x < L.nseg ? bv[seg0 + threadIdx.x] : 0u;
-      s_base[threadIdx.x] = pre + wave_scan_add_u32(mine) - mine;
-    }
-    __syncthreads();
-    const uint32_t* __restrict__ seg_list = (const uint32_t*)(saved + L.o_seg_list);
-    uint32_t* __restrict__ vis_list = (uint32_t*)(saved + L.o_vis_list);
-    GRec* __restrict__ grec = (GRec*)(saved + L.o_grec);
-    const uint32_t b = s_base[ls];
-    for (uint32_t k = sub; k < c; k += 16) {
-      const uint32_t i = seg_list[(size_t)(seg0 + ls) * kSeg + k];
-      grec[i].vis_pos = b + k;
-      vis_list[b + k] = i;
-    }
     return;
   }
   // the later of blocks 0 and 1 folds the two pair counts: what a caller sizes the workspace by is the larger of the pairs
@@ -213,7 +211,7 @@ void launch_binning(const ViewTab& tab, int nviews, const LOff& L, hipStream_t s
   const int k3 = (L.N > 0 && (L.mean_hint == 0 || L.mean_hint > kBucket)) ? 1 : 0;
   {
     ProfScope prof(PK_SCAN, st);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(3 + (L.nseg + 63) / 64, nviews), dim3(1024), 0, st, tab, L, k3);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(3, nviews), dim3(1024), 0, st, tab, L, k3);
   }
   if (k3) {
     ProfScope prof(PK_SCATTER, st);

@@ -488,6 +488,41 @@ __device__ __forceinline__ float sign_code(uint32_t c, float k) { return (c & 1u
 // final transmittance, last contributor, the L1 loss gradient (sign x per-view constant) -- is still in this lane's
 // registers and the tile's sorted splats are still staged in LDS, so the wave goes straight on with tile_backward():
 // no final_T / n_contrib / code-byte / index-list round trip through HBM, no second launch, one tile prologue.
+// The compact visible list of a view (what the dense backward iterates) rides in the tile kernel's launch: `kCompSegs` segments
+// per 256-thread block, 16 lanes per segment copy that segment's list (K1) to its place -- segment base = the visible counts of
+// the segments in front, which the block adds up itself (<= a few thousand values).  It used to be a set of blocks of K2, on the
+// critical path between K1 and the tile kernels (K2 17.6 -> 13.6 us without them); nothing before the backward reads the list.
+constexpr int kCompSegs = 16;
+__device__ __forceinline__ int comp_blocks(const LOff& L) { return (((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7; }   // (x8: XCD mapping)
+__device__ __forceinline__ void compact_visible_list(char* saved, const LOff& L, int j, uint32_t* lds /* >= 4 + kCompSegs words */) {
+  const uint32_t* __restrict__ bv = (const uint32_t*)(saved + L.o_block_vis);
+  const int seg0 = j * kCompSegs;
+  if (seg0 >= L.nseg) return;
+  uint32_t before = 0;
+  for (int i = threadIdx.x; i < seg0; i += 256) before += bv[i];
+  before = wave_scan_add_u32(before);
+  if ((threadIdx.x & 63) == 63) lds[threadIdx.x >> 6] = before;
+  const int ls = threadIdx.x >> 4, sub = threadIdx.x & 15;
+  const uint32_t c = seg0 + ls < L.nseg ? bv[seg0 + ls] : 0u;
+  __syncthreads();
+  if (threadIdx.x < 64) {                       // exclusive scan of the block's counts by one wave
+    const uint32_t pre = lds[0] + lds[1] + lds[2] + lds[3];
+    const uint32_t mine = ((int)threadIdx.x < kCompSegs && seg0 + (int)threadIdx.x < L.nseg) ? bv[seg0 + threadIdx.x] : 0u;
+    const uint32_t ex = pre + wave_scan_add_u32(mine) - mine;
+    if ((int)threadIdx.x < kCompSegs) lds[4 + threadIdx.x] = ex;
+  }
+  __syncthreads();
+  const uint32_t* __restrict__ seg_list = (const uint32_t*)(saved + L.o_seg_list);
+  uint32_t* __restrict__ vis_list = (uint32_t*)(saved + L.o_vis_list);
+  GRec* __restrict__ grec = (GRec*)(saved + L.o_grec);
+  const uint32_t b = lds[4 + ls];
+  for (uint32_t k = sub; k < c; k += 16) {
+    const uint32_t i = seg_list[(size_t)(seg0 + ls) * kSeg + k];
+    grec[i].vis_pos = b + k;
+    vis_list[b + k] = i;
+  }
+}
+
 template <int SORT_MAX, bool FUSED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TILE_WAVES))) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
                                                         LossCoef lc) {
@@ -510,7 +545,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
   constexpr size_t kKeyBytes = REGSORT ? 4 : 8;
   constexpr size_t kSlice = (size_t)SORT_MAX * kKeyBytes + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0);
   const int nblocks = sgx * sgy;
-  const int st = super_tile_of_block(blockIdx.x, nblocks);
+  const int ncomp = comp_blocks(L);             // the first blocks of the launch: the view's compact visible list (see above)
+  if ((int)blockIdx.x < ncomp) { compact_visible_list(saved, L, (int)blockIdx.x, (uint32_t*)smem); return; }
+  const int st = super_tile_of_block((int)blockIdx.x - ncomp, nblocks);
   if (st >= nblocks) return;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave-uniform: tile state in SGPRs
   constexpr int kLdsSortMax = SORT_MAX;
@@ -856,7 +893,7 @@ template <int SORT_MAX, bool FUSED>
 static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab& lt,
                                const LossCoef& lc, hipStream_t st) {
   int nblocks = L.sgx * L.sgy;
-  int grid = ((nblocks + 7) / 8) * 8;
+  int grid = ((nblocks + 7) / 8) * 8 + ((((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7);
   constexpr size_t lds = 4 * ((size_t)SORT_MAX * (sort_in_registers(SORT_MAX) ? 4 : 8) + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0));
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
