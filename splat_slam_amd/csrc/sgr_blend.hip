@@ -414,23 +414,63 @@ __device__ __forceinline__ void bwd_chunk2(
   float t_gx = s_gx.x + s_gx.y, t_gy = s_gy.x + s_gy.y, t_gxx = s_gxx.x + s_gxx.y, t_gxy = s_gxy.x + s_gxy.y,
         t_gyy = s_gyy.x + s_gyy.y, t_o = a_o.x + a_o.y, t_r = a_r.x + a_r.y, t_g = a_g.x + a_g.y, t_b = a_b.x + a_b.y,
         t_d = a_d.x + a_d.y;
-  if (GW < kWave) {
-    // the PP groups saw disjoint pixels: add them up (fixed order), result valid in every group
-#pragma unroll
-    for (int off = GW; off < kWave; off <<= 1) {
-      t_gx += __shfl_xor(t_gx, off); t_gy += __shfl_xor(t_gy, off); t_gxx += __shfl_xor(t_gxx, off);
-      t_gxy += __shfl_xor(t_gxy, off); t_gyy += __shfl_xor(t_gyy, off); t_o += __shfl_xor(t_o, off);
-      t_r += __shfl_xor(t_r, off); t_g += __shfl_xor(t_g, off); t_b += __shfl_xor(t_b, off); t_d += __shfl_xor(t_d, off);
+  // The slot of this (tile, Gaussian) pair, 12 floats: gx gy gxx gxy | o r g b | gyy d - -  (RAW sums: the conic / half-image
+  // factors that turn them into dL/dmean2D and dL/dconic are per Gaussian, the dense backward applies them once to the sum over
+  // the Gaussian's tiles; the last 8 bytes are padding, never written or read).
+  float* __restrict__ out = (float*)partials + (size_t)slot * 12;
+  if (GW == kWave) {
+    if (slot != 0xffffffffu) {
+      *(float4*)(out + 0) = make_float4(t_gx, t_gy, t_gxx, t_gxy);
+      *(float4*)(out + 4) = make_float4(t_o, t_r, t_g, t_b);
+      *(float2*)(out + 8) = make_float2(t_gyy, t_d);
     }
+    return;
   }
-  if (sub == 0 && slot != 0xffffffffu) {
-    {
-      float dmx = (-(A * t_gx) - B * t_gy) * halfW;
-      float dmy = (-(Cc * t_gy) - B * t_gx) * halfH;
-      partials[(size_t)slot * 3 + 0] = make_float4(dmx, dmy, -0.5f * t_gxx, -t_gxy);
-      partials[(size_t)slot * 3 + 1] = make_float4(-0.5f * t_gyy, t_o, t_r, t_g);
-      *(float2*)&partials[(size_t)slot * 3 + 2] = make_float2(t_b, t_d);      // (the slot's last 8 bytes are padding: never read)
+  // GW < 64: the 64 / GW groups saw disjoint pixels and their ten sums must meet.  As a butterfly of ds_bpermute shuffles that
+  // was 10 x log2(64 / GW) shuffles + adds (88 instructions for a 4-lane chunk: more than its two loop iterations).  Here the
+  // values are paired and the HALVES of the wave trade places (v_permlane32_swap: a.hi <-> b.lo), so one swap + one add folds
+  // TWO values over the half-wave distance, each total landing in the half that keeps it; v_permlane16_swap does the same over
+  // the row distance (a.row1 <-> b.row0, a.row3 <-> b.row2), and the distances inside a 16-lane row are DPP row rotations
+  // folded into the add.  5 + 3 registers instead of 10 per level, and every row ends up owning the two or three floats it
+  // stores: row 0 (gx gy; gyy), row 1 (gxx gxy), row 2 (o r; d), row 3 (g b).  Fixed order: bitwise reproducible.
+  asm volatile("s_nop 1\n\t"
+               "v_permlane32_swap_b32 %0, %5\n\tv_permlane32_swap_b32 %1, %6\n\tv_permlane32_swap_b32 %2, %7\n\t"
+               "v_permlane32_swap_b32 %3, %8\n\tv_permlane32_swap_b32 %4, %9\n\ts_nop 1\n\t"
+               "v_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %7\n\tv_add_f32 %3, %3, %8\n\tv_add_f32 %4, %4, %9\n\t"
+               "s_nop 1"
+               : "+v"(t_gx), "+v"(t_gxx), "+v"(t_gy), "+v"(t_gxy), "+v"(t_gyy), "+v"(t_o), "+v"(t_g), "+v"(t_r), "+v"(t_b), "+v"(t_d));
+  // lower half: t_gx t_gxx t_gy t_gxy t_gyy are complete (for GW = 32); upper half: the same registers hold o g r b d
+  if (GW == 32) {
+    if (slot != 0xffffffffu) {
+      const int up = lane >= 32 ? 1 : 0;
+      float* o2 = out + 4 * up;
+      *(float2*)(o2 + 0) = make_float2(t_gx, t_gy);       // upper half: o r
+      *(float2*)(o2 + 2) = make_float2(t_gxx, t_gxy);     //             g b
+      out[8 + up] = t_gyy;                                //             d
     }
+    return;
+  }
+  float u01 = t_gx, u23 = t_gy, u4 = t_gyy, w1 = t_gxx, w3 = t_gxy, w4 = 0.f;
+  asm volatile("s_nop 1\n\t"
+               "v_permlane16_swap_b32 %0, %3\n\tv_permlane16_swap_b32 %1, %4\n\tv_mov_b32 %5, %2\n\ts_nop 1\n\t"
+               "v_permlane16_swap_b32 %2, %5\n\ts_nop 1\n\t"
+               "v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %5\n\ts_nop 1"
+               : "+v"(u01), "+v"(u23), "+v"(u4), "+v"(w1), "+v"(w3), "+v"(w4));
+  // rows: u01 = gx | gxx | o | g,  u23 = gy | gxy | r | b,  u4 = gyy | gyy | d | d   (complete for GW = 16)
+  if (GW <= 8)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(u01), "+v"(u23), "+v"(u4));
+  if (GW <= 4)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(u01), "+v"(u23), "+v"(u4));
+  if ((lane & 15) < GW && slot != 0xffffffffu) {       // the first group of every row stores that row's floats
+    const int row = lane >> 4;
+    *(float2*)(out + 2 * row) = make_float2(u01, u23);
+    if (!(row & 1)) out[8 + (row >> 1)] = u4;            // row 0: gyy, row 2: d
   }
 }
 

@@ -732,9 +732,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-// Per-entry partials written by blend_bwd (12 floats = 48 B per (tile, Gaussian) pair):
-//   0,1 : dL/d(mean2D) in NDC-scaled pixel units   2,3,4 : dL/dA, dL/dB, dL/dC (true partials of the conic)
-//   5   : dL/dopacity   6,7,8 : dL/drgb   9 : dL/ddepth   10,11 : unused
+// Per-entry partials written by blend_bwd (12 floats = 48 B per (tile, Gaussian) pair), RAW sums over the tile's pixels:
+//   0,1 : sum G dL/dG (dx, dy)   2,3 : the same times (dx dx, dx dy)   4 : dL/dopacity   5,6,7 : dL/drgb
+//   8 : sum G dL/dG dy dy   9 : dL/ddepth   10,11 : unused
+// (the dense backward below turns the per-Gaussian totals of 0..4 into dL/dmean2D and dL/dconic)
 struct GaussGrad {
   float p[3], s[3], q[4], S6[6], op, m2[2], rgb_or_sh0[3];
 };
@@ -1109,6 +1110,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     }
   }
   if (!have) return;
+  {
+    // the slots hold RAW sums (sgr_blend.hip: gx gy gxx gxy | o r g b | gyy d - -); this Gaussian's conic (A, B, C) and the
+    // half-image factors turn their totals into dL/dmean2D (NDC-scaled pixel units) and the true partials of the conic
+    // (summed in slot order -- gsum[0..9] = gx gy gxx gxy o r g b gyy d -- and put into the order the projection backward takes)
+    const float G0 = gsum[0], G1 = gsum[1], Gxx = gsum[2], Gxy = gsum[3], Go = gsum[4], Gr = gsum[5], Gg = gsum[6], Gb = gsum[7],
+                Gyy = gsum[8], Gd = gsum[9];
+    gsum[0] = (-(g1.x * G0) - g1.y * G1) * (0.5f * (float)L.W);
+    gsum[1] = (-(g1.z * G1) - g1.y * G0) * (0.5f * (float)L.H);
+    gsum[2] = -0.5f * Gxx;
+    gsum[3] = -Gxy;
+    gsum[4] = -0.5f * Gyy;
+    gsum[5] = Go; gsum[6] = Gr; gsum[7] = Gg; gsum[8] = Gb; gsum[9] = Gd;
+  }
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   GaussGrad acc;
 #pragma unroll
