@@ -1233,12 +1233,20 @@ class FusedMappingLoop(MappingLoop):
             if n > 0:
                 self._ensure_state()
                 c0 = self.iteration_count
-                picks, per = [], min(2, len(random_viewpoint_stack))
-                for _ in range(n):               # the reference's draws, in its order (mapper.py:470)
-                    picks += torch.randperm(len(random_viewpoint_stack))[:2].tolist()
-                lrs = [float(self._xyz_group()["lr"])] + [self.gaussians.lr_at(c0 + k) for k in range(1, n)]
-                (self._run_span_ranks if self._parallel() else self._run_span)(viewpoint_stack, random_viewpoint_stack, picks,
-                                                                               lrs, 10.0, "window")
+                per = min(2, len(random_viewpoint_stack))
+                run = self._run_span_ranks if self._parallel() else self._run_span
+                # The draws and learning rates of an iteration cost the host ~15 us (torch.randperm, the lr schedule): for a
+                # keyframe's 60 iterations that is ~1 ms before anything is enqueued -- with the GPU idle, because a span starts
+                # behind a read-back.  The first few iterations therefore go out as a span of their own and the rest is drawn
+                # while they run (two spans = one span, iteration by iteration: bitwise, tests/test_gpu_fused.py).
+                picks, k0 = [], 0
+                for k1 in ((min(n, 4), n) if (n > 8 and not self._parallel()) else (n,)):
+                    part = []
+                    for _ in range(k0, k1):          # the reference's draws, in its order (mapper.py:470)
+                        part += torch.randperm(len(random_viewpoint_stack))[:2].tolist()
+                    lrs = [float(self._xyz_group()["lr"]) if k == 0 else self.gaussians.lr_at(c0 + k) for k in range(k0, k1)]
+                    run(viewpoint_stack, random_viewpoint_stack, part, lrs, 10.0, "window")
+                    picks, k0 = part, k1
                 self.iteration_count = c0 + n
                 self.gaussians.update_learning_rate(self.iteration_count)
                 self.last_used = list(viewpoint_stack) + [random_viewpoint_stack[k] for k in picks[len(picks) - per:]]
