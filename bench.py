@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--profile-all", action="store_true", help="event-time every kernel kind inside the timed region (adds overhead)")
     ap.add_argument("--refine-views", default="world", help="views per optimiser step of the timed final_refine leg on N > 1 GPUs: "
                     "'world' (one random view per rank and step: configs[4]) or 1 (the reference's step, replicated)")
+    ap.add_argument("--settle", type=int, default=150, help="untimed iterations right after the scene is built, BEFORE the --warmup steps: "
+                    "workspace capacities, list hints, allocator pools and the GPU's clocks reach the state a session is in from its "
+                    "second keyframe on (a 20-step timed region that starts 5 steps after an idle GPU reads 8 %% slower)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing protocol only, no GPU work (CPU test of --gpus N)")
     return ap.parse_args()
 
@@ -354,6 +357,8 @@ def main():
     world, rank, dev, intr, lib = B.world, B.rank, B.dev, B.intr, B.lib
     N = args.gaussians
     loop, cams = B.build(args.loop, args.scale_add)
+    if args.settle:
+        B.run_steps(loop, args.settle)
     trace("setup done")
     if args.warmup:
         B.run_steps(loop, args.warmup)
@@ -391,7 +396,7 @@ def main():
                    "parallelism": "single GPU" if world == 1 else
                    ("view-parallel x%d, %s" % (world, "RCCL reduce-scatter + Adam on 1/%d of the Gaussians + all-gather (ZeRO-1)" % world
                                                  if args.sync == "zero1" else "one RCCL all-reduce of the flat gradient buffer"))},
-        "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4),
+        "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4), "settle_iterations_untimed": args.settle,
         "map_iterations_per_s": round(args.steps / elapsed, 2),
         "world_size_seen": (B.dist.get_world_size() if B.dist is not None else 1), "transport": B.transport,
     }
