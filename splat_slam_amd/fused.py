@@ -1324,7 +1324,12 @@ class FusedMappingLoop(MappingLoop):
         """occ_aware_visibility of mapper.py:494-498 from the last render of every window keyframe; with split views each
         keyframe was rendered by one rank: the masks are combined (max) so that every rank sees all of them."""
         if not (self._parallel() and self.split_views):
-            return {kf: (self._views[c.uid].n_touched > 0).long() for kf, c in zip(current_window, viewpoint_stack)}
+            # (one stack + one compare + one cast for the whole window instead of two launches per keyframe: the dict is rebuilt at
+            # the end of every map() call; its values are rows of one [window, N] tensor)
+            if not viewpoint_stack:
+                return {}
+            m = (torch.stack([self._views[c.uid].n_touched for c in viewpoint_stack]) > 0).long()
+            return {kf: m[i] for i, kf in enumerate(current_window)}
         import torch.distributed as dist
         n = self.gaussians._xyz.shape[0]
         m = torch.zeros((len(viewpoint_stack), n), dtype=torch.int32, device=self.device)
