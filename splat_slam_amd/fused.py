@@ -1237,10 +1237,11 @@ class FusedMappingLoop(MappingLoop):
                 run = self._run_span_ranks if self._parallel() else self._run_span
                 # The draws and learning rates of an iteration cost the host ~15 us (torch.randperm, the lr schedule): for a
                 # keyframe's 60 iterations that is ~1 ms before anything is enqueued -- with the GPU idle, because a span starts
-                # behind a read-back.  The first few iterations therefore go out as a span of their own and the rest is drawn
-                # while they run (two spans = one span, iteration by iteration: bitwise, tests/test_gpu_fused.py).
+                # behind a read-back.  The first 2 iterations therefore go out as a span of their own, the next 6 are drawn while
+                # those run, the rest while these run (several spans = one span, iteration by iteration: bitwise,
+                # tests/test_gpu_fused.py).
                 picks, k0 = [], 0
-                for k1 in ((min(n, 4), n) if (n > 8 and not self._parallel()) else (n,)):
+                for k1 in ((2, 8, n) if (n > 12 and not self._parallel()) else (n,)):
                     part = []
                     for _ in range(k0, k1):          # the reference's draws, in its order (mapper.py:470)
                         part += torch.randperm(len(random_viewpoint_stack))[:2].tolist()
