@@ -140,9 +140,12 @@ class MappingLoop:
         """mapper.py:503-508: with a full window the prune pass leaves in `n_obs` how many window keyframes see each Gaussian
         (the mask it then derives from it is dropped, the counts stay in the model)."""
         if len(current_window) == self.window_size:
-            self.gaussians.n_obs.fill_(0)
-            for vis in self.occ_aware_visibility.values():
-                self.gaussians.n_obs += vis.to(self.gaussians.n_obs.device, self.gaussians.n_obs.dtype)
+            n_obs = self.gaussians.n_obs                 # (one stack + sum + cast instead of two launches per window keyframe)
+            vis = [v.to(n_obs.device) for v in self.occ_aware_visibility.values()]
+            if vis:
+                n_obs.copy_(torch.stack(vis).sum(dim=0).to(n_obs.dtype))
+            else:
+                n_obs.fill_(0)
 
     # ---------------------------------------------------------------------------------- mapper.py:400-568
     def map(self, current_window, prune=False, iters=1):
