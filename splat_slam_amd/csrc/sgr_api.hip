@@ -165,7 +165,7 @@ static void tab_set_view(ViewTab& t, int v, const SgrSettings* s, const SgrOutpu
 static int forward_batch(const ViewTab& tab, int nviews, const Layout& L, const Common& cm, const SgrInputs& in, hipStream_t st,
                          bool counters_clean = false, int max_list_hint = 0) {
   LOff d = L.dev();
-  d.mean_hint = max_list_hint;
+  d.set_hint(max_list_hint);
   // header + per-tile pair counters; tile_scan re-zeroes the counters after reading them, so only blocks that never
   // went through a forward (or the caller does not vouch for) need this launch
   if (!counters_clean) launch_zero_heads(tab, nviews, d, L.zero_bytes, st);
@@ -211,7 +211,7 @@ int sgr_forward(const SgrSettings* s, const SgrInputs* in, const SgrOutputs* out
     if ((int64_t)R > L.cap) return set_error(SGR_ERR_CAPACITY, "%u (tile, Gaussian) pairs exceed capacity %lld", R, (long long)L.cap);
   }
   LOff d1 = L.dev();
-  d1.mean_hint = ws->max_list_hint;
+  d1.set_hint(ws->max_list_hint);
   launch_blend_fwd(tab, 1, d1, s->bg, nullptr, nullptr, st);          // K4: per-tile sort + compositing
   HIP_TRY(hipGetLastError());
   return SGR_OK;
@@ -391,8 +391,9 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
   }
   Layout L = make_layout(f.settings.num_gaussians, f.settings.image_height, f.settings.image_width, f.ws.capacity);
   LOff d = L.dev();
-  d.mean_hint = 0;
-  for (int v = 0; v < num_views; ++v) d.mean_hint = views[v].ws.max_list_hint > d.mean_hint ? views[v].ws.max_list_hint : d.mean_hint;
+  int hint = 0;
+  for (int v = 0; v < num_views; ++v) hint = views[v].ws.max_list_hint > hint ? views[v].ws.max_list_hint : hint;
+  d.set_hint(hint);
   Common cm = make_common(&f.settings);
   const int HW = f.settings.image_height * f.settings.image_width;
   for (int base = 0; base < num_views; base += kMaxViews) {

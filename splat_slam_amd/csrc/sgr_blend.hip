@@ -329,7 +329,7 @@ struct SrcStaged {
 template <int GW, typename SRC>
 __device__ __forceinline__ void bwd_chunk2(
     int lane, int start, int end, bool carry, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
-    const LOff& L, float halfW, float halfH, float4* __restrict__ partials) {
+    const LOff& L, float4* __restrict__ partials) {
   constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
   // (opaque to the optimiser: the five instantiations sit in one loop, and hoisting each one's lane arithmetic out of it
   //  cost more live registers than the kernel has at 5 waves per SIMD -- they were spilled to scratch: +37 MB of writes per launch)
@@ -494,7 +494,6 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
   }
   // wave-uniform floats are pinned to SGPRs (the compiler keeps converted integers in VGPRs: at 96 registers every one counts)
   auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-  const float halfW = uniform(0.5f * (float)L.W), halfH = uniform(0.5f * (float)L.H);
   const float tx0 = uniform((float)(tx * kTile)), ty0 = uniform((float)(ty * kTile));
   // The list is cut into chunks of 64 / 32 / 16 / 8 / 4 splats from the far end: a lane = a splat, and a chunk of width GW works
   // on 64 / GW pixel pairs at once, so a chunk costs 32 * GW / 64 iterations of the loop above whatever part of its lanes is
@@ -506,11 +505,11 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
     const int gw = end >= 48 ? 64 : (end >= 24 ? 32 : (end >= 12 ? 16 : (end >= 5 ? 8 : 4)));
     const int start = gw >= end ? 0 : end - gw;
     const bool carry = start > 0;
-    if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
-    else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
-    else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
-    else if (gw == 8) bwd_chunk2<8>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
-    else bwd_chunk2<4>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, halfW, halfH, partials);
+    if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
+    else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
+    else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
+    else if (gw == 8) bwd_chunk2<8>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
+    else bwd_chunk2<4>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
     end = start;
     if (carry) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

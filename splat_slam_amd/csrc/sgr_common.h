@@ -32,7 +32,12 @@ __host__ __device__ inline int tile_counter_shift(int x, int y) { return 16 * ((
 // map has enough segments to fill the chip; a young SLAM map (60 k Gaussians = 235 segments, 40 % of them visible, splats of
 // hundreds of bins) would otherwise run its whole forward binning on a quarter of the CUs.
 constexpr int kK1MaxParts = 4;
-__host__ __device__ inline int k1_parts_for(int nseg) { return nseg >= 768 ? 1 : (nseg >= 384 ? 2 : kK1MaxParts); }
+// A DENSE map (the caller measured lists beyond a bucket) takes two parts even when it has segments enough: the second round of
+// blocks overlaps its loads and projections with the first round's counting atomics, which is where such a map's K1 waits
+// (opaque bench scene 0.21 -> 0.185 ms; a fresh map loses 8 us to the doubled cull and keeps one part).
+__host__ __device__ inline int k1_parts_for(int nseg, int longest_list_hint = 0) {
+  return nseg >= 768 ? (longest_list_hint > 64 ? 2 : 1) : (nseg >= 384 ? 2 : kK1MaxParts);
+}
 constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
 // Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the
 // key goes straight into the tile's fixed bucket -- no second pass.  Only tiles with more than kBucket pairs are re-scattered
@@ -139,6 +144,8 @@ struct ViewTab {
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {
   int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg, mean_hint, k1_parts;
+  // the caller's measured longest list (0: unknown): everything derived from it changes with it, in ONE place
+  __host__ void set_hint(int h) { mean_hint = h; k1_parts = k1_parts_for(nseg, h); }
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
       o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
