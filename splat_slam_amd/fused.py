@@ -785,7 +785,6 @@ class FusedMappingLoop(MappingLoop):
         n_it = len(lrs)
         if self._parallel() or n_it == 0:
             raise RuntimeError("_run_span is the single-GPU fast path")
-        pl = self._plan()
         self._settle_capacity(list(window_cams) + list(pool_cams))               # estimates for new cameras, ONE capacity
         per0 = len(picks) // n_it if picks else 0
         if n_it > 1 and not verified and any(self._views[c.uid].estimated for c in
