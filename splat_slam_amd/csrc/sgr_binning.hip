@@ -37,8 +37,8 @@ __device__ uint32_t block1024_scan(LOAD in, uint32_t* __restrict__ out, int n, u
   return carry;
 }
 
-// the exactly sized runs of over-full tiles: the overflow list (tile, rank, key) is filed at start(tile) + rank, and the first
-// kBucket keys of every over-full tile are copied over from its bucket.  `first` / `stride`: this caller's share of the work.
+// the exactly sized runs of over-full tiles: the overflow list (tile, rank, key) is filed at start(tile) + rank; the first kBucket
+// keys of such a tile stay in its bucket (the tile kernels read both places).  `first` / `stride`: this caller's share of the work.
 __device__ __forceinline__ void file_overfull_runs(char* saved, char* scratch, const LOff& L, size_t novf, size_t first, size_t stride) {
   const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
   uint64_t* __restrict__ entries = (uint64_t*)(scratch + L.o_entries);
@@ -47,14 +47,6 @@ __device__ __forceinline__ void file_overfull_runs(char* saved, char* scratch, c
     const OvfEntry o = ovf[e];
     const uint64_t pos = (uint64_t)(ranges[(size_t)o.tile * kRngStride].x & ~kOverfull) + o.rank;
     if ((int64_t)pos < L.cap) entries[pos] = o.key;
-  }
-  const uint64_t* __restrict__ bucket = (const uint64_t*)(scratch + L.o_bucket);
-  const size_t nslots = (size_t)L.ntiles * kBucket;
-  for (size_t e = first; e < nslots; e += stride) {
-    const uint32_t x = ranges[(e / kBucket) * kRngStride].x;
-    if (!(x & kOverfull)) continue;
-    const uint64_t pos = (uint64_t)(x & ~kOverfull) + (e % kBucket);
-    if ((int64_t)pos < L.cap) entries[pos] = bucket[e];
   }
 }
 

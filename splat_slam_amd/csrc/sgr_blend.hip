@@ -122,13 +122,16 @@ struct SortMerge {
   }
 };
 // sorts keys_in[0..count) (count <= 64 * KPL) and leaves the sorted Gaussian indices (low words) in ids[0..64 * KPL)
+// (the keys of an over-full tile live in two places: ranks 0..kBucket-1 in the tile's bucket, where K1 binned them, the rest in the
+//  tile's exactly sized run, where K3 filed the overflow list -- `run` is addressed by rank as well; nobody copies the bucket part over)
 template <int KPL>
-__device__ __forceinline__ void wave_sort_registers(const uint64_t* __restrict__ keys_in, int count, int lane, uint32_t* ids /*LDS*/) {
+__device__ __forceinline__ void wave_sort_registers(const uint64_t* __restrict__ bucket, const uint64_t* __restrict__ run, int count, int lane,
+                                                    uint32_t* ids /*LDS*/) {
   uint64_t k[KPL];
 #pragma unroll
   for (int r = 0; r < KPL; ++r) {
     const int e = lane * KPL + r;
-    k[r] = e < count ? keys_in[e] : ~0ull;
+    k[r] = e < count ? (e < kBucket ? bucket[e] : run[e]) : ~0ull;
   }
   SortMerge<KPL, 2>::run(k, lane);
 #pragma unroll
@@ -632,8 +635,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
     // One chunk.  Every lane keeps ITS (unsorted) key and finds the key's position in the sorted list by counting
     // smaller keys (keys are unique; broadcast through SGPRs: count short steps and no LDS round trips instead of a
     // 21-step shuffle network), fetches the key's record and files it under that position.
-    if (count > 32 && lane >= 32 && lane < count) key_spec = keys_in[lane];
-    const uint64_t key = overfull ? (lane < count ? keys_in[lane] : ~0ull) : (lane < count ? key_spec : ~0ull);
+    if (count > 32 && lane >= 32 && lane < count) key_spec = bucket[lane];
+    const uint64_t key = lane < count ? key_spec : ~0ull;       // (ranks below kBucket are in the bucket whatever the tile's final count)
     const uint32_t g = (uint32_t)key;
     const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
     uint32_t rank = 0;
@@ -662,16 +665,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
     }
   } else if (REGSORT && count <= kLdsSortMax) {
     mode = 1;                                 // 65..512 keys: sorted in registers, 2 / 4 / 8 per lane (count > 64: keys_in = the tile's run)
-    if (count <= 2 * kWave) wave_sort_registers<2>(keys_in, count, lane, ids);
-    else if (count <= 4 * kWave) wave_sort_registers<4>(keys_in, count, lane, ids);
-    else wave_sort_registers<8>(keys_in, count, lane, ids);
+    if (count <= 2 * kWave) wave_sort_registers<2>(bucket, entries + begin, count, lane, ids);
+    else if (count <= 4 * kWave) wave_sort_registers<4>(bucket, entries + begin, count, lane, ids);
+    else wave_sort_registers<8>(bucket, entries + begin, count, lane, ids);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (!FUSED)
       for (int i = lane; i < count; i += kWave) point_list[begin + i] = ids[i];
   } else if (count <= kLdsSortMax) {
     mode = 1;
-    for (int i = lane; i < count; i += kWave) keys[i] = keys_in[i];
+    for (int i = lane; i < count; i += kWave) keys[i] = i < kBucket ? bucket[i] : keys_in[i];      // (count > 64: keys_in = the tile's run)
     __builtin_amdgcn_wave_barrier();
     wave_sort_any(count, lane, [&](int i) { return keys[i]; }, [&](int i, uint64_t v) { keys[i] = v; },
                   [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); });
@@ -680,6 +683,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
   } else {
     mode = 2;                                 // slow path: in place in HBM through device-coherent accesses
     uint64_t* e = entries + begin;
+    if (lane < kBucket) __hip_atomic_store(e + lane, bucket[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the bucket part joins its run)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __builtin_amdgcn_wave_barrier();
     wave_sort_any(count, lane,
                   [&](int i) { return __hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
                   [&](int i, uint64_t v) { __hip_atomic_store(e + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
