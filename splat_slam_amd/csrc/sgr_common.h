@@ -34,9 +34,11 @@ __host__ __device__ inline int tile_counter_shift(int x, int y) { return 16 * ((
 constexpr int kK1MaxParts = 4;
 // A DENSE map (the caller measured lists beyond a bucket) takes two parts even when it has segments enough: the second round of
 // blocks overlaps its loads and projections with the first round's counting atomics, which is where such a map's K1 waits
-// (opaque bench scene 0.21 -> 0.185 ms; a fresh map loses 8 us to the doubled cull and keeps one part).
+// (opaque bench scene 0.21 -> 0.185 ms; a fresh map loses 8 us to the doubled cull and keeps one part, and so does a map of
+// more than half a million Gaussians, where the cull itself is the larger half of K1: 1.5 M Gaussians, 0.913 ms per iteration
+// with one part, 0.997 with two).
 __host__ __device__ inline int k1_parts_for(int nseg, int longest_list_hint = 0) {
-  return nseg >= 768 ? (longest_list_hint > 64 ? 2 : 1) : (nseg >= 384 ? 2 : kK1MaxParts);
+  return nseg >= 768 ? ((longest_list_hint > 64 && nseg < 2048) ? 2 : 1) : (nseg >= 384 ? 2 : kK1MaxParts);
 }
 constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
 // Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the
