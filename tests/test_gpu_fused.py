@@ -521,6 +521,40 @@ def test_segment_view_test_is_conservative_bitwise_same_results():
         assert int((res[0]["radii"] > 0).sum()) > 1000
 
 
+def test_two_view_parts_per_segment_on_a_dense_map_give_the_same_bits_as_one():
+    """K1 deals the views of a DENSE map (measured lists beyond a bucket) to two blocks per 256-Gaussian segment even when the map
+    has segments enough for one (>= 768): the visibility words of the two parts are OR-ed by the optimiser pass, everything else is
+    per view -- images, radii, contribution counters, losses and the accumulated gradients must be bit-identical to the one-part run
+    (hint 0 = nothing measured: one part, same kernels otherwise)."""
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    intr = syn.INTRINSICS["replica"]
+    params = syn.room_parameters(200000, seed=11, device=DEV)          # 782 segments
+    params["scaling"] = params["scaling"] + 1.4
+    cams = syn.make_views(params, 5, intr, DEV, seed=11)
+    res = []
+    for hint in (0, 200):
+        f = _loop(FusedMappingLoop, syn, params, cams, range(5))
+        f._ensure_state()
+        f._activate()
+        f._run_views(cams, stats=True)                                  # sizes the workspaces (probe renders), measures nothing else
+        torch.cuda.synchronize()
+        f._list_hint = {c.uid: hint for c in cams} if hint else {}
+        f._views_dirty()
+        f._acc["flat"].zero_()
+        f._acc_clean = True
+        f._run_views(cams, stats=False)
+        torch.cuda.synchronize()
+        assert f._max_list() == hint
+        res.append(dict(flat=f._acc["flat"].clone(), radii=torch.stack([f._views[c.uid].radii for c in cams]).clone(),
+                        nt=torch.stack([f._views[c.uid].n_touched for c in cams]).clone(),
+                        loss=torch.cat([f._views[c.uid].loss for c in cams]).clone(),
+                        img=torch.stack([f._views[c.uid].color for c in cams]).clone()))
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert int((res[0]["radii"] > 0).sum()) > 5000 and float(res[0]["flat"].abs().max()) > 0
+
+
 def test_views_that_overflow_the_pair_capacity_take_no_part_in_the_step():
     """Capacity overflow between two host checks (the forwards run asynchronously): the truncated views must contribute zeros --
     not the partial slots nobody wrote -- so parameters and Adam moments stay finite and sane; the next check_overflow()
