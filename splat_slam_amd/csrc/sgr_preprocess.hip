@@ -961,7 +961,7 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
 // Phase 1 (dense): thread = entry of a view's compact visible list; grid = (ceil(N/256), views), blocks beyond the
 // list exit at once.  Writes one 64-byte gradient record per (view, visible Gaussian) and the view's pose partials.
 // With a single view the rarely used extras (SH degree > 0, precomputed colour / covariance) go straight to the outputs.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) preprocess_bwd_dense_kernel(
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) preprocess_bwd_dense_kernel(
     ViewTab tab, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, float* __restrict__ dshs, float* __restrict__ dcov3D, int accumulate) {
