@@ -307,8 +307,10 @@ class Bench:
         """The same map() iteration through the drop-in autograd API: splat_slam_amd.mapper.MappingLoop keeps the reference's
         loop structure (render() per view -> GaussianRasterizer, loss, backward, torch.optim.Adam)."""
         loop, cams = self.build("autograd", self.args.scale_add)
-        self.run_steps(loop, 3)
-        el, host = self.timed(loop, steps)
+        self.run_steps(loop, 6)
+        # host-bound: one-off stalls of the first iterations (lazy kernel loads, allocator growth: tens of ms once) would swamp a
+        # 6-iteration average -- the better of two timed blocks is the steady state
+        el, host = min(self.timed(loop, steps), self.timed(loop, steps))
         views = len(loop.current_window) + min(2, self.args.views - len(loop.current_window))
         ms_it = 1e3 * el / steps
         return {"dropin_keyframes_per_s": round((steps / el) / 61.0, 3), "ms_per_iteration": round(ms_it, 3),
