@@ -60,6 +60,7 @@ class _ViewBuffers:
         ntiles = ((H + 7) // 8) * ((W + 7) // 8)
         self.loss_scratch = torch.empty(max(1024, ntiles) * 16, dtype=torch.uint8, device=dev)   # one LossPart per 8x8 tile
         self._ibuf, self._icap = None, 0
+        self.gen = 0               # bumped whenever a buffer a cached SgrMapView points into is re-allocated (ints, saved, scratch)
         self.saved = None
         self.scratch = None
         self.clean = False         # the saved block went through a forward (its per-tile counters are zero)
@@ -74,6 +75,7 @@ class _ViewBuffers:
         if N > self._icap:
             self._icap = int(N * 1.3) + 4096
             self._ibuf = torch.empty(2 * self._icap, dtype=torch.int32, device=self.dev)
+            self.gen += 1
         self.radii, self.n_touched = self._ibuf[:N], self._ibuf[self._icap:self._icap + N]
         self.n = N
         self.pairs = -1            # (tile, Gaussian) pairs seen by the probe render; -1 = not probed at this map size
@@ -135,6 +137,7 @@ class _Slot:
         self.clean = self.ran = False
         self.capacity = 0
         self.mv = None
+        self.gen = 0
 
 
 class _ExposureSlab:
@@ -245,8 +248,10 @@ class FusedMappingLoop(MappingLoop):
         super().__init__(config, device=device, fused_loss=True, knn_fn=knn_fn)
         # `ssim_loss: True` (slam_utils.py:89-98, off by default) is not a per-pixel L1: the fused tile kernel's loss epilogue does
         # not apply, and the three loops run as the autograd MappingLoop (drop-in rasterizer + torch loss) instead
+        # `spherical_harmonics: True` (mapper.py:78,85: sh_degree 3, off and "not tested" upstream, splat_slam.yaml:59) gives the map a
+        # [N, 15, 3] f_rest group the fused optimiser pass has no rows for: same fallback (the rasterizer itself handles SH 0-3)
         from splat_slam_amd.losses import uses_ssim
-        self.autograd_fallback = uses_ssim(config["mapping"])
+        self.autograd_fallback = uses_ssim(config["mapping"]) or bool(config["mapping"]["Training"].get("spherical_harmonics", False))
         self.lib = nat.lib()
         self.check_every = check_every
         self.fuse_tail = True            # gather + Adam + next activations in one pass (single GPU, regular iterations)
@@ -371,7 +376,10 @@ class FusedMappingLoop(MappingLoop):
         for vb in self._views.values():
             vb.new_map(N)
         if gm.active_sh_degree != 0 or gm._features_rest.numel() != 0:
-            raise NotImplementedError("FusedMappingLoop supports the reference's default sh_degree 0 (mapper.py:85)")
+            # (only reachable with a model that was handed to the loop from outside, e.g. a PLY with SH coefficients:
+            #  `spherical_harmonics: True` in the config selects the autograd loop in __init__)
+            raise NotImplementedError("the fused iteration covers the reference's default sh_degree 0 (mapper.py:85); set "
+                                      "mapping.Training.spherical_harmonics: True to run this map through the autograd loop")
         for g in gm.optimizer.param_groups:          # make sure Adam state exists exactly like torch would create it
             p = g["params"][0]
             st = gm.optimizer.state.get(p)
@@ -518,15 +526,18 @@ class FusedMappingLoop(MappingLoop):
                     del self._ws_owners[k]
                     if old.saved is not None and old.saved.numel() >= sb and old.scratch.numel() >= tb and (vb.saved is None):
                         vb.saved, vb.scratch, vb.clean = old.saved, old.scratch, False     # (another (H, W) may have used it)
+                        vb.gen += 1
                     old.saved = old.scratch = None
                     old.clean = old.ran = False
                     old.mv = None
                     break
         if vb.saved is None or vb.saved.numel() < sb:
             vb.saved = torch.empty((int(sb * 1.3) + (1 << 20)) // 256 * 256, dtype=torch.uint8, device=self.device)
+            vb.gen += 1
             vb.clean = False       # per-tile counters of a fresh block are garbage: the library zeroes them once
         if vb.scratch is None or vb.scratch.numel() < tb:
             vb.scratch = torch.empty((int(tb * 1.3) + (1 << 20)) // 256 * 256, dtype=torch.uint8, device=self.device)
+            vb.gen += 1
         if not getattr(vb, "is_slot", False):
             self._ws_owners[me] = vb
 
@@ -643,14 +654,18 @@ class FusedMappingLoop(MappingLoop):
         N, H, W = gm._xyz.shape[0], int(cam.image_height), int(cam.image_width)
         if hit is not None and hit[0] == key:
             mv = hit[1]
-            if hit[2] != N:          # the map changed size: same buffers, same camera -- only what depends on N is re-filled
+            if hit[2] != N or hit[3] != vb.gen:
+                # the map changed size, or one of the camera's buffers was re-allocated meanwhile (an entry that is only compared by
+                # N would point at freed radii / workspace memory once N returns to an earlier value): same camera -- only what
+                # depends on N or on the buffers is re-filled
                 mv.settings.num_gaussians = N
                 mv.out.radii, mv.out.n_touched = vb.radii.data_ptr(), vb.n_touched.data_ptr()
                 if not slot:
                     mv.ws = self._workspace(vb, N, H, W, self._cap)
-                hit[2] = N
+                hit[2], hit[3] = N, vb.gen
             elif not slot and (vb.saved is None or id(vb) not in self._ws_owners):
                 mv.ws = self._workspace(vb, N, H, W, self._cap)         # (its blocks went to another camera meanwhile)
+                hit[3] = vb.gen
             elif not slot:
                 self._ws_owners.move_to_end(id(vb))
             return mv
@@ -668,7 +683,7 @@ class FusedMappingLoop(MappingLoop):
         mv.dL_dexposure = vb.d_exp.data_ptr() if row is None else self._exp.grad.data_ptr() + 8 * row
         mv.dL_dtau = vb.d_tau.data_ptr() if self.keyframe_optimizers is not None else None
         mv.loss_scratch, mv.loss_scratch_bytes = vb.loss_scratch.data_ptr(), vb.loss_scratch.numel()
-        vb.mv[(images, slot)] = [key, mv, N]
+        vb.mv[(images, slot)] = [key, mv, N, vb.gen]
         return mv
 
     def _settle_capacity(self, cams):

@@ -14,6 +14,8 @@ What differs, on purpose (MI355X-first, documented in DESIGN.md):
 """
 
 import numpy as np
+import weakref
+
 import torch
 from torch import nn
 
@@ -106,8 +108,9 @@ class GaussianModel:
         """Shared activation of one parameter set: every render between two parameter updates sees the same tensor (and one
         autograd node).  Consequence: ONE backward per set of renders, like the reference's iteration (mapper.py:426-490);
         `render A, render B, lossA.backward(), lossB.backward()` needs share_activations = False (or retain_graph).
-        Kernels that write parameters through raw pointers (fused Adam, sgr_deform_points) do not bump `_version`:
-        they call invalidate_activations()."""
+        FusedAdam bumps `_version` of every parameter it steps (like torch.optim.Adam's in-place ops); other kernels that write
+        parameters through raw pointers (the fused loops' sgr_map_step / sgr_map_run, sgr_deform_points) call
+        invalidate_activations()."""
         if not self.share_activations or not torch.is_grad_enabled():
             return fn(*params)
         vers = tuple(p._version for p in params)
@@ -117,9 +120,11 @@ class GaussianModel:
         out = fn(*params)
         if out.requires_grad:
             # a backward frees this node's graph: whatever is rendered afterwards needs a fresh one
-            def drop(grad, n=name, o=out):
+            # (the hook holds a weak reference: out -> hook -> closure -> out would leave every iteration's [N, .] activations
+            #  to the cyclic collector instead of the reference count)
+            def drop(grad, n=name, o=weakref.ref(out)):
                 h = self._act.get(n)
-                if h is not None and h[2] is o:
+                if h is not None and h[2] is o():
                     del self._act[n]
             out.register_hook(drop)
             self._act[name] = (params, vers, out)      # (the Parameters are held: identity, not id(), decides a hit)

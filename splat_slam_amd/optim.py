@@ -49,6 +49,9 @@ class FusedAdam(torch.optim.Adam):
                 n = p.numel()
                 if n == 0:
                     continue
+                # the kernels write through raw pointers: bump the version counter like torch.optim.Adam's in-place ops do, so that
+                # anything keyed on `_version` (GaussianModel's activation cache, autograd's saved-tensor checks) sees the update
+                torch.autograd.graph.increment_version(p)
                 if not grad.is_contiguous():
                     grad = grad.contiguous()
                 if stream is None:
