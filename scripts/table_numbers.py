@@ -41,8 +41,10 @@ for name, n, cam in CONFIGS:
     d = json.loads(out.strip().splitlines()[-1])
     row = {"config": name, "fwd_ms": d["render_ms"]["forward"], "fwd_bwd_loss_ms": d["render_ms"]["forward_backward_loss"],
            "map_it_per_s": d["map_iterations_per_s"], "kf_per_s": d["value"], "refine_it_per_s": d["refine_iterations_per_s"],
-           "hbm_frac_blend_bwd": d["roofline"]["frac"], "valu_frac_blend_bwd": d["roofline"]["valu_frac_at_60flop_per_pair"],
-           "blend_bwd_ms": d["roofline"]["avg_launch_ms"], "fused_tile_kernel_ms": d["roofline_fused"]["avg_launch_ms"],
+           "hbm_frac_blend_bwd": d["roofline_unfused_blend_bwd"]["frac"],
+           "valu_frac_blend_bwd": d["roofline_unfused_blend_bwd"]["valu_frac_at_60flop_per_pair"],
+           "blend_bwd_ms": d["roofline_unfused_blend_bwd"]["avg_launch_ms"], "fused_tile_kernel_ms": d["roofline"]["avg_launch_ms"],
+           "hbm_frac_fused_tile_kernel": d["roofline"]["frac"],
            "ms_per_step": d["ms_per_step"], "work_per_view": d["work_per_view"]}
     if "cpu_baseline" in d:
         row["cpu_oracle"] = d["cpu_baseline"]

@@ -34,12 +34,20 @@ def test_bench_line_has_the_contract_keys():
 
 
 def test_committed_profiles_agree_with_the_bench_line():
+    """`roofline` describes the dominant kernel of the timed loop (round 4 on: the fused tile kernel; earlier lines: blend_bwd); its
+    event-timed launch duration agrees with the committed rocprofv3 trace of the same command, its traffic with the PMC pass."""
     d = _latest_line()
     tag = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))[-1].split(os.sep)[-1].split("_")[0]
     k = json.load(open(os.path.join(ROOT, "profiles", tag + "_kernel_batched_avg.json")))["kernels"]
-    trace_us = k["sgr::blend_bwd_kernel<true>"]["avg_us"]
-    event_us = 1e3 * d["roofline"]["avg_launch_ms"]
-    assert abs(trace_us - event_us) / event_us < 0.10, (trace_us, event_us)      # rocprofv3 trace vs live HIP events
-    h = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm_bytes.json")))["kernels"]["sgr::blend_bwd_kernel<true>"]
-    assert d["roofline"]["traffic"] in (None, h["hbm_bytes_per_launch_corrected"]) or \
-        abs(d["roofline"]["traffic"] - h["hbm_bytes_per_launch_corrected"]) / h["hbm_bytes_per_launch_corrected"] < 0.05
+    hb = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm_bytes.json")))["kernels"]
+    legs = [(d["roofline"], "sgr::blend_fwd_kernel<512, true>" if "FUSED" in d["roofline"]["kernel"] else "sgr::blend_bwd_kernel<true>")]
+    if "roofline_unfused_blend_bwd" in d:
+        assert d["roofline"]["in_timed_region"] is True
+        legs.append((d["roofline_unfused_blend_bwd"], "sgr::blend_bwd_kernel<true>"))
+    for r, name in legs:
+        trace_us = k[name]["avg_us"]
+        event_us = 1e3 * r["avg_launch_ms"]
+        assert abs(trace_us - event_us) / event_us < 0.10, (name, trace_us, event_us)      # rocprofv3 trace vs live HIP events
+        h = hb[name]
+        assert r["traffic"] in (None, h["hbm_bytes_per_launch_corrected"]) or \
+            abs(r["traffic"] - h["hbm_bytes_per_launch_corrected"]) / h["hbm_bytes_per_launch_corrected"] < 0.05
