@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 8
+#define SGR_ABI_VERSION 9
 
 typedef enum SgrStatus {
   SGR_OK = 0,
@@ -379,7 +379,10 @@ typedef struct SgrMapStep {
                                   -2 (with adam_groups == NULL): no optimiser step, but the gather pass of the fused form
                                   ADDS the views' gradient sums to the sinks and carries the loss sums and the exposure
                                   step -- the first half of a multi-GPU iteration (an all-reduce of the sinks and an
-                                  optimiser-only step follow) */
+                                  optimiser-only step follow)
+                                  -3: like -2, but the pass STORES the sums (zeros for Gaussians no view of the batch sees)
+                                  into the sinks of all num_gaussians rows instead of adding: the sinks need not be zeroed
+                                  between two iterations (one 56 B x N memset per exchange less) */
 } SgrMapStep;
 int sgr_map_step(const SgrMapStep* step, void* stream);
 

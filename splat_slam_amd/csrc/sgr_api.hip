@@ -499,9 +499,9 @@ static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_cle
       }
     }
   }
-  // grads_clean == -2: no optimiser step in this call, but the gather pass of the fused form (with its riders: loss sums
-  // and the exposure step) adds the views' gradients to the sinks -- the first half of a multi-GPU iteration
-  if (p->grads_clean == -2 && !p->adam_groups && p->num_views > 0 && p->num_views <= kMaxViews && !p->forward_only && p->grads &&
+  // grads_clean == -2 / -3: no optimiser step in this call, but the gather pass of the fused form (with its riders: loss sums
+  // and the exposure step) adds the views' gradients to the sinks / stores them there -- the first half of a multi-GPU iteration
+  if ((p->grads_clean == -2 || p->grads_clean == -3) && !p->adam_groups && p->num_views > 0 && p->num_views <= kMaxViews && !p->forward_only && p->grads &&
       p->in && p->views) {
     const SgrGradInputs& g = *p->grads;
     try_fuse = g.accumulate && g.dL_dmeans3D && g.dL_dshs && g.dL_dopacities && g.dL_dscales && g.dL_drotations &&
@@ -511,7 +511,7 @@ static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_cle
       try_fuse = !p->views[v].dL_dtau && p->views[v].settings.sh_degree == 0 && p->views[v].settings.sh_coeffs == 1;
     if (try_fuse) {
       fa = FusedAdam{};
-      fa.gather_only = 1;
+      fa.gather_only = p->grads_clean == -3 ? 2 : 1;     // (-3: the sums are stored for every Gaussian, the sinks need no zeroing)
       fa.G.g[0].grad = g.dL_dmeans3D; fa.G.g[1].grad = g.dL_dshs; fa.G.g[2].grad = g.dL_dopacities;
       fa.G.g[3].grad = g.dL_dscales; fa.G.g[4].grad = g.dL_drotations;
       fa.stat_accum = g.stat_grad_accum;

@@ -345,7 +345,8 @@ __global__ void __launch_bounds__(256) gaussian_adam_kernel(int64_t n, AdamGroup
 // The single-GPU tail of a mapping iteration in one pass: thread = Gaussian; adds up its gradient records over the
 // views of the batch in view order (exactly grad_gather_kernel's sum), then the Adam step of all five groups, then the
 // activations the next iteration renders with.  MODE 3 (multi-GPU) stops after the sum: it is added to the gradient
-// buffers (what grad_gather_kernel does with accumulate = 1), the riders still do the loss sums + exposure step.
+// buffers (what grad_gather_kernel does with accumulate = 1), the riders still do the loss sums + exposure step; MODE 4
+// stores it instead (for every Gaussian), so that the flat buffer the ranks exchange is never zeroed in between.
 template <int MODE>
 __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nviews, LOff L, FusedAdam fa) {
   if ((int)blockIdx.x < fa.tail_views) {      // rider blocks (scheduled first): one per view
@@ -426,7 +427,15 @@ __global__ void __launch_bounds__(256) gather_adam_kernel(ViewTab tab, int nview
     g4[0] += a[10]; g4[1] += a[11]; g4[2] += a[12]; g4[3] += a[13];
     return;
   }
-  gaussian_adam_one<MODE == 3 ? 1 : MODE>(i, fa.G, fa.c, fa.iso_coef, a, fa.s_out, fa.r_out, fa.o_out);
+  if (MODE == 4) {          // ... STORED, for every Gaussian (zeros where no view sees it): nobody has to zero the buffer in between
+    st3(fa.G.g[0].grad + 3 * (size_t)i, F3{a[0], a[1], a[2]});
+    st3(fa.G.g[1].grad + 3 * (size_t)i, F3{a[3], a[4], a[5]});
+    fa.G.g[2].grad[i] = a[6];
+    st3(fa.G.g[3].grad + 3 * (size_t)i, F3{a[7], a[8], a[9]});
+    *(float4*)(fa.G.g[4].grad + 4 * (size_t)i) = make_float4(a[10], a[11], a[12], a[13]);
+    return;
+  }
+  gaussian_adam_one<MODE >= 3 ? 1 : MODE>(i, fa.G, fa.c, fa.iso_coef, a, fa.s_out, fa.r_out, fa.o_out);
 }
 
 // the Adam step of all five groups; with output pointers also the activations the next forward renders with (the
@@ -445,7 +454,9 @@ int gaussian_adam_step_act(int64_t n, const SgrAdamGroup groups[5], float beta1,
 void launch_gather_adam(const ViewTab& tab, int nviews, const LOff& L, const FusedAdam& fa, hipStream_t st) {
   if (L.N <= 0) return;
   const int grid = L.pre_blocks + fa.tail_views;
-  if (fa.gather_only)
+  if (fa.gather_only == 2)
+    hipLaunchKernelGGL(gather_adam_kernel<4>, dim3(grid), dim3(256), 0, st, tab, nviews, L, fa);
+  else if (fa.gather_only)
     hipLaunchKernelGGL(gather_adam_kernel<3>, dim3(grid), dim3(256), 0, st, tab, nviews, L, fa);
   else if (fa.grads_clean)
     hipLaunchKernelGGL(gather_adam_kernel<2>, dim3(grid), dim3(256), 0, st, tab, nviews, L, fa);

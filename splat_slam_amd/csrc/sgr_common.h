@@ -298,7 +298,7 @@ struct FusedAdam {
   AdamConst c;
   float iso_coef;
   int grads_clean;            // gradient sinks are all-zero on entry: neither read nor written
-  int gather_only;            // no optimiser step: the gathered sums are ADDED to the sinks (multi-GPU: all-reduce follows)
+  int gather_only;            // no optimiser step: the gathered sums are ADDED to (1) / STORED in (2) the sinks (multi-GPU: an exchange follows)
   float *s_out, *r_out, *o_out;
   float *stat_accum, *stat_denom, *stat_maxr;
   // optional riders of the same launch (one extra block): the fixed-order sum of the per-tile loss parts of every view

@@ -261,6 +261,7 @@ class FusedMappingLoop(MappingLoop):
         self._acc = None          # gradient accumulators wrt activated inputs + activated copies
         self._acc_key = None
         self._acc_clean = True
+        self._flat_dirty = False  # ZeRO-1 store-mode exchange: the flat sinks hold the last local sums, not zeros (see _exchange_and_adam)
         self._scratch = None
         self._since_check = 0
         # True: the PERIODIC capacity check of map() posts its header read-back and looks at it one check later (no host wait).
@@ -369,6 +370,7 @@ class FusedMappingLoop(MappingLoop):
         self._zero = None
         self._acc_key, self._acc_ids = key, ids
         self._acc_clean = True     # the gradient sinks are all-zero (every Adam step leaves them so)
+        self._flat_dirty = False
         self._stale_iso = 0.0      # (every tensor is new: nothing a prune pass left behind survives)
         # N changed: the per-camera buffers stay (see _ViewBuffers), cameras that left the map are dropped
         live = set(self.viewpoints)
@@ -421,7 +423,13 @@ class FusedMappingLoop(MappingLoop):
         self.comm.all_gather(zr["v"], zr["v"][lo:hi])
         zr["stale_moments"] = False
 
-    def _exchange_and_adam(self, pl, iso_weight, skip=()):
+    def _clean_flat(self):
+        """The sinks as every non-store-mode path expects them when `_acc_clean` says so: all-zero."""
+        if self._flat_dirty:
+            self._acc["flat"].zero_()
+            self._flat_dirty = False
+
+    def _exchange_and_adam(self, pl, iso_weight, skip=(), stored=False):
         """Second half of a multi-GPU iteration: the ranks' gradient sums meet, Adam steps, everybody ends with the same
         parameters and the activations of the next forward.  pl.groups carry lr / step of this iteration."""
         stream = self._stream()
@@ -442,7 +450,13 @@ class FusedMappingLoop(MappingLoop):
         zr = self._zero
         plan = zr["plan"]
         self.comm.reduce_scatter(zr["shard"], a["flat"])
-        a["flat"].zero_()
+        if stored:
+            # the gather pass STORED this iteration's sums for every Gaussian (grads_clean = -3) and the next one will again: the
+            # 56 B x N memset per exchange is gone; whoever uses the sinks in any other way zeroes them first (_clean_flat)
+            self._flat_dirty = True
+        else:
+            a["flat"].zero_()
+            self._flat_dirty = False
         grp = (nat.SgrAdamGroup * 5)()
         r0, r1 = (C.c_int64 * 5)(), (C.c_int64 * 5)()
         for k, name in enumerate(_GROUPS):
@@ -852,6 +866,7 @@ class FusedMappingLoop(MappingLoop):
 
     def _launch_span(self, prep):
         run, pl, n_it, per, window_cams, pool_cams, picks, _keep = prep
+        self._clean_flat()
         rc = self.lib.sgr_map_run(C.byref(run), self._stream())
         nat.check(rc, "sgr_map_run")
         self.gaussians.invalidate_activations()    # parameters changed through raw pointers: cached torch activations are stale
@@ -882,7 +897,12 @@ class FusedMappingLoop(MappingLoop):
         st = self._setup(pl, iso_weight, True, (), stats, False, "none", bump=False)
         views_st = nat.SgrMapStep()
         C.memmove(C.byref(views_st), C.byref(st), C.sizeof(st))
-        views_st.adam_groups, views_st.grads_clean, views_st.exp_rows = None, -2, 0
+        # store mode (-3) while the sinks hold nothing that must survive: the gather pass overwrites every row, nobody zeroes the
+        # flat buffer between iterations; a prune pass's leftovers (not _acc_clean) are ADDED to (-2) and the buffer zeroed after
+        stored = self._acc_clean and self._zero is not None
+        if not stored:
+            self._clean_flat()
+        views_st.adam_groups, views_st.grads_clean, views_st.exp_rows = None, (-3 if stored else -2), 0
         arr = (nat.SgrMapView * max(1, len(pos)))()
         views_st.num_views, views_st.views = len(pos), arr
         stream = self._stream()
@@ -902,10 +922,12 @@ class FusedMappingLoop(MappingLoop):
                 self._exp.grad[: max(exp_rows) + 1].zero_()                 # rows of cameras other ranks render stay 0 here
             if pos:
                 nat.check(self.lib.sgr_map_step(C.byref(views_st), stream), "sgr_map_step")
+            elif stored:
+                self._clean_flat()           # (a rank without views this iteration contributes zeros)
             pl.groups[0].lr = lrs[k]
             for g in range(5):
                 pl.groups[g].step += 1
-            self._exchange_and_adam(pl, iso_weight)
+            self._exchange_and_adam(pl, iso_weight, stored=stored and bool(pos))
             if exp_rows:
                 self._exposure_exchange(exp_rows)
                 self._exp.step_mask(self.lib, exp_rows, stream)
@@ -941,14 +963,20 @@ class FusedMappingLoop(MappingLoop):
             do_adam = bool(st.adam_groups)
             iso = st.iso_weight if do_adam else 0.0
             st.adam_groups, st.exp_rows = None, 0
+            # store mode (see _run_span_ranks): this rank's views overwrite every row of the sinks, which hold nothing to keep
+            stored = do_adam and self.fuse_tail and self._acc_clean and self._zero is not None and len(cams) > 0
+            if not stored:
+                self._clean_flat()
             if do_adam and self.fuse_tail:
-                st.grads_clean = -2
+                st.grads_clean = -3 if stored else -2
             rc = self.lib.sgr_map_step(C.byref(st), self._stream()) if (len(cams) or activate) else 0
             if rc == 0 and do_adam:
-                self._exchange_and_adam(pl, iso, skip)
+                self._exchange_and_adam(pl, iso, skip, stored=stored)
                 if exposure != "none" and len(all_cams):
                     self._exposure_step(all_cams, only_rendered=isinstance(exposure, list))
         else:
+            if not forward_only:
+                self._clean_flat()
             rc = self.lib.sgr_map_step(C.byref(st), self._stream())
         if not activate:
             st.scaling, st.rotation, st.opacity = sc, ro, op

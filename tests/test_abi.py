@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
         assert name in nat.SIGNATURES, f"{name} has no ctypes signature in splat_slam_amd/_native.py"
     assert sorted(nat.SIGNATURES) == declared
     lib = nat.lib()
-    assert lib.sgr_abi_version() == 8
+    assert lib.sgr_abi_version() == 9
     assert isinstance(nat.last_error(), str)
 
 
