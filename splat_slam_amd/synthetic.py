@@ -33,6 +33,11 @@ INTRINSICS = {
     "metric": dict(W=640, H=480, fx=400.0, fy=400.0, cx=319.5, cy=239.5),
     "replica": dict(W=640, H=320, fx=320.0, fy=600.0 * 320.0 / 680.0, cx=599.5 * 640.0 / 1200.0, cy=339.5 * 320.0 / 680.0),
     "tiny": dict(W=96, H=64, fx=70.0, fy=70.0, cx=47.5, cy=31.5),
+    # the other two datasets the reference is configured for, after the datasets.py:94-107 scaling (non-square pixels, principal
+    # point off the image centre): /root/reference/configs/TUM_RGBD/tum.yaml:40-47, configs/Scannet/scannet.yaml:48-55 -- the same
+    # numbers golden G1 was generated with (tests/test_golden_host.py checks them against the fixture)
+    "tum": dict(W=512, H=384, fx=517.3 * 512 / 640.0, fy=516.5 * 384 / 480.0, cx=318.6 * 512 / 640.0, cy=255.3 * 384 / 480.0),
+    "scannet": dict(W=320, H=240, fx=577.59 * 320 / 640.0, fy=578.73 * 240 / 480.0, cx=318.9 * 320 / 640.0, cy=242.68 * 240 / 480.0),
 }
 ROOM = (6.0, 3.0, 4.0)      # x (length), y (height, down), z (width): a 6 x 4 x 3 m box
 

@@ -22,8 +22,10 @@ explicitly instead of by a looser tolerance:
     pixel's whole contribution (measured at configs[0]: 2 such pairs in the view, 3e-3 of the largest gradient; every other
     Gaussian agrees to 1e-5).  The oracle reports the Gaussians that have such a pair (raster_oracle.knife_edge_gaussians,
     band 5e-4).  The two headline configs are first MOVED OFF their knife edges (opacities of those Gaussians nudged by
-    0.2-2 %, 2 rounds) and then compared with no exception at all; the batched / long-list cases hold every Gaussian that is
-    not on the list to 1e-4 and bound the listed ones (2e-2, and only a few may exceed 1e-4);
+    0.2-2 %, 2 rounds) and then compared with no exception at all; the batched cases hold every Gaussian that is
+    not on the list to 1e-4 and bound the listed ones (2e-2, and only a few may exceed 1e-4); the LONG-LIST cases (opaque maps:
+    the list holds practically every Gaussian there and pins nothing) hold EVERY visible Gaussian to 1e-4 except a counted
+    <= 0.1 % of them, bounded by 2e-3 (_per_gaussian_bounded; rounds 1-3 accepted "rel L2 <= 2e-4, rel max <= 5e-3" here);
   * splats of a tile are ordered by the fp32 BIT PATTERN of their view-space depth.  With 300 k Gaussians on planar walls
     a handful of overlapping pairs per view have depths equal to the last ulp; which of the two comes first is decided by
     the rounding of the depth itself (first full-size run: 17 pixels / 3e-3, gradients off by up to 7e-3 of the maximum
@@ -143,6 +145,33 @@ def _per_gaussian_report(soft, what, a, b, knife_rows, width, visible=None):
     soft.check(q[0] <= 1e-5, f"{what}: median per-Gaussian rel err {q[0]:.1e}")
 
 
+def _per_gaussian_bounded(soft, what, a, b, knife_rows, width, visible, max_frac=1e-3, hard=2e-3):
+    """The acceptance rule of the long-list cases (round 4; it replaces "rel L2 <= 2e-4 and rel max <= 5e-3"): EVERY visible Gaussian
+    within REL of the oracle, except a counted few -- at most max(3, max_frac x visible) -- that a flipped cut-off at one of their
+    ~1000 pixels moved, and those by no more than `hard`.  The rule does not lean on the oracle's knife-edge list: on a
+    surface-covering map that list holds practically every Gaussian (each has SOME pixel on a cut-off) and therefore pins
+    nothing; its coverage is printed, and where it covers no more than a quarter of the visible Gaussians the exceptions must
+    additionally all be on it."""
+    a, b = a.double().reshape(-1, width), b.double().reshape(-1, width)
+    m = b.abs().max().clamp_min(1e-30)
+    e = (a - b).abs().max(dim=1).values / m
+    nvis = int(visible.sum())
+    ev = e[visible]
+    if ev.numel() == 0:
+        return
+    q = torch.quantile(ev, torch.tensor([0.5, 0.99, 0.999], dtype=torch.float64)).tolist()
+    beyond = e > REL
+    allowed = max(3, int(math.ceil(max_frac * nvis)))
+    cover = float((knife_rows & visible).sum()) / max(1, nvis)
+    soft.check(int(beyond.sum()) <= allowed and e.max().item() <= hard,
+               f"{what}: {int(beyond.sum())} of {nvis} visible Gaussians beyond {REL} (allowed {allowed}), worst {e.max().item():.2e} (allowed {hard}); "
+               f"quantiles 50/99/99.9 % = {q[0]:.1e}/{q[1]:.1e}/{q[2]:.1e}; the oracle's knife-edge list covers {100 * cover:.1f} % of the visible Gaussians"
+               + (" -- it pins nothing here, the count bound is the check" if cover > 0.25 else ""))
+    soft.check(q[2] <= 0.5 * REL and q[0] <= 1e-5, f"{what}: 99.9 % quantile {q[2]:.1e}, median {q[0]:.1e}")
+    if cover <= 0.25:
+        soft.check(int((beyond & ~knife_rows).sum()) == 0, f"{what}: {int((beyond & ~knife_rows).sum())} Gaussians beyond {REL} are NOT on the knife-edge list")
+
+
 WIDTH = {"means3D": 3, "means2D": 3, "opacities": 1, "shs": 3, "scales": 3, "rotations": 4}
 
 
@@ -199,11 +228,11 @@ def test_autograd_api_matches_oracle_at_config_size(case):
             r = rel_linf(hip_g[k].reshape(-1), ref_g[k].reshape(-1))
             soft.check(r <= 3 * REL, f"{name}: grad {k} rel err {r:.3e}")
         elif not deknife:
-            a, b = hip_g[k].double().reshape(-1), ref_g[k].double().reshape(-1)
-            l2, linf = ((a - b).norm() / b.norm()).item(), rel_linf(a, b)
-            soft.check(l2 <= 2 * REL and linf <= 5e-3, f"{name}: grad {k} rel L2 err {l2:.3e}, rel max err {linf:.3e}")
             if k in WIDTH:
-                _per_gaussian_report(soft, f"{name}: grad {k}", hip_g[k], ref_g[k], on_edge, WIDTH[k], vis_rows)
+                _per_gaussian_bounded(soft, f"{name}: grad {k}", hip_g[k], ref_g[k], on_edge, WIDTH[k], vis_rows)
+            else:       # pose gradients are sums over all Gaussians: a flipped pair moves them by its share
+                r = rel_linf(hip_g[k].reshape(-1), ref_g[k].reshape(-1))
+                soft.check(r <= 3 * REL, f"{name}: grad {k} rel err {r:.3e}")
         elif k in WIDTH:
             strict, loose, n_loose = _strict_rel(hip_g[k], ref_g[k], on_edge, WIDTH[k])
             soft.check(strict <= REL, f"{name}: grad {k} rel err {strict:.3e} (Gaussians off the knife edges)")
@@ -350,9 +379,7 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
     for mine, ref, w in pairs:
         a, b = acc[mine].detach().cpu().double().reshape(-1, w), x[ref].grad.double().reshape(-1, w)
         if by_l2:      # long lists: (almost) every Gaussian has some pixel on a knife edge -- see the opaque autograd case
-            l2, linf = ((a - b).norm() / b.norm()).item(), rel_linf(a, b)
-            soft.check(l2 <= 2 * REL and linf <= 5e-3, f"accumulated grad {mine}: rel L2 err {l2:.3e}, rel max err {linf:.3e}")
-            _per_gaussian_report(soft, f"accumulated grad {mine}", a, b, on_edge, w, seen)
+            _per_gaussian_bounded(soft, f"accumulated grad {mine}", a, b, on_edge, w, seen)
             continue
         strict, loose, n_loose = _strict_rel(a, b, on_edge, w)
         e = (a - b).abs().max(dim=1).values / b.abs().max()
@@ -379,7 +406,7 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
                             **{f"cam{k}_view": _oracle_settings(c, intr).viewmatrix.numpy() for k, c in enumerate(cams)})
     a, b = gm.xyz_gradient_accum.cpu().double().reshape(-1, 1), stat_accum.reshape(-1, 1)
     if by_l2:
-        soft.check(((a - b).norm() / b.norm()).item() <= 2 * REL, f"densification statistic: rel L2 err {((a - b).norm() / b.norm()).item():.3e}")
+        _per_gaussian_bounded(soft, "densification statistic", a, b, on_edge, 1, seen)
     else:
         strict, loose, n_loose = _strict_rel(a, b, on_edge, 1)
         soft.check(strict <= REL and loose <= 2e-2, f"densification statistic: rel err {strict:.3e} / knife-edge {loose:.3e}")
