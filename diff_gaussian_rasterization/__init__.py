@@ -16,6 +16,13 @@ views (one launch per stage) and returns the five summed gradients.  Per view th
 [N, .] gradient tensors and their accumulation by the autograd engine.  Views whose inputs are not shared (the caller
 recomputes its activations per render) form batches of one: same results, no saving.  SPLAT_RASTER_BATCH=0 switches the
 batching off (every view returns its own dense gradients, as upstream does).
+
+Round 4: for the reference's own call (sh_degree 0, shs [N,1,3], scales + rotations, fp32 contiguous GPU tensors) the nodes and the
+workspace state machine described above run in C++ (csrc/dgr_native.cpp -> _dgr.so, built by __graft_entry__.build(): libtorch
+autograd nodes over the same C ABI): a forward is ONE call into the extension and the backward never re-enters the interpreter
+(a 12-view iteration of the reference-shaped loop: 3.4 -> see BASELINE.md ms of host time).  This file keeps every other input
+combination (precomputed colours / covariances, SH degrees 1-3, SPLAT_RASTER_BATCH=0) and is the specification the C++ half was
+written from; SPLAT_RASTER_NATIVE=0 runs everything through it.
 """
 # flake8: noqa: E501
 from typing import NamedTuple
@@ -31,7 +38,7 @@ import torch.nn as nn
 
 from splat_slam_amd import _native as nat
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "native_extension"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -201,6 +208,36 @@ class _DeviceState:
 
 
 _states = {}
+
+# ---- the C++ half ----------------------------------------------------------------------------------------------------------------
+NATIVE = os.environ.get("SPLAT_RASTER_NATIVE", "1") != "0"
+_ext, _ext_tried = None, False
+
+
+def native_extension():
+    """diff_gaussian_rasterization/_dgr.so (C++ autograd nodes + workspace state; splat_slam_amd.build.build_dropin_ext) or None when
+    it has not been built or SPLAT_RASTER_NATIVE=0.  A library that exists but does not load raises: a broken build must not
+    silently run the slower path."""
+    global _ext, _ext_tried
+    if not NATIVE:
+        return None
+    if not _ext_tried:
+        _ext_tried = True
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dgr.so")
+        if os.path.exists(path):
+            import importlib.util
+            nat.lib()                            # libsplat_hip.so first (same object the extension links)
+            spec = importlib.util.spec_from_file_location("diff_gaussian_rasterization._dgr", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != nat.lib().sgr_abi_version():
+                raise ImportError("diff_gaussian_rasterization/_dgr.so was built against another libsplat_hip.so ABI: rebuild")
+            _ext = mod
+        else:
+            import warnings
+            warnings.warn("diff_gaussian_rasterization/_dgr.so is not built (python -m splat_slam_amd.build): the rasterizer's autograd "
+                          "nodes run in Python (same HIP kernels, ~3x the host time per mapping iteration)", RuntimeWarning)
+    return _ext
 
 
 def _state(device):
@@ -552,6 +589,15 @@ def _batchable(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
                         raster_settings):
+    ext = native_extension() if BATCH else None
+    if ext is not None and _empty_to_none(colors_precomp) is None and _empty_to_none(cov3Ds_precomp) is None and means3D.is_cuda:
+        rs = raster_settings
+        out = ext.try_rasterize(means3D, means2D, _empty_to_none(sh), opacities, _empty_to_none(scales), _empty_to_none(rotations), theta, rho,
+                                int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy), rs.bg,
+                                float(rs.scale_modifier), rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, int(rs.sh_degree), rs.campos,
+                                bool(rs.prefiltered), bool(rs.debug), SYNC, DEFER_POSE_GRADS)
+        if out is not None:                  # (None: not the reference's call shape -- the Python nodes below take it)
+            return out
     if _batchable(means3D, sh, _empty_to_none(colors_precomp), opacities, scales, rotations, _empty_to_none(cov3Ds_precomp),
                   raster_settings):
         st = _state(means3D.device)
@@ -572,6 +618,11 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 def saved_block_of(output):
     """(saved workspace block, capacity) of the forward that produced `output` (one of the differentiable tensors a
     GaussianRasterizer call returned) -- parity tooling: sgr_query_* read the forward's own depth keys / counters from it."""
+    ext = native_extension()
+    if ext is not None:
+        hit = ext.saved_block_of(output)
+        if hit is not None:
+            return hit
     fn = output.grad_fn
     r = getattr(fn, "record", None)
     if r is not None:
@@ -583,6 +634,8 @@ def check_overflow():
     """Waits for the pair counts of all forwards issued so far and raises if any of them dropped pairs."""
     for st in _states.values():
         st.report(wait=True)
+    if native_extension() is not None:
+        native_extension().check_overflow()
 
 
 class GaussianRasterizer(nn.Module):

@@ -64,6 +64,11 @@ def timed(name, fn):
 
 
 mapper_mod.render = timed("render() incl. rasterizer forward", mapper_mod.render)
+ext = drg.native_extension()
+res["native_nodes"] = ext is not None
+drg.rasterize_gaussians = timed("  of which rasterize_gaussians (one call into _dgr.so, or the Python node)", drg.rasterize_gaussians)
+if ext is not None:
+    ext.profile_enable(True)
 drg._RasterizeGaussians.forward = staticmethod(timed("  of which _RasterizeGaussians.forward body", drg._RasterizeGaussians.forward))
 drg._RasterizeGaussians.backward = staticmethod(timed("  of which _RasterizeGaussians.backward (record)", drg._RasterizeGaussians.backward))
 drg._batched_backward = timed("  of which collector: batched backward", drg._batched_backward)
@@ -86,7 +91,8 @@ res["phases_ms_per_iteration"] = {k: round(1e-3 * statistics.median(SAMPLES[k]) 
 res["phases_ms_per_iteration_mean_incl_one_off_stalls"] = {k: round(1e3 * v / a.iters, 4) for k, v in T.items()}
 res["calls_per_iteration"] = {k: round(v / a.iters, 2) for k, v in CNT.items()}
 res["instrumented_ms_per_iteration_host"] = round(1e3 * wall / a.iters, 3)
-res["collector_ms_per_iteration"] = {k: round(1e3 * v / (a.iters * 2 + 3), 4) for k, v in drg._PROF.items()}
+res["collector_ms_per_iteration"] = ({k: round(1e3 * v / a.iters, 4) for k, v in ext.profile_read().items()} if ext is not None else
+                                      {k: round(1e3 * v / (a.iters * 2 + 3), 4) for k, v in drg._PROF.items()})
 res["first_calls_us"] = {k: v[:40] for k, v in SAMPLES.items()}
 print(json.dumps({k: v for k, v in res.items() if k != "first_calls_us"}, indent=1))
 print("first calls (us):", json.dumps(res["first_calls_us"]))

@@ -57,5 +57,45 @@ def build_native(force=False, verbose=True):
     return LIB
 
 
+# ---- the host-only C++ half of the drop-in package (autograd nodes + workspace state over the C ABI; no kernels) ----------------------
+DROPIN_DIR = os.path.join(os.path.dirname(HERE), "diff_gaussian_rasterization")
+DROPIN_SRC = os.path.join(DROPIN_DIR, "csrc", "dgr_native.cpp")
+DROPIN_LIB = os.path.join(DROPIN_DIR, "_dgr.so")
+
+
+def dropin_needs_build():
+    if not os.path.exists(DROPIN_LIB):
+        return True
+    t = os.path.getmtime(DROPIN_LIB)
+    return any(os.path.getmtime(p) > t for p in (DROPIN_SRC, os.path.join(os.path.dirname(HERE), "include", "splat_hip.h")))
+
+
+def build_dropin_ext(force=False, verbose=True):
+    """g++ -> diff_gaussian_rasterization/_dgr.so: a pybind11 / libtorch extension that links libsplat_hip.so (rpath relative to the
+    package).  Host code only, so plain g++ with torch's include / library paths (what torch.utils.cpp_extension would pass)."""
+    if not force and not dropin_needs_build():
+        return DROPIN_LIB
+    build_native(verbose=verbose)
+    import sysconfig
+    import pybind11
+    import torch
+    from torch.utils import cpp_extension as ce
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cxx = os.environ.get("CXX", "g++")
+    inc = ce.include_paths() + [pybind11.get_include(), sysconfig.get_paths()["include"], os.path.join(rocm, "include")]
+    tlib = ce.library_paths()[0]
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-sign-compare",
+           "-DTORCH_EXTENSION_NAME=_dgr", "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + p for p in inc]
+    cmd += [DROPIN_SRC, "-o", DROPIN_LIB, "-L" + tlib, "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10", "-lc10_hip", "-ltorch_hip",
+            "-L" + LIBDIR, "-lsplat_hip", "-Wl,-rpath," + tlib, "-Wl,-rpath,$ORIGIN/../splat_slam_amd/lib"]
+    if verbose:
+        print("[build]", " ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return DROPIN_LIB
+
+
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv))
+    print(build_dropin_ext(force="--force" in sys.argv))

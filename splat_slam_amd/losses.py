@@ -79,6 +79,11 @@ def get_median_depth(depth, opacity=None, mask=None, return_std=False):
     return (picked.median(), picked.std(), use) if return_std else picked.median()
 
 
+def _native_nodes():
+    import diff_gaussian_rasterization as drg
+    return drg.native_extension()
+
+
 class _FusedMappingLoss(torch.autograd.Function):
     """One pass over the image: loss value + dL/dimage, dL/ddepth, dL/da, dL/db (fixed-order reduction)."""
 
@@ -125,4 +130,7 @@ def get_loss_mapping_fused(config, image, depth, viewpoint, opacity, initializat
         gt_depth = _gt_depth(viewpoint, image.device).contiguous()
         viewpoint._depth_dev = gt_depth     # keep the ground-truth depth resident instead of re-uploading per call
     a, b = (None, None) if initialization else (viewpoint.exposure_a, viewpoint.exposure_b)
+    ext = _native_nodes()
+    if ext is not None and image.is_cuda:        # the same launch, its autograd node in C++ (diff_gaussian_rasterization/csrc/dgr_native.cpp)
+        return ext.mapping_loss(image, depth, a, b, gt_image, gt_depth, float(alpha), float(thr))
     return _FusedMappingLoss.apply(image, depth, a, b, gt_image.contiguous(), gt_depth, float(alpha), float(thr))

@@ -32,9 +32,25 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         lib = nat.lib()
         stream = None
+        import diff_gaussian_rasterization as drg
+        ext = drg.native_extension()
         for g in self.param_groups:
             b1, b2 = g["betas"]
             lr, eps = float(g["lr"]), float(g["eps"])
+            if ext is not None:       # the whole group in one call into the C++ half: no ctypes call, `.item()` or CPU add per tensor
+                ps, gs, ms, vs, ts = [], [], [], [], []
+                for p in g["params"]:
+                    if p.grad is None:
+                        continue
+                    st = self.state[p]
+                    if len(st) == 0:                       # exactly what torch.optim.Adam._init_group creates
+                        st["step"] = torch.tensor(0.0, dtype=torch.get_default_dtype())
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    ps.append(p); gs.append(p.grad); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); ts.append(st["step"])
+                if ps and all(t.dtype is torch.float32 and t.device.type == "cpu" for t in ts):
+                    ext.adam_group_step(ps, gs, ms, vs, ts, lr, float(b1), float(b2), eps)
+                    continue
             small = []                                 # tensors of <= kSmall elements of this group go out in ONE launch
             for p in g["params"]:
                 grad = p.grad

@@ -133,3 +133,52 @@ def move_off_knife_edges(inp, s, max_rounds=12):
                 sc[kg] *= 1.0 + 0.003 * torch.rand(kg.numel(), 1, generator=g, dtype=torch.float64)
                 inp["scales"] = sc.float().double()
     raise AssertionError("scene still has knife-edge pairs after %d rounds" % max_rounds)
+
+
+def depth_tie_gaussians(inp, s, ulps=32, window=64):
+    """Visible Gaussians that have a NEAR TIE in view-space depth (within `ulps` fp32 ulp) with another visible Gaussian whose
+    16x16-tile rectangle overlaps theirs -- the only pairs whose order the rounding of the depth itself can decide."""
+    pp = O.preprocess(inp["means3D"], None, inp["opacities"], inp.get("shs"), inp.get("colors_precomp"), inp.get("scales"),
+                      inp.get("rotations"), inp.get("cov3D_precomp"), None, None, s)
+    vis = torch.nonzero(pp.visible).flatten()
+    d = pp.depth.detach()[vis].double()
+    order = torch.argsort(d)
+    ds, ids, rect = d[order], vis[order], pp.rect[vis][order]
+    hit = torch.zeros(ds.numel(), dtype=torch.bool)
+    tol = ulps * ds.abs() * 2.0 ** -23
+    for k in range(1, window + 1):
+        if k >= ds.numel():
+            break
+        near = (ds[k:] - ds[:-k]) <= tol[:-k]
+        if not bool(near.any()):
+            break                              # (sorted: no pair further apart in the order can be nearer in depth)
+        a, b = rect[:-k], rect[k:]
+        overlap = (a[:, 0] < b[:, 2]) & (b[:, 0] < a[:, 2]) & (a[:, 1] < b[:, 3]) & (b[:, 1] < a[:, 3])
+        m = near & overlap
+        hit[:-k] |= m
+        hit[k:] |= m
+    else:
+        raise AssertionError("depth ties: window too small")
+    return ids[hit]
+
+
+def move_off_knife_edges_and_depth_ties(inp, s, max_rounds=30, seed=23):
+    """move_off_knife_edges + pushes overlapping near-ties in depth apart along the viewing direction (by 0.02-0.2 mm) until neither
+    is left.  Returns (rounds, Gaussian moves).  After it, ANY two correct implementations order every tile's splats alike."""
+    g = torch.Generator().manual_seed(seed)
+    direction = s.viewmatrix.double().t()[2, :3].clone()
+    moves = 0
+    for rnd in range(max_rounds):
+        rounds = move_off_knife_edges(inp, s)
+        ties = depth_tie_gaussians(inp, s)
+        if ties.numel() == 0 and rounds == 0:
+            return rnd, moves
+        if ties.numel() == 0:
+            continue
+        moves += int(ties.numel())
+        m = inp["means3D"].clone()
+        step = (2e-5 + 2e-4 * torch.rand(ties.numel(), 1, generator=g, dtype=torch.float64))
+        sign = torch.where(torch.rand(ties.numel(), 1, generator=g) < 0.5, -1.0, 1.0).double()
+        m[ties] += direction[None] * step * sign
+        inp["means3D"] = m.float().double()
+    raise AssertionError("near ties / knife edges did not clear after %d rounds" % max_rounds)

@@ -31,6 +31,25 @@ def test_header_symbols_are_exported_and_bound():
     assert isinstance(nat.last_error(), str)
 
 
+def test_dropin_cpp_extension_builds_loads_and_links_the_c_abi():
+    """diff_gaussian_rasterization/_dgr.so (host-only C++: libtorch autograd nodes + workspace state over the C ABI) builds with g++,
+    loads next to libsplat_hip.so and exposes its entry points; the product sources under csrc/ never mention the oracle."""
+    from splat_slam_amd.build import build_dropin_ext
+    path = build_dropin_ext(verbose=False)
+    assert os.path.exists(path)
+    import diff_gaussian_rasterization as drg
+    ext = drg.native_extension()
+    assert ext is not None and ext.abi_version() == 9
+    for name in ("try_rasterize", "mapping_loss", "adam_group_step", "densify_stats_views", "saved_block_of", "check_overflow", "stats",
+                 "set_capacity", "profile_enable", "profile_read"):
+        assert callable(getattr(ext, name)), name
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+    assert "libsplat_hip.so" in needed and "$ORIGIN/../splat_slam_amd/lib" in needed
+    src = open(os.path.join(ROOT, "diff_gaussian_rasterization", "csrc", "dgr_native.cpp")).read()
+    assert "oracle" not in src
+
+
 def test_struct_layouts_match_the_header():
     from splat_slam_amd import _native as nat
     # 10 x 4-byte scalars, then 5 pointers (8-aligned) -- see SgrSettings in include/splat_hip.h
@@ -75,7 +94,7 @@ def test_product_path_has_no_cpu_fallback_and_never_imports_the_oracle():
           scales=torch.ones(2, 3), rotations=torch.tensor([[1.0, 0, 0, 0]] * 2))
     with pytest.raises(Exception, match="excatly one"):
         r(means3D=torch.zeros(2, 3), means2D=torch.zeros(2, 3), opacities=torch.ones(2, 1))
-    for pkg in ("splat_slam_amd", "diff_gaussian_rasterization", "simple_knn"):
+    for pkg in ("splat_slam_amd", "diff_gaussian_rasterization", "simple_knn", "lietorch"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
             for f in files:
                 if f.endswith(".py"):

@@ -124,10 +124,9 @@ def test_autograd_api_matches_oracle_that_sorts_by_its_own_depths():
     """The full-size cases hand the oracle the HIP forward's fp32 depths as SORT KEYS (after checking them to 8 ulp), because two
     correct implementations order splats whose depths agree to an ulp differently.  Here nothing is handed over: the oracle sorts
     by its own depths; the scene (configs[0] shape) is first moved off its knife edges AND its near ties (visible Gaussians whose
-    depths are within 32 fp32 ulp of each other are pushed apart along the viewing direction), then held to 1e-4 with no
-    exceptions -- an ordering defect on the HIP side would have nowhere to hide."""
-    from gpu_utils import GRAD_KEYS, move_off_knife_edges, rel_linf, run_hip, run_oracle
-    from oracle import raster_oracle as O
+    depths are within 32 fp32 ulp of each other AND whose tile rectangles overlap are pushed apart along the viewing direction),
+    then held to 1e-4 with no exceptions -- an ordering defect on the HIP side would have nowhere to hide."""
+    from gpu_utils import GRAD_KEYS, move_off_knife_edges_and_depth_ties, rel_linf, run_hip, run_oracle
     from test_gpu_fullsize import REL, Soft, WIDTH, _activated_inputs, _oracle_settings, _room
     n = 20000
     syn, intr, params, cams = _room(n, "replica", 1)
@@ -135,30 +134,8 @@ def test_autograd_api_matches_oracle_that_sorts_by_its_own_depths():
     inp = _activated_inputs(gm)
     s = _oracle_settings(cams[0], intr)
     soft = Soft()
-    view = s.viewmatrix.double().t()
-    direction = view[2, :3].clone()
-    g = torch.Generator().manual_seed(23)
-    moved_total = 0
-    for rnd in range(20):
-        rounds = move_off_knife_edges(inp, s)
-        pp = O.preprocess(inp["means3D"], None, inp["opacities"], inp["shs"], None, inp["scales"], inp["rotations"], None, None, None, s)
-        vis = torch.nonzero(pp.visible).flatten()
-        d = pp.depth[vis].double()
-        order = torch.argsort(d)
-        ds = d[order]
-        ulp = torch.abs(ds[:-1]) * 2.0 ** -23
-        close = (ds[1:] - ds[:-1]) <= 32 * ulp
-        ties = torch.unique(torch.cat([vis[order[:-1]][close], vis[order[1:]][close]]))
-        if ties.numel() == 0 and rounds == 0:
-            break
-        moved_total += int(ties.numel())
-        m = inp["means3D"].clone()
-        m[ties] += direction[None] * (2e-5 + 2e-4 * torch.rand(ties.numel(), 1, generator=g, dtype=torch.float64)) * \
-            torch.where(torch.rand(ties.numel(), 1, generator=g) < 0.5, -1.0, 1.0).double()
-        inp["means3D"] = m.float().double()
-    else:
-        raise AssertionError("near ties / knife edges did not clear")
-    soft.check(True, f"{moved_total} Gaussian moves (near depth ties pushed apart along the viewing direction) over {rnd} rounds")
+    rounds, moves = move_off_knife_edges_and_depth_ties(inp, s)
+    soft.check(True, f"{moves} Gaussian moves (overlapping near ties in depth pushed apart along the viewing direction) over {rounds} rounds")
     gw = torch.Generator().manual_seed(5)
     wc = torch.randn(3, intr["H"], intr["W"], generator=gw, dtype=torch.float64)
     wd = torch.randn(1, intr["H"], intr["W"], generator=gw, dtype=torch.float64)
