@@ -758,7 +758,7 @@ static Tensor mapping_loss(const Tensor& image_in, const Tensor& depth_in, const
                            has_exp ? exp_a->data_ptr<float>() : nullptr, has_exp ? exp_b->data_ptr<float>() : nullptr, (float)alpha, (float)thr,
                            1.0f, a + 4 * hw + 2, a, a + 3 * hw, a + 4 * hw, a + 4 * hw + 1, a + 4 * hw + 4, 4 * 4096, (void*)stream),
           "sgr_mapping_loss");
-    loss = arena.narrow(0, 4 * hw + 2, 1).view({});
+    loss = arena.select(0, 4 * hw + 2);          // 0-dim (`view({})` would pick the view(ScalarType) overload)
   }
   const bool need = torch::autograd::GradMode::is_enabled() &&
                     (image_in.requires_grad() || depth_in.requires_grad() || (has_exp && (exp_a->requires_grad() || exp_b->requires_grad())));

@@ -147,13 +147,13 @@ static int check_workspace(const SgrWorkspace* ws, const Layout& L) {
 static Common make_common(const SgrSettings* s) {
   Common c;
   c.deg = s->sh_degree; c.M = s->sh_coeffs; c.tanfovx = s->tanfovx; c.tanfovy = s->tanfovy; c.mod = s->scale_modifier;
-  c.bg = s->bg; c.projraw = s->projmatrix_raw;
+  c.bg = s->bg;
   c.upstream_pose_jac = g_opt[SGR_OPT_UPSTREAM_POSE_JACOBIAN];
   return c;
 }
 
 static void tab_set_view(ViewTab& t, int v, const SgrSettings* s, const SgrOutputs* out, const SgrWorkspace* ws) {
-  t.viewmatrix[v] = s->viewmatrix; t.projmatrix[v] = s->projmatrix; t.campos[v] = s->campos;
+  t.viewmatrix[v] = s->viewmatrix; t.projmatrix[v] = s->projmatrix; t.campos[v] = s->campos; t.projraw[v] = s->projmatrix_raw;
   t.saved[v] = (char*)ws->saved; t.scratch[v] = (char*)ws->scratch;
   if (out) {
     t.color[v] = out->color; t.depth[v] = out->depth; t.opacity[v] = out->opacity; t.radii[v] = out->radii;
@@ -288,7 +288,7 @@ int sgr_backward_views(int32_t num_views, const SgrBackwardView* views, const Sg
               m.settings.image_width == f.settings.image_width && m.settings.tanfovx == f.settings.tanfovx &&
               m.settings.tanfovy == f.settings.tanfovy && m.settings.scale_modifier == f.settings.scale_modifier &&
               m.settings.sh_degree == f.settings.sh_degree && m.settings.sh_coeffs == f.settings.sh_coeffs &&
-              m.settings.bg == f.settings.bg && m.settings.projmatrix_raw == f.settings.projmatrix_raw && m.ws.capacity == f.ws.capacity;
+              m.settings.bg == f.settings.bg && m.ws.capacity == f.ws.capacity;
     for (int u = 0; u < v; ++u) uniform = uniform && views[u].ws.scratch != m.ws.scratch && views[u].ws.saved != m.ws.saved;
   }
   SgrGradInputs g = *grad_in;
@@ -362,7 +362,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
               m.settings.image_width == f.settings.image_width && m.settings.tanfovx == f.settings.tanfovx &&
               m.settings.tanfovy == f.settings.tanfovy && m.settings.scale_modifier == f.settings.scale_modifier &&
               m.settings.sh_degree == f.settings.sh_degree && m.settings.sh_coeffs == f.settings.sh_coeffs &&
-              m.settings.bg == f.settings.bg && m.settings.projmatrix_raw == f.settings.projmatrix_raw &&
+              m.settings.bg == f.settings.bg &&
               m.ws.capacity == f.ws.capacity;
     // several views accumulate through fixed-size gradient records: the reference's default inputs only
     if (num_views > 1) uniform = uniform && in->shs && m.settings.sh_degree == 0 && in->scales && in->rotations;

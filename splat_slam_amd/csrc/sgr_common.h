@@ -131,6 +131,8 @@ struct ViewTab {
   const float* viewmatrix[kMaxViews];
   const float* projmatrix[kMaxViews];
   const float* campos[kMaxViews];
+  const float* projraw[kMaxViews];   // projection_matrix of the view (per view since round 4: cameras of one batch may hold their own copies,
+                                     // and intrinsics that differ only in the principal point batch together)
   char* saved[kMaxViews];
   char* scratch[kMaxViews];
   float* color[kMaxViews];
@@ -162,7 +164,6 @@ struct Common {
   int upstream_pose_jac;   // SGR_OPT_UPSTREAM_POSE_JACOBIAN
   float tanfovx, tanfovy, mod;
   const float* bg;
-  const float* projraw;
 };
 
 // SGR_DEBUG environment variable -- stage-cost experiments only (scripts/stage_times.py), results are wrong when set:

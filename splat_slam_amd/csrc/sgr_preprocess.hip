@@ -307,6 +307,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
   __shared__ int32_t* p_ntouched[kMaxViews];
   __shared__ const float* p_campos[kMaxViews];
   __shared__ char* p_scratch[kMaxViews];
+  __shared__ const float* p_projraw[kMaxViews];
   __shared__ uint8_t cand[kMaxViews][kSeg];
   __shared__ uint32_t wtot[kMaxViews][4];
   __shared__ uint32_t vstart[kMaxViews + 1];
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     if (u < nviews) {
       if (tid < 16) mats[u][tid] = tab.viewmatrix[u][tid];
       else if (tid < 32) mats[u][tid] = tab.projmatrix[u][tid - 16];
-      if (tid == 32) { p_saved[u] = tab.saved[u]; p_radii[u] = tab.radii[u]; p_ntouched[u] = tab.n_touched[u]; p_campos[u] = tab.campos[u]; p_scratch[u] = tab.scratch[u]; }
+      if (tid == 32) { p_saved[u] = tab.saved[u]; p_radii[u] = tab.radii[u]; p_ntouched[u] = tab.n_touched[u]; p_campos[u] = tab.campos[u]; p_scratch[u] = tab.scratch[u]; p_projraw[u] = tab.projraw[u]; }
     }
   }
   if (tid <= kMaxViews) { vbase_t[tid] = 0u; vbase_v[tid] = 0u; }
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
             const float limx = 1.3f * cm.tanfovx, limy = 1.3f * cm.tanfovy;
             const float tn = (fx * fx * (1.f + limx * limx) + fy * fy * (1.f + limy * limy)) * iz0 * iz0;
             const float rad = ceilf(3.f * sqrtf(tn * tsm * 1.01f + 1.0f)) + 3.f;
-            const float ox = 0.5f * L.W * (cm.projraw[8] + 1.f) - 0.5f, oy = 0.5f * L.H * (cm.projraw[9] + 1.f) - 0.5f;
+            const float ox = 0.5f * L.W * (p_projraw[tid][8] + 1.f) - 0.5f, oy = 0.5f * L.H * (p_projraw[tid][9] + 1.f) - 0.5f;
             const float px0 = fx * xz0 + ox - rad - 1.f, px1 = fx * xz1 + ox + rad + (kRefTile - 1) + 1.f;
             const float py0 = fy * yz0 + oy - rad - 1.f, py1 = fy * yz1 + oy + rad + (kRefTile - 1) + 1.f;
             if (isfinite(px0) && isfinite(px1) && isfinite(py0) && isfinite(py1) && isfinite(rad))
@@ -1133,7 +1134,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   for (int j = 0; j < 6; ++j) acc.S6[j] = 0.f;
   acc.op = 0.f; acc.m2[0] = 0.f; acc.m2[1] = 0.f;
   preprocess_bwd_one_view(i, L.H, L.W, cm.deg, cm.M, cm.tanfovx, cm.tanfovy, cm.mod, tab.viewmatrix[v], tab.projmatrix[v],
-                          cm.projraw, tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                          tab.projraw[v], tab.campos[v], means3D, shs, colors_precomp, scales, rotations, cov3D_precomp,
                           gsum, q3.w, dshs, accumulate, acc, tau, cm.upstream_pose_jac);
   // the record sits at the GAUSSIAN's index (one full 64-byte sector): the gather pass then needs no list-slot lookup
   float4* rec = (float4*)(tab.scratch[v] + L.o_gradrec) + (size_t)i * 4;

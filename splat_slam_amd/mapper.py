@@ -196,8 +196,9 @@ class MappingLoop:
                     # occ_aware_visibility and n_obs and returns before optimizer.step()/zero_grad()
                     self._count_observations(current_window)
                     return False
-                for vsp, vis, radii in per_view:
-                    self._visible_stats(vsp, vis, radii)
+                if not self.gaussians.add_views_stats([(vsp, radii) for vsp, _, radii in per_view]):    # (GPU: one call for all views)
+                    for vsp, vis, radii in per_view:
+                        self._visible_stats(vsp, vis, radii)
                 update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
                 if update_gaussian:
                     self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th,
