@@ -814,6 +814,15 @@ static void adam_group_step(const std::vector<Tensor>& params, const std::vector
     check(sgr_adam_step_multi((int32_t)small.size(), small.data(), (float)lr, (float)b1, (float)b2, (float)eps, (void*)stream), "sgr_adam_step_multi");
 }
 
+using AdamGroupArgs = std::tuple<std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, double, double,
+                                 double, double>;
+// every parameter group of an optimiser in one call
+static void adam_groups_step(const std::vector<AdamGroupArgs>& groups) {
+  for (const auto& g : groups)
+    adam_group_step(std::get<0>(g), std::get<1>(g), std::get<2>(g), std::get<3>(g), std::get<4>(g), std::get<5>(g), std::get<6>(g), std::get<7>(g),
+                    std::get<8>(g));
+}
+
 // add_densification_stats + the max_radii2D update of SEVERAL views (gaussian_model.py:738-742, src/mapper.py:522-529): one host call
 static void densify_stats_views(const std::vector<Tensor>& means2D_grads, const std::vector<Tensor>& radii, Tensor accum, Tensor denom,
                                 Tensor max_radii) {
@@ -859,6 +868,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("last_pairs") = -1);
   m.def("mapping_loss", &dgr::mapping_loss);
   m.def("adam_group_step", &dgr::adam_group_step);
+  m.def("adam_groups_step", &dgr::adam_groups_step);
   m.def("densify_stats_views", &dgr::densify_stats_views);
   m.def("profile_enable", &dgr::profile_enable);
   m.def("profile_read", &dgr::profile_read);

@@ -34,10 +34,9 @@ class FusedAdam(torch.optim.Adam):
         stream = None
         import diff_gaussian_rasterization as drg
         ext = getattr(drg, "native_extension", lambda: None)()       # (tests inject the oracle under this module name)
-        for g in self.param_groups:
-            b1, b2 = g["betas"]
-            lr, eps = float(g["lr"]), float(g["eps"])
-            if ext is not None:       # the whole group in one call into the C++ half: no ctypes call, `.item()` or CPU add per tensor
+        if ext is not None:       # every group in ONE call into the C++ half: no ctypes call, `.item()` or CPU add per tensor
+            calls = []
+            for g in self.param_groups:
                 ps, gs, ms, vs, ts = [], [], [], [], []
                 for p in g["params"]:
                     if p.grad is None:
@@ -47,10 +46,23 @@ class FusedAdam(torch.optim.Adam):
                         st["step"] = torch.tensor(0.0, dtype=torch.get_default_dtype())
                         st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                         st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    ps.append(p); gs.append(p.grad); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); ts.append(st["step"])
-                if ps and all(t.dtype is torch.float32 and t.device.type == "cpu" for t in ts):
-                    ext.adam_group_step(ps, gs, ms, vs, ts, lr, float(b1), float(b2), eps)
-                    continue
+                    t = st["step"]
+                    if t.dtype is not torch.float32 or t.device.type != "cpu":
+                        calls = None
+                        break
+                    ps.append(p); gs.append(p.grad); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); ts.append(t)
+                if calls is None:
+                    break
+                if ps:
+                    b1, b2 = g["betas"]
+                    calls.append((ps, gs, ms, vs, ts, float(g["lr"]), float(b1), float(b2), float(g["eps"])))
+            if calls is not None:
+                if calls:
+                    ext.adam_groups_step(calls)
+                return loss
+        for g in self.param_groups:
+            b1, b2 = g["betas"]
+            lr, eps = float(g["lr"]), float(g["eps"])
             small = []                                 # tensors of <= kSmall elements of this group go out in ONE launch
             for p in g["params"]:
                 grad = p.grad
