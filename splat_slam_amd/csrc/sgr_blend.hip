@@ -622,7 +622,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
   const uint64_t* __restrict__ bucket = (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
   static_assert(kBucket >= kWave, "the first 64 entries of a bucket are fetched one per lane");
   uint64_t key_spec = lane < 32 ? bucket[lane] : ~0ull;
-  const uint2 rng = ranges[(size_t)tile * kRngStride];
+  uint2 rng = ranges[(size_t)tile * kRngStride];
+  if (L.dbg & 512) {             // EXPERIMENT (results wrong): no range / key round trip either (synthetic 11-entry lists)
+    key_spec = ((uint64_t)(uint32_t)(lane * 7 + 3) << 32) | (uint32_t)((tile * 11 + lane) % L.N);
+    rng = make_uint2((uint32_t)tile * 11u, (uint32_t)tile * 11u + 11u);
+  }
   const int64_t begin = rng.x & ~kOverfull;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
   const int count = endc > begin ? (int)(endc - begin) : 0;
@@ -648,11 +652,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
     uint32_t slot = 0xffffffffu;
     if (lane < count) {
+      if (L.dbg & 256) {         // EXPERIMENT (results wrong): no record gather -- what the second dependent round trip of a tile costs
+        m = make_float4(pxf + 0.25f * (float)(lane & 7) - 1.f, pyf - 0.25f * (float)(lane & 3), 0.f, 0.f);
+        co = make_float4(0.08f, 0.01f, 0.06f, 0.3f);
+        cd = make_float4(0.5f, 0.4f, 0.3f, 1.f + (float)lane);
+        slot = (uint32_t)(((uint64_t)tile * 16u + (uint32_t)lane) % (uint64_t)cap);
+      } else {
       const float4* rec = (const float4*)(grec + g);
       m = rec[0];
       co = rec[1];
       cd = rec[2];
       if (FUSED) slot = pair_slot(saved, L, g, ((const uint32_t*)(rec + 3))[1], __float_as_uint(m.z), __float_as_uint(m.w), tx, ty, cap);
+      }
     }
     if (lane >= count) rank = (uint32_t)lane;        // lane == count files the zero splat that pads an odd list
     if (!FUSED && lane < count) point_list[begin + rank] = g;      // (the fused backward reads the staged records instead)
