@@ -138,6 +138,14 @@ __device__ __forceinline__ void wave_sort_registers(const uint64_t* __restrict__
   for (int r = 0; r < KPL; ++r) ids[lane * KPL + r] = (uint32_t)k[r];
 }
 
+// The exponent of a splat's footprint is evaluated in base 2: both tile kernels take the conic (A, B, C) multiplied by log2(e) where they
+// stage / fetch a splat's record (three multiplies per (tile, splat) pair) and feed the quadratic form straight to v_exp_f32 -- the
+// multiply by log2(e) that __expf puts in front of every exponential was 2 of the ~95 issue slots of a backward iteration and 2 of
+// the ~45 of a forward trip.  Forward and backward scale the same way, so they still agree bit for bit on which pairs contribute;
+// the sign test `power <= 0` is unaffected.
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot); both blend kernels use 2-vectors
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
@@ -295,7 +303,7 @@ __device__ __forceinline__ SplatRec splat_from_grec(const GRec* __restrict__ gre
   const uint32_t rel = ((const uint32_t*)(rec + 3))[1];
   SplatRec s;
   s.slot = pair_slot(saved, L, g, rel, __float_as_uint(m.z), __float_as_uint(m.w), tx, ty, cap);
-  s.mx = m.x; s.my = m.y; s.A = co.x; s.B = co.y; s.C = co.z; s.op = co.w; s.r = cd.x; s.g = cd.y; s.b = cd.z; s.dep = cd.w;
+  s.mx = m.x; s.my = m.y; s.A = co.x * kLog2e; s.B = co.y * kLog2e; s.C = co.z * kLog2e; s.op = co.w; s.r = cd.x; s.g = cd.y; s.b = cd.z; s.dep = cd.w;
   return s;
 }
 // list position -> Gaussian through the index list the forward kernel published (blend_bwd_kernel)
@@ -367,7 +375,7 @@ __device__ __forceinline__ void bwd_chunk2(
     const v2f qf = __builtin_elementwise_fma(adx, dx, cdy2);
     const v2f bdxdy = (splat2(B) * dx) * dy;
     const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
-    const v2f G = {__expf(power.x), __expf(power.y)};
+    const v2f G = {exp2_fast(power.x), exp2_fast(power.y)};      // (the conic carries log2(e))
     const v2f og = splat2(op) * G;
     v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
     const bool ok0 = valid && (idx < nc0) && (power.x <= 0.0f) && (alpha.x >= kAlphaMin);
@@ -669,8 +677,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
     if (!FUSED && lane < count) point_list[begin + rank] = g;      // (the fused backward reads the staged records instead)
     if (lane <= count) {
       float* f = (float*)lds + (rank >> 1) * 24 + (rank & 1);
-      f[0] = m.x; f[2] = m.y; f[4] = co.x; f[6] = co.y;
-      f[8] = co.z; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
+      f[0] = m.x; f[2] = m.y; f[4] = co.x * kLog2e; f[6] = co.y * kLog2e;
+      f[8] = co.z * kLog2e; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
       f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
       if (FUSED) f[22] = __uint_as_float(slot);
     }
@@ -729,8 +737,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
         cd = rec[2];
       }
       float* f = (float*)lds + (lane >> 1) * 24 + (lane & 1);
-      f[0] = m.x; f[2] = m.y; f[4] = co.x; f[6] = co.y;
-      f[8] = co.z; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
+      f[0] = m.x; f[2] = m.y; f[4] = co.x * kLog2e; f[6] = co.y * kLog2e;
+      f[8] = co.z * kLog2e; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
       f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -749,7 +757,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
         const v2f qf = __builtin_elementwise_fma((v2f){q1.x, q1.y} * dx, dx, ((v2f){q2.x, q2.y} * dy) * dy);
         const v2f bdxdy = ((v2f){q1.z, q1.w} * dx) * dy;
         const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
-        const v2f G = {__expf(power.x), __expf(power.y)};
+        const v2f G = {exp2_fast(power.x), exp2_fast(power.y)};      // (the staged conic carries log2(e))
         const v2f og = (v2f){q2.z, q2.w} * G;
         const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
         const bool ok0 = (power.x <= 0.0f) && (alpha.x >= kAlphaMin);

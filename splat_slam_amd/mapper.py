@@ -101,6 +101,24 @@ class MappingLoop:
         else:
             self.keyframe_optimizers = torch.optim.Adam(groups) if groups else None
 
+    def _backward(self, make_loss):
+        """loss = make_loss(); loss.backward() -- once more from scratch if the rasterizer reports that a forward of this iteration
+        exceeded its pair capacity.  (Only the Python-node path of the drop-in package raises: inputs outside the reference's call
+        shape.  It has produced no gradient for the batch that raised and has already grown the capacity; batches of one that ran
+        before it may have accumulated into `.grad`, so the gradients are cleared before the second attempt -- ADVICE r3.  The C++
+        nodes re-run a truncated forward inside backward() themselves.)"""
+        for attempt in (0, 1):
+            out = make_loss()
+            try:
+                out[0].backward()
+                return out
+            except RuntimeError as e:
+                if attempt or "pair capacity" not in str(e):
+                    raise
+                self.gaussians.optimizer.zero_grad(set_to_none=True)
+                if self.keyframe_optimizers is not None:
+                    self.keyframe_optimizers.zero_grad(set_to_none=True)
+
     def _visible_stats(self, viewspace_points, vis, radii):
         """max_radii2D[vis] = max(max_radii2D[vis], radii[vis]) and add_densification_stats (mapper.py:332-335,523-529,
         gaussian_model.py:738-742) written without boolean-mask indexing: the same values element for element, but a mask
@@ -117,12 +135,11 @@ class MappingLoop:
         n_touched = None
         for mapping_iteration in range(self.init_itr_num if iters is None else iters):
             self.iteration_count += 1
-            pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
-            image, vsp, vis, radii, depth, opacity, n_touched = (pkg["render"], pkg["viewspace_points"],
-                                                                 pkg["visibility_filter"], pkg["radii"], pkg["depth"],
-                                                                 pkg["opacity"], pkg["n_touched"])
-            loss_init = self.loss_fn(self.config["mapping"], image, depth, viewpoint, opacity, initialization=True)
-            loss_init.backward()
+            def init_pass():
+                pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
+                return self.loss_fn(self.config["mapping"], pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True), pkg
+            loss_init, pkg = self._backward(init_pass)
+            vsp, vis, radii, n_touched = pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"], pkg["n_touched"]
             with torch.no_grad():
                 self._visible_stats(vsp, vis, radii)
                 if mapping_iteration % self.init_gaussian_update == 0:
@@ -170,18 +187,21 @@ class MappingLoop:
             self.iteration_count += 1
             # the window keyframes, then two keyframes drawn from the rest (torch RNG, mapper.py:470)
             extra = [random_viewpoint_stack[k] for k in torch.randperm(len(random_viewpoint_stack))[:2]]
-            passes = [view_pass(cam) for cam in viewpoint_stack + extra]
-            loss_mapping = 0
-            for term, _, _ in passes:
-                loss_mapping += term
+
+            def iteration_loss():
+                passes = [view_pass(cam) for cam in viewpoint_stack + extra]
+                loss_mapping = 0
+                for term, _, _ in passes:
+                    loss_mapping += term
+                scaling = self.gaussians.get_scaling
+                isotropic_loss = torch.abs(scaling - scaling.mean(dim=1).view(-1, 1))
+                # multi-GPU (grad_sync set): the view losses are summed over the ranks, the isotropy term must enter that sum ONCE
+                iso_weight = 10.0 if self.grad_sync is None else 10.0 / self.grad_sync.world
+                loss_mapping += iso_weight * isotropic_loss.mean()
+                return loss_mapping, passes
+            _, passes = self._backward(iteration_loss)
             per_view = [p[1] for p in passes]
             n_touched_acm = [p[2] for p in passes[:len(current_window)]]
-            scaling = self.gaussians.get_scaling
-            isotropic_loss = torch.abs(scaling - scaling.mean(dim=1).view(-1, 1))
-            # multi-GPU (grad_sync set): the view losses are summed over the ranks, the isotropy term must enter that sum ONCE
-            iso_weight = 10.0 if self.grad_sync is None else 10.0 / self.grad_sync.world
-            loss_mapping += iso_weight * isotropic_loss.mean()
-            loss_mapping.backward()
             if self.grad_sync is not None and not prune:      # (the prune pass never steps: nothing to exchange)
                 self.grad_sync.reduce()
             with torch.no_grad():
@@ -228,9 +248,10 @@ class MappingLoop:
             self.iteration_count += 1
             rand_idx = np.random.randint(0, len(random_viewpoint_stack))
             viewpoint = random_viewpoint_stack[rand_idx]
-            pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
-            loss_mapping = self.loss_fn(self.config["mapping"], pkg["render"], pkg["depth"], viewpoint, pkg["opacity"])
-            loss_mapping.backward()
+            def refine_pass(viewpoint=viewpoint):
+                pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background)
+                return (self.loss_fn(self.config["mapping"], pkg["render"], pkg["depth"], viewpoint, pkg["opacity"]),)
+            self._backward(refine_pass)
             with torch.no_grad():
                 self.gaussians.optimizer.step()
                 self.gaussians.optimizer.zero_grad(set_to_none=True)
