@@ -592,6 +592,14 @@ def main():
                 torch.cuda.empty_cache()
                 trace(name + " done")
 
+    ex = out.get("extra") or {}
+    if ex:        # the headline scene is a FRESH map (mean list 11); what a converged map costs belongs next to the number
+        out["value_context"] = {
+            "headline_scene": "fresh map: ~18 k of 300 k Gaussians visible, ~54 k (tile, Gaussian) pairs per view, lists <= 32",
+            "same_N_surface_covering_map_keyframes_per_s": (ex.get("opaque_scene") or {}).get("keyframes_per_s"),
+            "same_N_surface_covering_map_ms_per_step": (ex.get("opaque_scene") or {}).get("ms_per_step"),
+            "session_ms_per_keyframe_incl_seeding_densify_prune": (ex.get("session") or {}).get("ms_per_keyframe"),
+            "session_keyframes_per_s": (round(1e3 / ex["session"]["ms_per_keyframe"], 2) if (ex.get("session") or {}).get("ms_per_keyframe") else None)}
     if rank == 0:
         print(json.dumps(out))
     if B.dist is not None:

@@ -82,7 +82,9 @@ BATCH = os.environ.get("SPLAT_RASTER_BATCH", "1") != "0"
 # The camera-pose gradients (theta, rho: 3 floats each per view) of a batch are written into `.grad` by the collector -- set, or
 # added in ONE multi-tensor launch -- instead of travelling through 2 AccumulateGrad nodes (+ 2 tiny launches) per view:
 # `loss.backward()` leaves the same `.grad`s as upstream.  0: strict autograd semantics also for torch.autograd.grad / tensor
-# hooks on the pose deltas (the nodes then return the pose gradients themselves).
+# hooks on the pose deltas (the nodes then return the pose gradients themselves).  The C++ nodes (round 4) extend the deferral to
+# every hook-free LEAF whose `.grad` the mapping loop reads -- screenspace_points and the exposure parameters -- and give deferred
+# leaves no autograd edge at all: 60 AccumulateGrad visits less per 12-view backward pass.
 DEFER_POSE_GRADS = os.environ.get("SPLAT_RASTER_DEFER_POSE_GRADS", "1") != "0"
 _RING = 64
 _SENTINEL = 0xFFFFFFFF

@@ -132,5 +132,6 @@ def get_loss_mapping_fused(config, image, depth, viewpoint, opacity, initializat
     a, b = (None, None) if initialization else (viewpoint.exposure_a, viewpoint.exposure_b)
     ext = _native_nodes()
     if ext is not None and image.is_cuda:        # the same launch, its autograd node in C++ (diff_gaussian_rasterization/csrc/dgr_native.cpp)
-        return ext.mapping_loss(image, depth, a, b, gt_image, gt_depth, float(alpha), float(thr))
+        import diff_gaussian_rasterization as drg
+        return ext.mapping_loss(image, depth, a, b, gt_image, gt_depth, float(alpha), float(thr), bool(drg.DEFER_POSE_GRADS))
     return _FusedMappingLoss.apply(image, depth, a, b, gt_image.contiguous(), gt_depth, float(alpha), float(thr))
