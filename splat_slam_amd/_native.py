@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsplat_hip.so")
+# (SPLAT_HIP_LIB: another BUILD of the same library, for A/B measurements of kernel changes -- scripts/micro/ab_hash.py)
+LIB_PATH = os.environ.get("SPLAT_HIP_LIB") or os.path.join(_HERE, "lib", "libsplat_hip.so")
 
 SGR_OPT_FUSED_BLEND = 0
 SGR_OPT_UPSTREAM_POSE_JACOBIAN = 1

@@ -6,8 +6,8 @@
 // /root/reference/src/mapper.py:329,490,699.
 //
 // MI355X design (not the CUDA 16x16-block/atomicAdd scheme):
-//   * a bin is 8x8 pixels = exactly one wave64; a 256-thread workgroup is four independent waves covering one
-//     16x16 reference tile.  Waves never synchronise with each other: no __syncthreads in either kernel.
+//   * a bin is 8x8 pixels = exactly one wave64 = one workgroup (no __syncthreads in either kernel); the four tiles of a
+//     16x16 reference tile run back to back on the same XCD (tile_of_block).
 //   * FORWARD first sorts its tile's (depth bits | Gaussian) keys: <= 64 keys in registers (every lane ranks its key
 //     against the others, broadcast through SGPRs), <= 256 / 4096 keys bitonic in the wave's LDS slice, longer lists in
 //     place in HBM (slow path).  Then it is pixel-parallel (lane = pixel): 64 sorted splats at a time are staged into LDS
@@ -39,13 +39,6 @@ namespace sgr {
 // and backward of a tile in one wave; "mid" / "heavy": 1024 / 4096 64-bit keys bitonic in LDS (3 / 1 workgroups per CU).
 constexpr int kSortLight = 512, kSortMid = 1024, kSortHeavy = 4096;
 constexpr bool sort_in_registers(int sort_max) { return sort_max <= kSortLight; }
-
-// workgroup -> 16x16 super tile with an XCD-aware remap: hardware places block b on XCD b%8, we hand every XCD a
-// contiguous run of super tiles so neighbouring tiles (which share Gaussians) hit the same 4 MiB L2.
-__device__ __forceinline__ int super_tile_of_block(int b, int nblocks) {
-  int per = (nblocks + 7) >> 3;
-  return (b & 7) * per + (b >> 3);   // may be >= nblocks for the tail: caller checks
-}
 
 // Bitonic sort of a[0..n) for ANY n with one wave ("mirror" formulation: every compare-exchange is ascending, so
 // virtual +inf padding behind n never moves).  LOAD/STORE abstract LDS vs. device-coherent global memory.
@@ -210,68 +203,29 @@ __device__ __forceinline__ float group_shr1(float v, float fill, int lane) {
   if (GW == 32) r = (lane == 32) ? fill : r;
   return r;
 }
-// 8-lane groups (two per DPP row): row_shr:1 / :2 leak the upper neighbour group's tail into lanes 8 / 8,9 of the row, so
-// those lanes keep their value (one select per step); row_shr:4 is confined by its bank mask (banks 1 and 3 only).
-__device__ __forceinline__ float group8_scan_mul(float v) {
-  const int l8 = (int)(threadIdx.x & 7);
-  float t = v;
-  asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") : "+v"(t));
-  v = l8 == 0 ? v : t;
-  t = v;
-  asm(SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf") : "+v"(t));
-  v = l8 < 2 ? v : t;
-  asm(SGR_MUL_DPP("row_shr:4 row_mask:0xf bank_mask:0xa") : "+v"(v));
-  return v;
-}
-__device__ __forceinline__ float group8_scan_add(float v) {
-  const int l8 = (int)(threadIdx.x & 7);
-  float t = v;
-  asm(SGR_ADD_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") : "+v"(t));
-  v = l8 == 0 ? v : t;
-  t = v;
-  asm(SGR_ADD_DPP("row_shr:2 row_mask:0xf bank_mask:0xf") : "+v"(t));
-  v = l8 < 2 ? v : t;
-  asm(SGR_ADD_DPP("row_shr:4 row_mask:0xf bank_mask:0xa") : "+v"(v));
-  return v;
-}
+// Groups of 8 / 4 lanes are INTERLEAVED inside their DPP row: the 16 / GW groups of a row own the lanes l16 % (16 / GW), a lane's
+// position inside its group is l16 / (16 / GW).  "The previous lane of my group" is then a plain row_shr:(16 / GW) and a scan step
+// over distance d inside the group a row_shr:(d * 16 / GW), whose out-of-range lanes (the first d lanes of every group: exactly the
+// ones that must keep their value) are disabled by the hardware -- one DPP instruction per step and value.  Contiguous groups
+// (lanes 8..15 = the second group) leaked the lower group's tail through row_shr:1 / :2 and paid a copy and a select per step:
+// 7 instead of 3 (GW = 8) and 6 instead of 2 (GW = 4) instructions per scan and pixel, 16 of the ~88 of an iteration.
+#define SGR_SCAN2_IL8(OP)                                                                                       \
+  "s_nop 1\n\t" SGR_DPP2(OP, "row_shr:2 row_mask:0xf bank_mask:0xf") SGR_DPP2(OP, "row_shr:4 row_mask:0xf bank_mask:0xf") \
+      SGR_DPP2(OP, "row_shr:8 row_mask:0xf bank_mask:0xf") "s_nop 0"
+#define SGR_SCAN2_IL4(OP) \
+  "s_nop 1\n\t" SGR_DPP2(OP, "row_shr:4 row_mask:0xf bank_mask:0xf") SGR_DPP2(OP, "row_shr:8 row_mask:0xf bank_mask:0xf") "s_nop 0"
 template <>
-__device__ __forceinline__ void group_scan_mul2<8>(float& a, float& b) { a = group8_scan_mul(a); b = group8_scan_mul(b); }
+__device__ __forceinline__ void group_scan_mul2<8>(float& a, float& b) { asm(SGR_SCAN2_IL8("mul") : "+v"(a), "+v"(b)); }
 template <>
-__device__ __forceinline__ void group_scan_add2<8>(float& a, float& b) { a = group8_scan_add(a); b = group8_scan_add(b); }
+__device__ __forceinline__ void group_scan_add2<8>(float& a, float& b) { asm(SGR_SCAN2_IL8("add") : "+v"(a), "+v"(b)); }
 template <>
-__device__ __forceinline__ float group_shr1<8>(float v, float fill, int lane) {
-  float r = dpp_f<DPP_ROW_SHR1>(fill, v);
-  return (lane & 7) == 0 ? fill : r;
-}
-
-// 4-lane groups (lists <= 4: a quarter of a fresh map's tiles): two steps, 32 pixels per iteration
-__device__ __forceinline__ float group4_scan_mul(float v) {
-  const int l4 = (int)(threadIdx.x & 3);
-  float t = v;
-  asm(SGR_MUL_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") : "+v"(t));
-  v = l4 == 0 ? v : t;
-  t = v;
-  asm(SGR_MUL_DPP("row_shr:2 row_mask:0xf bank_mask:0xf") : "+v"(t));
-  return l4 < 2 ? v : t;
-}
-__device__ __forceinline__ float group4_scan_add(float v) {
-  const int l4 = (int)(threadIdx.x & 3);
-  float t = v;
-  asm(SGR_ADD_DPP("row_shr:1 row_mask:0xf bank_mask:0xf") : "+v"(t));
-  v = l4 == 0 ? v : t;
-  t = v;
-  asm(SGR_ADD_DPP("row_shr:2 row_mask:0xf bank_mask:0xf") : "+v"(t));
-  return l4 < 2 ? v : t;
-}
+__device__ __forceinline__ float group_shr1<8>(float v, float fill, int) { return dpp_f<DPP_ROW_SHR2>(fill, v); }
 template <>
-__device__ __forceinline__ void group_scan_mul2<4>(float& a, float& b) { a = group4_scan_mul(a); b = group4_scan_mul(b); }
+__device__ __forceinline__ void group_scan_mul2<4>(float& a, float& b) { asm(SGR_SCAN2_IL4("mul") : "+v"(a), "+v"(b)); }
 template <>
-__device__ __forceinline__ void group_scan_add2<4>(float& a, float& b) { a = group4_scan_add(a); b = group4_scan_add(b); }
+__device__ __forceinline__ void group_scan_add2<4>(float& a, float& b) { asm(SGR_SCAN2_IL4("add") : "+v"(a), "+v"(b)); }
 template <>
-__device__ __forceinline__ float group_shr1<4>(float v, float fill, int lane) {
-  float r = dpp_f<DPP_ROW_SHR1>(fill, v);
-  return (lane & 3) == 0 ? fill : r;
-}
+__device__ __forceinline__ float group_shr1<4>(float v, float fill, int) { return dpp_f<DPP_ROW_SHR4>(fill, v); }
 
 // The hot loop of the backward, TWO pixels per lane.  blend_bwd is bound by VALU issue (one wave64 op = 4 cycles), and
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot), so every lane carries its splat
@@ -336,17 +290,18 @@ struct SrcStaged {
 // One chunk = the list positions [start, start + GW) (those below `end`) against the 64 pixels of the tile, 2*64/GW pixels
 // per iteration.  Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix
 // scan.  Chunks run back to front; `carry`: more (nearer) chunks follow, leave (T, S) in front of this chunk per pixel.
-// LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | nc0,nc1, -,-) for pair g.
+// LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | nc0,nc1, x0,y) for pair g.
 template <int GW, typename SRC>
 __device__ __forceinline__ void bwd_chunk2(
-    int lane, int start, int end, bool carry, float tx0, float ty0, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
+    int lane, int start, int end, bool carry, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
     const LOff& L, float4* __restrict__ partials) {
   constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
   // (opaque to the optimiser: the five instantiations sit in one loop, and hoisting each one's lane arithmetic out of it
   //  cost more live registers than the kernel has at 5 waves per SIMD -- they were spilled to scratch: +37 MB of writes per launch)
   asm volatile("" : "+v"(lane));
-  const int sub = lane / GW;                     // which of them this lane works on
-  const int sl = lane % GW;
+  constexpr int GPR = GW < 16 ? 16 / GW : 1;     // groups per DPP row (narrow groups are interleaved inside their row, see above)
+  const int sub = GW < 16 ? (lane >> 4) * GPR + (lane & (GPR - 1)) : lane / GW;      // which of them this lane works on
+  const int sl = GW < 16 ? (lane & 15) / GPR : lane % GW;                            // its position inside its group
   const int idx = start + (GW - 1 - sl);         // list position of this lane's splat
   const bool valid = idx < end;
   float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
@@ -363,12 +318,13 @@ __device__ __forceinline__ void bwd_chunk2(
     const int gp = it * PP + sub;                // this lane's pixel pair (same for the whole group)
     const float4 a0 = pixA2[gp * 2], a1 = pixA2[gp * 2 + 1];     // LDS, broadcast inside the group
     const float4 b0 = pixB2[gp * 2];
-    const float2 b1 = *(const float2*)&pixB2[gp * 2 + 1];
+    const float4 b1 = pixB2[gp * 2 + 1];
     const int nc0 = __float_as_int(b1.x), nc1 = __float_as_int(b1.y);
     if (GW == kWave && __builtin_amdgcn_readfirstlane(max(nc0, nc1)) <= start) continue;   // both ended before this chunk
-    const int p0 = 2 * gp;                                     // pixels p0, p0 + 1: same row
-    const v2f dx = splat2(mx) - (v2f){tx0 + (float)(p0 & 7), tx0 + (float)((p0 & 7) + 1)};
-    const v2f dy = splat2(my) - splat2(ty0 + (float)(p0 >> 3));
+    // pixels 2 gp, 2 gp + 1 (same row): their coordinates were staged with the pixel state (b1.z = x of the first, b1.w = y; both
+    // exact integers) -- rebuilding them from gp cost 8 of an iteration's instructions
+    const v2f dx = splat2(mx) - (v2f){b1.z, b1.z + 1.f};
+    const v2f dy = splat2(my) - splat2(b1.w);
     // eval_alpha() on the pair, same operation order
     const v2f adx = splat2(A) * dx;
     const v2f cdy2 = (splat2(Cc) * dy) * dy;
@@ -468,17 +424,18 @@ __device__ __forceinline__ void bwd_chunk2(
                "v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %5\n\ts_nop 1"
                : "+v"(u01), "+v"(u23), "+v"(u4), "+v"(w1), "+v"(w3), "+v"(w4));
   // rows: u01 = gx | gxx | o | g,  u23 = gy | gxy | r | b,  u4 = gyy | gyy | d | d   (complete for GW = 16)
+  // the groups of a row (interleaved: lane ^ 1 for two, lane ^ 2 then lane ^ 1 for four -- the pairing order of the contiguous layout)
+  if (GW == 4)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(u01), "+v"(u23), "+v"(u4));
   if (GW <= 8)
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
                  : "+v"(u01), "+v"(u23), "+v"(u4));
-  if (GW <= 4)
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-                 : "+v"(u01), "+v"(u23), "+v"(u4));
-  if ((lane & 15) < GW && slot != 0xffffffffu) {       // the first group of every row stores that row's floats
+  if ((lane & (GPR - 1)) == 0 && slot != 0xffffffffu) {       // the first group of every row stores that row's floats
     const int row = lane >> 4;
     *(float2*)(out + 2 * row) = make_float2(u01, u23);
     if (!(row & 1)) out[8 + (row >> 1)] = u4;            // row 0: gyy, row 2: d
@@ -500,12 +457,10 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
     float* fb = (float*)pixB + (lane >> 1) * 8 + (lane & 1);
     fa[0] = pxA[0]; fa[2] = pxA[1]; fa[4] = pxA[2]; fa[6] = pxA[3];
     fb[0] = pxB[0]; fb[2] = pxB[1]; fb[4] = pxB[2];
+    fb[6] = (lane & 1) ? (float)(ty * kTile + (lane >> 3)) : (float)(tx * kTile + (lane & 7));     // the pair's x0 | y
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  // wave-uniform floats are pinned to SGPRs (the compiler keeps converted integers in VGPRs: at 96 registers every one counts)
-  auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-  const float tx0 = uniform((float)(tx * kTile)), ty0 = uniform((float)(ty * kTile));
   // The list is cut into chunks of 64 / 32 / 16 / 8 / 4 splats from the far end: a lane = a splat, and a chunk of width GW works
   // on 64 / GW pixel pairs at once, so a chunk costs 32 * GW / 64 iterations of the loop above whatever part of its lanes is
   // filled.  One 64-wide chunk per started 64 splats left the lists of a converged map (33-256) at 55-75 % lane use; the
@@ -513,14 +468,15 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
   // rounded up when the chunk would be at least 3/4 full (the per-chunk epilogue costs about one iteration).
   int end = eff;
   while (end > 0) {
-    const int gw = end >= 48 ? 64 : (end >= 24 ? 32 : (end >= 12 ? 16 : (end >= 5 ? 8 : 4)));
+    const int gw = (L.dbg & 1024) ? (end >= 61 ? 64 : (end >= 29 ? 32 : (end >= 13 ? 16 : (end >= 5 ? 8 : 4))))
+                                  : (end >= 48 ? 64 : (end >= 24 ? 32 : (end >= 12 ? 16 : (end >= 5 ? 8 : 4))));
     const int start = gw >= end ? 0 : end - gw;
     const bool carry = start > 0;
-    if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
-    else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
-    else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
-    else if (gw == 8) bwd_chunk2<8>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
-    else bwd_chunk2<4>(lane, start, end, carry, tx0, ty0, pixA, pixB, src, L, partials);
+    if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, pixA, pixB, src, L, partials);
+    else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, pixA, pixB, src, L, partials);
+    else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, pixA, pixB, src, L, partials);
+    else if (gw == 8) bwd_chunk2<8>(lane, start, end, carry, pixA, pixB, src, L, partials);
+    else bwd_chunk2<4>(lane, start, end, carry, pixA, pixB, src, L, partials);
     end = start;
     if (carry) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -542,30 +498,23 @@ __device__ __forceinline__ float sign_code(uint32_t c, float k) { return (c & 1u
 // per 256-thread block, 16 lanes per segment copy that segment's list (K1) to its place -- segment base = the visible counts of
 // the segments in front, which the block adds up itself (<= a few thousand values).  It used to be a set of blocks of K2, on the
 // critical path between K1 and the tile kernels (K2 17.6 -> 13.6 us without them); nothing before the backward reads the list.
-constexpr int kCompSegs = 16;
+constexpr int kCompSegs = 4;
 __device__ __forceinline__ int comp_blocks(const LOff& L) { return (((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7; }   // (x8: XCD mapping)
-__device__ __forceinline__ void compact_visible_list(char* saved, const LOff& L, int j, uint32_t* lds /* >= 4 + kCompSegs words */) {
+__device__ __forceinline__ void compact_visible_list(char* saved, const LOff& L, int j) {       // one wave
   const uint32_t* __restrict__ bv = (const uint32_t*)(saved + L.o_block_vis);
-  const int seg0 = j * kCompSegs;
+  const int seg0 = j * kCompSegs, lane = threadIdx.x;
   if (seg0 >= L.nseg) return;
   uint32_t before = 0;
-  for (int i = threadIdx.x; i < seg0; i += 256) before += bv[i];
-  before = wave_scan_add_u32(before);
-  if ((threadIdx.x & 63) == 63) lds[threadIdx.x >> 6] = before;
-  const int ls = threadIdx.x >> 4, sub = threadIdx.x & 15;
+  for (int i = lane; i < seg0; i += kWave) before += bv[i];
+  before = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add_u32(before), 63);
+  const int ls = lane >> 4, sub = lane & 15;
   const uint32_t c = seg0 + ls < L.nseg ? bv[seg0 + ls] : 0u;
-  __syncthreads();
-  if (threadIdx.x < 64) {                       // exclusive scan of the block's counts by one wave
-    const uint32_t pre = lds[0] + lds[1] + lds[2] + lds[3];
-    const uint32_t mine = ((int)threadIdx.x < kCompSegs && seg0 + (int)threadIdx.x < L.nseg) ? bv[seg0 + threadIdx.x] : 0u;
-    const uint32_t ex = pre + wave_scan_add_u32(mine) - mine;
-    if ((int)threadIdx.x < kCompSegs) lds[4 + threadIdx.x] = ex;
-  }
-  __syncthreads();
+  const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, 0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)c, 16),
+                 c2 = (uint32_t)__builtin_amdgcn_readlane((int)c, 32);
+  const uint32_t b = before + (ls > 0 ? c0 : 0u) + (ls > 1 ? c1 : 0u) + (ls > 2 ? c2 : 0u);
   const uint32_t* __restrict__ seg_list = (const uint32_t*)(saved + L.o_seg_list);
   uint32_t* __restrict__ vis_list = (uint32_t*)(saved + L.o_vis_list);
   GRec* __restrict__ grec = (GRec*)(saved + L.o_grec);
-  const uint32_t b = lds[4 + ls];
   for (uint32_t k = sub; k < c; k += 16) {
     const uint32_t i = seg_list[(size_t)(seg0 + ls) * kSeg + k];
     grec[i].vis_pos = b + k;
@@ -573,8 +522,23 @@ __device__ __forceinline__ void compact_visible_list(char* saved, const LOff& L,
   }
 }
 
+// Workgroup = ONE wave = one 8x8 tile.  The four waves of a 16x16 super tile used to share a 256-thread workgroup: they never
+// synchronise, but a workgroup's LDS (5 workgroups per CU) is released only when its LAST wave retires, and the four lists of a
+// super tile differ in length -- the counters showed 3.7 resident waves per SIMD on average where the registers allow 5.
+// tile_of_block(): hardware places block b on XCD b % 8; every XCD gets a contiguous run of super tiles and walks it tile by tile, so
+// neighbouring tiles (which share Gaussians) still hit the same 4 MiB L2 at about the same time.
+__device__ __forceinline__ bool tile_of_block(int b, int sgx, int sgy, int& tx, int& ty) {
+  const int nsuper = sgx * sgy, per = (nsuper + 7) >> 3;
+  const int j = b >> 3, st = (b & 7) * per + (j >> 2), wv = j & 3;
+  if (st >= nsuper || j >= 4 * per) return false;
+  tx = (st % sgx) * 2 + (wv & 1);
+  ty = (st / sgx) * 2 + (wv >> 1);
+  return true;
+}
+__device__ __forceinline__ int tile_blocks(int sgx, int sgy) { return 8 * 4 * ((sgx * sgy + 7) >> 3); }
+
 template <int SORT_MAX, bool FUSED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TILE_WAVES))) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TILE_WAVES))) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
                                                         LossCoef lc) {
   const int vw = blockIdx.y;
   char* saved = tab.saved[vw];
@@ -590,19 +554,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
   float2* __restrict__ pix_state = (float2*)(saved + L.o_final_T);
   uint32_t* __restrict__ tile_maxc = (uint32_t*)(saved + L.o_tile_maxc);
   int32_t* __restrict__ n_touched = tab.n_touched[vw];
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // per wave: SORT_MAX sorted ids (4 B) or keys (8 B) + 64 splats x 48 B (+ FUSED: 2 x 64 float4 of pixel state)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // SORT_MAX sorted ids (4 B) or keys (8 B) + 64 splats x 48 B (+ FUSED: 2 x 64 float4 of pixel state)
   constexpr bool REGSORT = sort_in_registers(SORT_MAX);
   constexpr size_t kKeyBytes = REGSORT ? 4 : 8;
-  constexpr size_t kSlice = (size_t)SORT_MAX * kKeyBytes + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0);
-  const int nblocks = sgx * sgy;
   const int ncomp = comp_blocks(L);             // the first blocks of the launch: the view's compact visible list (see above)
-  if ((int)blockIdx.x < ncomp) { compact_visible_list(saved, L, (int)blockIdx.x, (uint32_t*)smem); return; }
-  const int st = super_tile_of_block((int)blockIdx.x - ncomp, nblocks);
-  if (st >= nblocks) return;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave-uniform: tile state in SGPRs
+  if ((int)blockIdx.x < ncomp) { compact_visible_list(saved, L, (int)blockIdx.x); return; }
+  int tx, ty;
+  if (!tile_of_block((int)blockIdx.x - ncomp, sgx, sgy, tx, ty)) return;
+  const int lane = threadIdx.x;
   constexpr int kLdsSortMax = SORT_MAX;
-  char* slice = smem + (size_t)wv * kSlice;
-  const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
+  char* slice = smem;
   if (tx >= gx || ty >= gy) return;          // whole wave outside the image
   const int tile = ty * gx + tx;
   const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
@@ -717,7 +678,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
   float T = 1.f;
   v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, Dd = {0.f, 0.f};   // (even, odd) list positions, added at the end
   uint32_t last = 0;
-  bool done = !inside;
+  bool done = !inside || (L.dbg & 2048);       // (bit 11, EXPERIMENT: no walk, no backward -- what the rest of a tile's wave costs)
   const v2f px2 = splat2(pxf), py2 = splat2(pyf);
 
   for (int base = 0; base < count; base += kWave) {
@@ -849,7 +810,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
 
   // ---- the backward of this tile, right here
   if (count == 0) return;
-  const int eff = min(count, (int)mx);
+  const int eff = (L.dbg & 4096) ? 0 : min(count, (int)mx);      // (bit 12, EXPERIMENT: no backward)
   float4* __restrict__ partials = (float4*)(tab.scratch[vw] + L.o_partials);
   // pairs the walk never reached (behind every pixel's last contributor) still own a slot: define it as zero
   const float k_rgb = lc.w_rgb * (lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f);     // the floats blend_bwd<true> rebuilds from the code byte
@@ -887,7 +848,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_TI
 }
 
 template <bool PACKED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES))) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES))) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
   const int vw = blockIdx.y;
   const char* saved = tab.saved[vw];
   const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
@@ -900,12 +861,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_BW
   const float* __restrict__ dL_dcolor = tab.dL_dcolor[vw];
   const float* __restrict__ dL_ddepth = tab.dL_ddepth[vw];
   float4* __restrict__ partials = (float4*)(tab.scratch[vw] + L.o_partials);
-  __shared__ float4 pixbuf[4][2][kWave];      // per wave: pixel gradients + running (T, S) carries
-  const int nblocks = sgx * sgy;
-  const int st = super_tile_of_block(blockIdx.x, nblocks);
-  if (st >= nblocks) return;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave-uniform: tile state in SGPRs
-  const int tx = (st % sgx) * 2 + (wv & 1), ty = (st / sgx) * 2 + (wv >> 1);
+  __shared__ float4 pixbuf[2][kWave];         // pixel gradients + running (T, S) carries
+  int tx, ty;
+  if (!tile_of_block((int)blockIdx.x, sgx, sgy, tx, ty)) return;
+  const int lane = threadIdx.x;
   if (tx >= gx || ty >= gy) return;
   const int tile = ty * gx + tx;
   // this pixel's state first: its six loads do not depend on the tile's list and overlap the range / list round trips
@@ -950,21 +909,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGR_BW
   }
   if (eff == 0) return;
   const SrcPointList src = {point_list, begin, grec, saved, tx, ty, cap};
-  tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixbuf[wv][0], pixbuf[wv][1], src, L, partials);
+  tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixbuf[0], pixbuf[1], src, L, partials);
 }
 
 template <int SORT_MAX, bool FUSED>
 static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab& lt,
                                const LossCoef& lc, hipStream_t st) {
-  int nblocks = L.sgx * L.sgy;
-  int grid = ((nblocks + 7) / 8) * 8 + ((((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7);
-  constexpr size_t lds = 4 * ((size_t)SORT_MAX * (sort_in_registers(SORT_MAX) ? 4 : 8) + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0));
+  int grid = 8 * 4 * ((L.sgx * L.sgy + 7) / 8) + ((((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7);
+  constexpr size_t lds = (size_t)SORT_MAX * (sort_in_registers(SORT_MAX) ? 4 : 8) + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((blend_fwd_kernel<SORT_MAX, FUSED>), dim3(grid, nviews), dim3(256), lds, st, tab, L, bg, lt, lc);
+  hipLaunchKernelGGL((blend_fwd_kernel<SORT_MAX, FUSED>), dim3(grid, nviews), dim3(kWave), lds, st, tab, L, bg, lt, lc);
 }
 
 // 0 light / 1 mid / 2 heavy from the longest list the caller has MEASURED for the cameras of the batch (max_list_hint =
@@ -1009,16 +967,15 @@ void launch_blend_fused(const ViewTab& tab, int nviews, const LOff& L, const flo
 // lt / lc given: the pixel gradients are the code bytes blend_fwd's loss epilogue wrote for these views
 void launch_blend_bwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab* lt, const LossCoef* lc,
                       hipStream_t st) {
-  int nblocks = L.sgx * L.sgy;
-  int grid = ((nblocks + 7) / 8) * 8;
+  int grid = 8 * 4 * ((L.sgx * L.sgy + 7) / 8);
   ProfScope prof(PK_BLEND_BWD, st);
   SignGrad sg = {};
   if (lt && lc) {
     for (int v = 0; v < nviews; ++v) sg.exp_a[v] = lt->exp_a[v];
     sg.w_rgb = lc->w_rgb; sg.w_dep = lc->w_dep;
-    hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid, nviews), dim3(256), 0, st, tab, L, bg, sg);
+    hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid, nviews), dim3(kWave), 0, st, tab, L, bg, sg);
   } else {
-    hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid, nviews), dim3(256), 0, st, tab, L, bg, sg);
+    hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid, nviews), dim3(kWave), 0, st, tab, L, bg, sg);
   }
 }
 
