@@ -156,10 +156,22 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // maximum o
   asm(SGR_ROW_STEPS(SGR_MAX1) "s_nop 1" : "+v"(v));
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ void wave_sum4(float& a, float& b, float& c, float& d) {   // four totals, in every lane
-  // (interleaved: three independent instructions separate dependent DPP steps, no wait states needed)
-  asm("s_nop 1\n\t" SGR_ROW_STEPS(SGR_ADD4) "s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-  a = readlane_f(a, 63); b = readlane_f(b, 63); c = readlane_f(c, 63); d = readlane_f(d, 63);
+// Four wave totals at once: the HALVES of the wave trade places (v_permlane32_swap: a.hi <-> b.lo), so one swap + one add folds TWO
+// values over the half-wave distance; v_permlane16_swap does the same over the row distance; the last 16 lanes are four DPP row
+// rotations of ONE register.  10 instructions where four separate DPP reductions took 24 + 4 readlanes.  Returns, in lane 0 of
+// row r (lanes 0, 16, 32, 48): the total of a, c, b, d (in this order).  Fixed association: bitwise reproducible.
+__device__ __forceinline__ float wave_sum4_rows(float a, float b, float c, float d) {
+  asm("s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1\n\t"
+      "v_add_f32 %0, %0, %1\n\tv_add_f32 %2, %2, %3\n\ts_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %2\n\ts_nop 1\n\t"
+      "v_add_f32 %0, %0, %2\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  return a;
 }
 
 // Per-pixel state that only the two blend kernels exchange is stored TILE-major (index tile * 64 + lane): a wave then
@@ -231,7 +243,7 @@ __device__ __forceinline__ float group_shr1<4>(float v, float fill, int) { retur
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot), so every lane carries its splat
 // against a horizontally adjacent pixel PAIR in 2-vectors: the quadratic form, the colour dot product, alpha*T and all
 // ten accumulate FMAs issue once per pair; only the DPP scans, exp/rcp and the selects stay per pixel.  Every packed op
-// is the same IEEE operation sequence as eval_alpha(), so forward and backward still agree bit for bit on which pairs
+// is the same IEEE operation sequence as the forward walk's, so forward and backward still agree bit for bit on which pairs
 // contribute.  Branch free: a pair that does not contribute has alpha*T = 0 and G*dL/dalpha = 0.
 // (A matrix-core variant -- the 16-lane-group layout is exactly the A/B operand layout of v_mfma_f32_16x16x4_f32, the
 // ten sums being two small GEMMs over the pixels -- cut the instruction count by 20 % but ran 8 % slower: fp32 MFMA
@@ -302,7 +314,7 @@ __device__ __forceinline__ void bwd_chunk2(
   constexpr int GPR = GW < 16 ? 16 / GW : 1;     // groups per DPP row (narrow groups are interleaved inside their row, see above)
   const int sub = GW < 16 ? (lane >> 4) * GPR + (lane & (GPR - 1)) : lane / GW;      // which of them this lane works on
   const int sl = GW < 16 ? (lane & 15) / GPR : lane % GW;                            // its position inside its group
-  const int idx = start + (GW - 1 - sl);         // list position of this lane's splat
+  int idx = start + (GW - 1 - sl);               // list position of this lane's splat
   const bool valid = idx < end;
   float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
   uint32_t slot = 0xffffffffu;                   // this (tile, Gaussian) pair's slot inside the Gaussian's run of partials
@@ -310,35 +322,43 @@ __device__ __forceinline__ void bwd_chunk2(
     const SplatRec sr = src.load(idx, L);
     mx = sr.mx; my = sr.my; A = sr.A; B = sr.B; Cc = sr.C; op = sr.op; cr = sr.r; cg = sr.g; cb = sr.b; dep = sr.dep; slot = sr.slot;
   }
-  v2f s_gx = {0.f, 0.f}, s_gy = {0.f, 0.f}, s_gxx = {0.f, 0.f}, s_gxy = {0.f, 0.f}, s_gyy = {0.f, 0.f};
-  v2f a_o = {0.f, 0.f}, a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
+  if (!valid) idx = 0x7fffffff;                  // (an empty lane is behind every pixel's last contributor: `idx < nc` rejects it)
+  v2f s_gx, s_gy, s_gxx, s_gxy, s_gyy, a_o, a_r, a_g, a_b, a_d;       // (64-bit moves: the compiler cleared the twenty halves one by one)
+  asm("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0\n\t"
+      "v_mov_b64 %5, 0\n\tv_mov_b64 %6, 0\n\tv_mov_b64 %7, 0\n\tv_mov_b64 %8, 0\n\tv_mov_b64 %9, 0"
+      : "=v"(s_gx), "=v"(s_gy), "=v"(s_gxx), "=v"(s_gxy), "=v"(s_gyy), "=v"(a_o), "=v"(a_r), "=v"(a_g), "=v"(a_b), "=v"(a_d));
 
 #pragma unroll 1
   for (int it = 0; it < 32 / PP; ++it) {
     const int gp = it * PP + sub;                // this lane's pixel pair (same for the whole group)
     const float4 a0 = pixA2[gp * 2], a1 = pixA2[gp * 2 + 1];     // LDS, broadcast inside the group
     const float4 b0 = pixB2[gp * 2];
-    const float4 b1 = pixB2[gp * 2 + 1];
+    float4 b1 = pixB2[gp * 2 + 1];
+    asm volatile("" : "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));      // (one ds_read_b128: the compiler split it into three reads)
     const int nc0 = __float_as_int(b1.x), nc1 = __float_as_int(b1.y);
     if (GW == kWave && __builtin_amdgcn_readfirstlane(max(nc0, nc1)) <= start) continue;   // both ended before this chunk
     // pixels 2 gp, 2 gp + 1 (same row): their coordinates were staged with the pixel state (b1.z = x of the first, b1.w = y; both
     // exact integers) -- rebuilding them from gp cost 8 of an iteration's instructions
     const v2f dx = splat2(mx) - (v2f){b1.z, b1.z + 1.f};
     const v2f dy = splat2(my) - splat2(b1.w);
-    // eval_alpha() on the pair, same operation order
+    // the forward walk's footprint evaluation on the pair, same operation order
     const v2f adx = splat2(A) * dx;
     const v2f cdy2 = (splat2(Cc) * dy) * dy;
     const v2f qf = __builtin_elementwise_fma(adx, dx, cdy2);
     const v2f bdxdy = (splat2(B) * dx) * dy;
     const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
     const v2f G = {exp2_fast(power.x), exp2_fast(power.y)};      // (the conic carries log2(e))
-    const v2f og = splat2(op) * G;
-    v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
-    const bool ok0 = valid && (idx < nc0) && (power.x <= 0.0f) && (alpha.x >= kAlphaMin);
-    const bool ok1 = valid && (idx < nc1) && (power.y <= 0.0f) && (alpha.y >= kAlphaMin);
-    // a pair that does not contribute takes part with alpha = 0: factor 1 in the product, weight 0 in the sums
-    alpha.x = ok0 ? alpha.x : 0.f;
-    alpha.y = ok1 ? alpha.y : 0.f;
+    v2f og = splat2(op) * G;
+    // (alpha = min(0.99, og) >= 1/255  <=>  og >= 1/255: the test does not wait for the clamp)
+    const bool ok0 = (idx < nc0) && (power.x <= 0.0f) && (og.x >= kAlphaMin);
+    const bool ok1 = (idx < nc1) && (power.y <= 0.0f) && (og.y >= kAlphaMin);
+    // a pair that does not contribute takes part with opacity * G = 0: alpha = 0 (factor 1 in the product, weight 0 in the sums) and
+    // G dL/dG = 0 -- ONE select per pixel masks everything downstream
+    og.x = ok0 ? og.x : 0.f;
+    og.y = ok1 ? og.y : 0.f;
+    static_assert(kAlphaMax == 0.99f, "the literal 0x3f7d70a4 below is 0.99f");
+    v2f alpha;                                           // min(0.99, og) (as asm: behind a select fminf() first canonicalises its operand)
+    asm("v_min_f32 %0, 0x3f7d70a4, %2\n\tv_min_f32 %1, 0x3f7d70a4, %3" : "=&v"(alpha.x), "=v"(alpha.y) : "v"(og.x), "v"(og.y));
     const v2f one_m = splat2(1.f) - alpha;
     float P0 = one_m.x, P1 = one_m.y;
     group_scan_mul2<GW>(P0, P1);                         // prod over this splat and all behind it (in chunk)
@@ -366,11 +386,8 @@ __device__ __forceinline__ void bwd_chunk2(
     a_g = __builtin_elementwise_fma(aT, dCg, a_g);
     a_b = __builtin_elementwise_fma(aT, dCb, a_b);
     a_d = __builtin_elementwise_fma(aT, dD, a_d);
-    v2f gd = G * dL_dalpha;                              // dL/dopacity contribution; alpha clamp is straight-through
-    gd.x = ok0 ? gd.x : 0.f;
-    gd.y = ok1 ? gd.y : 0.f;
-    a_o += gd;
-    const v2f gg = gd * splat2(op);                      // G * dL/dG
+    const v2f gg = og * dL_dalpha;                       // G * dL/dG = opacity * G * dL/dalpha (the alpha clamp is straight-through)
+    a_o += gg;                                           // dL/dopacity = sum G dL/dalpha = (this sum) / opacity, divided once after the loop
     const v2f gxv = gg * dx, gyv = gg * dy;
     s_gx += gxv;
     s_gy += gyv;
@@ -379,8 +396,8 @@ __device__ __forceinline__ void bwd_chunk2(
     s_gyy = __builtin_elementwise_fma(gyv, dy, s_gyy);
   }
   float t_gx = s_gx.x + s_gx.y, t_gy = s_gy.x + s_gy.y, t_gxx = s_gxx.x + s_gxx.y, t_gxy = s_gxy.x + s_gxy.y,
-        t_gyy = s_gyy.x + s_gyy.y, t_o = a_o.x + a_o.y, t_r = a_r.x + a_r.y, t_g = a_g.x + a_g.y, t_b = a_b.x + a_b.y,
-        t_d = a_d.x + a_d.y;
+        t_gyy = s_gyy.x + s_gyy.y, t_o = (a_o.x + a_o.y) * (op > 0.f ? __builtin_amdgcn_rcpf(op) : 0.f), t_r = a_r.x + a_r.y,
+        t_g = a_g.x + a_g.y, t_b = a_b.x + a_b.y, t_d = a_d.x + a_d.y;
   // The slot of this (tile, Gaussian) pair, 12 floats: gx gy gxx gxy | o r g b | gyy d - -  (RAW sums: the conic / half-image
   // factors that turn them into dL/dmean2D and dL/dconic are per Gaussian, the dense backward applies them once to the sum over
   // the Gaussian's tiles; the last 8 bytes are padding, never written or read).
@@ -704,7 +721,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // Two splats per trip, branch free.  blend_fwd is VALU-issue bound like the backward, so the footprint (eval_alpha's
+    // Two splats per trip, branch free.  blend_fwd is VALU-issue bound like the backward, so the footprint (the same
     // operation sequence, packed), alpha * T and the four accumulate FMAs issue once per PAIR (v_pk_*_f32); exp, the
     // tests and the transmittance chain stay per splat.  The "every pixel finished" exit is polled every 4 splats.
     auto walk = [&](auto count_touched) {
@@ -721,8 +738,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         const v2f G = {exp2_fast(power.x), exp2_fast(power.y)};      // (the staged conic carries log2(e))
         const v2f og = (v2f){q2.z, q2.w} * G;
         const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
-        const bool ok0 = (power.x <= 0.0f) && (alpha.x >= kAlphaMin);
-        const bool ok1 = (power.y <= 0.0f) && (alpha.y >= kAlphaMin);
+        const bool ok0 = (power.x <= 0.0f) && (og.x >= kAlphaMin);          // (<=> alpha >= 1/255; the backward tests the same value)
+        const bool ok1 = (power.y <= 0.0f) && (og.y >= kAlphaMin);
         const v2f one_m = splat2(1.f) - alpha;
         const float test0 = T * one_m.x;
         const bool live0 = !done && ok0;
@@ -803,8 +820,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   }
   if (!FUSED && gt_image && code_bytes_tiled(L)) ((uint8_t*)lt.dimage[vw])[tpix] = (uint8_t)code;
   if (gt_image) {      // uniform per view
-    wave_sum4(l_rgb, l_dep, l_da, l_db);
-    if (lane == 0) ((LossPart*)lt.parts[vw])[tile] = {l_rgb, l_dep, l_da, l_db};
+    const float tot = wave_sum4_rows(l_rgb, l_dep, l_da, l_db);          // rows: |rgb|, d/da, |depth|, d/db
+    const int row = lane >> 4;
+    if ((lane & 15) == 0) ((float*)((LossPart*)lt.parts[vw] + tile))[row == 1 ? 2 : (row == 2 ? 1 : row)] = tot;
   }
   if (!FUSED) return;
 

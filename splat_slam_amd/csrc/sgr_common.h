@@ -348,19 +348,6 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 
-// The one definition of a splat's footprint at a pixel.  Forward and backward MUST agree bit-for-bit on the
-// skip decisions, so both call this and the multiply/add order is pinned with explicit fma's.
-struct AlphaEval { float power, G, alpha; bool ok; };
-__device__ __forceinline__ AlphaEval eval_alpha(float dx, float dy, float A, float B, float C, float opac) {
-  AlphaEval r;
-  float q = __fmaf_rn(A * dx, dx, (C * dy) * dy);
-  r.power = __fmaf_rn(-0.5f, q, -(B * dx) * dy);
-  r.G = __expf(r.power);
-  r.alpha = fminf(kAlphaMax, opac * r.G);
-  r.ok = (r.power <= 0.0f) && (r.alpha >= kAlphaMin);
-  return r;
-}
-
 // ---- wave64 DPP scans (gfx9 DPP: row_shr within 16 lanes, row_bcast across rows)
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ float dpp_f(float old, float v) {
