@@ -239,6 +239,33 @@ __device__ __forceinline__ void group_scan_add2<4>(float& a, float& b) { asm(SGR
 template <>
 __device__ __forceinline__ float group_shr1<4>(float v, float fill, int) { return dpp_f<DPP_ROW_SHR4>(fill, v); }
 
+// Two uses of "the previous lane of my group" that fold into ONE DPP instruction each (per pixel of the pair):
+//   prev_times(): r = prev(p) * m, the group's first lane (no previous lane: its DPP source is out of range, the lane is disabled and
+//                 keeps what r held) gets 1 * m -- r is preset to m;
+//   prev_plus(): prev(q) + c, the first lane gets 0 + c (bound_ctrl:0 reads an out-of-range source as zero).
+// GW = 32 has a first lane in the middle of the wave-wide shift (lane 32): one select puts it right.
+#define SGR_PREV2(INS, CTRL, TAIL) "s_nop 1\n\t" INS " %0, %2, %4 " CTRL " row_mask:0xf bank_mask:0xf" TAIL "\n\t" INS " %1, %3, %5 " CTRL " row_mask:0xf bank_mask:0xf" TAIL "\n\ts_nop 1"
+template <int GW>
+__device__ __forceinline__ v2f prev_times(float p0, float p1, v2f m, int lane) {
+  v2f r = m;
+  if constexpr (GW == 16) asm(SGR_PREV2("v_mul_f32_dpp", "row_shr:1", "") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1), "v"(m.x), "v"(m.y));
+  else if constexpr (GW == 8) asm(SGR_PREV2("v_mul_f32_dpp", "row_shr:2", "") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1), "v"(m.x), "v"(m.y));
+  else if constexpr (GW == 4) asm(SGR_PREV2("v_mul_f32_dpp", "row_shr:4", "") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1), "v"(m.x), "v"(m.y));
+  else asm(SGR_PREV2("v_mul_f32_dpp", "wave_shr:1", "") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1), "v"(m.x), "v"(m.y));
+  if (GW == 32 && lane == 32) r = m;
+  return r;
+}
+template <int GW>
+__device__ __forceinline__ v2f prev_plus(float q0, float q1, v2f c, int lane) {
+  v2f r;
+  if constexpr (GW == 16) asm(SGR_PREV2("v_add_f32_dpp", "row_shr:1", " bound_ctrl:0") : "=&v"(r.x), "=&v"(r.y) : "v"(q0), "v"(q1), "v"(c.x), "v"(c.y));
+  else if constexpr (GW == 8) asm(SGR_PREV2("v_add_f32_dpp", "row_shr:2", " bound_ctrl:0") : "=&v"(r.x), "=&v"(r.y) : "v"(q0), "v"(q1), "v"(c.x), "v"(c.y));
+  else if constexpr (GW == 4) asm(SGR_PREV2("v_add_f32_dpp", "row_shr:4", " bound_ctrl:0") : "=&v"(r.x), "=&v"(r.y) : "v"(q0), "v"(q1), "v"(c.x), "v"(c.y));
+  else asm(SGR_PREV2("v_add_f32_dpp", "wave_shr:1", " bound_ctrl:0") : "=&v"(r.x), "=&v"(r.y) : "v"(q0), "v"(q1), "v"(c.x), "v"(c.y));
+  if (GW == 32 && lane == 32) r = c;
+  return r;
+}
+
 // The hot loop of the backward, TWO pixels per lane.  blend_bwd is bound by VALU issue (one wave64 op = 4 cycles), and
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot), so every lane carries its splat
 // against a horizontally adjacent pixel PAIR in 2-vectors: the quadratic form, the colour dot product, alpha*T and all
@@ -362,10 +389,9 @@ __device__ __forceinline__ void bwd_chunk2(
     const v2f one_m = splat2(1.f) - alpha;
     float P0 = one_m.x, P1 = one_m.y;
     group_scan_mul2<GW>(P0, P1);                         // prod over this splat and all behind it (in chunk)
-    const v2f E = {group_shr1<GW>(P0, 1.f, lane), group_shr1<GW>(P1, 1.f, lane)};   // prod over all strictly behind it
     const v2f rP = {__builtin_amdgcn_rcpf(P0), __builtin_amdgcn_rcpf(P1)};
     const v2f Tj = (v2f){b0.x, b0.y} * rP;               // transmittance in front of splat j
-    const v2f inv1ma = E * rP;                           // 1 / (1 - alpha_j)
+    const v2f inv1ma = prev_times<GW>(P0, P1, rP, lane); // 1 / (1 - alpha_j) = (prod over all strictly behind it) / (prod incl. it)
     const v2f dCr = {a0.x, a0.y}, dCg = {a0.z, a0.w}, dCb = {a1.x, a1.y}, dD = {a1.z, a1.w};
     const v2f w = __builtin_elementwise_fma(dCr, splat2(cr), __builtin_elementwise_fma(dCg, splat2(cg),
                   __builtin_elementwise_fma(dCb, splat2(cb), dD * splat2(dep))));
@@ -373,13 +399,12 @@ __device__ __forceinline__ void bwd_chunk2(
     const v2f q = w * aT;
     float Q0 = q.x, Q1 = q.y;
     group_scan_add2<GW>(Q0, Q1);                         // inclusive: this splat and all behind it
-    const v2f Qi = {Q0, Q1};
     const v2f Sc = {b0.z, b0.w};
-    const v2f Sx = (Qi - q) + Sc;                        // strictly behind (+ carried chunks + background term)
+    const v2f Sx = prev_plus<GW>(Q0, Q1, Sc, lane);      // strictly behind (+ carried chunks + background term)
     const v2f dL_dalpha = __builtin_elementwise_fma(Tj, w, -(Sx * inv1ma));
     if (carry && sl == GW - 1) {
       // carry to the next (nearer) chunk: the last lane of the group holds the nearest splat of this chunk
-      const v2f S2 = Qi + Sc;
+      const v2f S2 = (v2f){Q0, Q1} + Sc;
       pixB2[gp * 2] = make_float4(Tj.x, Tj.y, S2.x, S2.y);
     }
     a_r = __builtin_elementwise_fma(aT, dCr, a_r);
