@@ -137,6 +137,7 @@ __device__ __forceinline__ void wave_sort_registers(const uint64_t* __restrict__
 // the ~45 of a forward trip.  Forward and backward scale the same way, so they still agree bit for bit on which pairs contribute;
 // the sign test `power <= 0` is unaffected.
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kStash = 16, kStashStride = 66, kStashOffset = 864;      // (864 = the staging bytes of 16 splats + the pad splat)
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot); both blend kernels use 2-vectors
@@ -330,10 +331,10 @@ struct SrcStaged {
 // per iteration.  Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix
 // scan.  Chunks run back to front; `carry`: more (nearer) chunks follow, leave (T, S) in front of this chunk per pixel.
 // LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | nc0,nc1, x0,y) for pair g.
-template <int GW, typename SRC>
+template <int GW, typename SRC, bool STASH = false>
 __device__ __forceinline__ void bwd_chunk2(
     int lane, int start, int end, bool carry, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
-    const LOff& L, float4* __restrict__ partials) {
+    const LOff& L, float4* __restrict__ partials, const float* stash = nullptr /*LDS: exp(power) of the forward walk, see blend_fwd_kernel*/) {
   constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
   // (opaque to the optimiser: the five instantiations sit in one loop, and hoisting each one's lane arithmetic out of it
   //  cost more live registers than the kernel has at 5 waves per SIMD -- they were spilled to scratch: +37 MB of writes per launch)
@@ -349,6 +350,7 @@ __device__ __forceinline__ void bwd_chunk2(
     const SplatRec sr = src.load(idx, L);
     mx = sr.mx; my = sr.my; A = sr.A; B = sr.B; Cc = sr.C; op = sr.op; cr = sr.r; cg = sr.g; cb = sr.b; dep = sr.dep; slot = sr.slot;
   }
+  const float* my_stash = STASH ? stash + (valid ? idx : start) * kStashStride : nullptr;
   if (!valid) idx = 0x7fffffff;                  // (an empty lane is behind every pixel's last contributor: `idx < nc` rejects it)
   v2f s_gx, s_gy, s_gxx, s_gxy, s_gyy, a_o, a_r, a_g, a_b, a_d;       // (64-bit moves: the compiler cleared the twenty halves one by one)
   asm("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0\n\t"
@@ -368,17 +370,23 @@ __device__ __forceinline__ void bwd_chunk2(
     // exact integers) -- rebuilding them from gp cost 8 of an iteration's instructions
     const v2f dx = splat2(mx) - (v2f){b1.z, b1.z + 1.f};
     const v2f dy = splat2(my) - splat2(b1.w);
-    // the forward walk's footprint evaluation on the pair, same operation order
-    const v2f adx = splat2(A) * dx;
-    const v2f cdy2 = (splat2(Cc) * dy) * dy;
-    const v2f qf = __builtin_elementwise_fma(adx, dx, cdy2);
-    const v2f bdxdy = (splat2(B) * dx) * dy;
-    const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
-    const v2f G = {exp2_fast(power.x), exp2_fast(power.y)};      // (the conic carries log2(e))
+    v2f G, power = {0.f, 0.f};
+    if constexpr (STASH) {
+      const float2 gs = *(const float2*)(my_stash + 2 * gp);     // what the forward walk computed for these two pixels (-1: power > 0)
+      G = (v2f){gs.x, gs.y};
+    } else {
+      // the forward walk's footprint evaluation on the pair, same operation order
+      const v2f adx = splat2(A) * dx;
+      const v2f cdy2 = (splat2(Cc) * dy) * dy;
+      const v2f qf = __builtin_elementwise_fma(adx, dx, cdy2);
+      const v2f bdxdy = (splat2(B) * dx) * dy;
+      power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
+      G = (v2f){exp2_fast(power.x), exp2_fast(power.y)};         // (the conic carries log2(e))
+    }
     v2f og = splat2(op) * G;
-    // (alpha = min(0.99, og) >= 1/255  <=>  og >= 1/255: the test does not wait for the clamp)
-    const bool ok0 = (idx < nc0) && (power.x <= 0.0f) && (og.x >= kAlphaMin);
-    const bool ok1 = (idx < nc1) && (power.y <= 0.0f) && (og.y >= kAlphaMin);
+    // (alpha = min(0.99, og) >= 1/255  <=>  og >= 1/255: the test does not wait for the clamp; a stashed -1 fails it for power > 0)
+    const bool ok0 = (idx < nc0) && (STASH || power.x <= 0.0f) && (og.x >= kAlphaMin);
+    const bool ok1 = (idx < nc1) && (STASH || power.y <= 0.0f) && (og.y >= kAlphaMin);
     // a pair that does not contribute takes part with opacity * G = 0: alpha = 0 (factor 1 in the product, weight 0 in the sums) and
     // G dL/dG = 0 -- ONE select per pixel masks everything downstream
     og.x = ok0 ? og.x : 0.f;
@@ -490,7 +498,7 @@ __device__ __forceinline__ void bwd_chunk2(
 template <typename SRC>
 __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty, const float pxA[4], float pxB[3],
                                               const float* __restrict__ bg, float4* pixA /*LDS*/, float4* pixB /*LDS*/, const SRC& src,
-                                              const LOff& L, float4* __restrict__ partials) {
+                                              const LOff& L, float4* __restrict__ partials, const float* stash = nullptr) {
   // the background term -T_final/(1-alpha_j) * (bg . dL/dC) has the same shape as "colour behind splat j"
   pxB[1] = pxB[0] * (bg[0] * pxA[0] + bg[1] * pxA[1] + bg[2] * pxA[2]);
   // pixel p -> pair p / 2, half p % 2
@@ -514,6 +522,19 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
                                   : (end >= 48 ? 64 : (end >= 24 ? 32 : (end >= 12 ? 16 : (end >= 5 ? 8 : 4))));
     const int start = gw >= end ? 0 : end - gw;
     const bool carry = start > 0;
+    if constexpr (std::is_same<SRC, SrcStaged>::value) {
+      if (stash) {            // (a list of <= kStash splats: chunks of 16 / 8 / 4 only)
+        if (gw == 16) bwd_chunk2<16, SRC, true>(lane, start, end, carry, pixA, pixB, src, L, partials, stash);
+        else if (gw == 8) bwd_chunk2<8, SRC, true>(lane, start, end, carry, pixA, pixB, src, L, partials, stash);
+        else bwd_chunk2<4, SRC, true>(lane, start, end, carry, pixA, pixB, src, L, partials, stash);
+        end = start;
+        if (carry) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        continue;
+      }
+    }
     if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, pixA, pixB, src, L, partials);
     else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, pixA, pixB, src, L, partials);
     else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, pixA, pixB, src, L, partials);
@@ -611,9 +632,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  uint64_t* keys = (uint64_t*)slice;          // mid / heavy build: the keys, sorted in place
-  uint32_t* ids = (uint32_t*)slice;           // light build: sorted Gaussian indices (the keys were sorted in registers)
-  float4* lds = (float4*)(slice + SORT_MAX * kKeyBytes);
+  float4* lds = (float4*)slice;                              // 64 staged splats x 48 B
+  uint64_t* keys = (uint64_t*)(slice + kWave * 48);          // mid / heavy build: the keys, sorted in place
+  uint32_t* ids = (uint32_t*)(slice + kWave * 48);           // light build: sorted Gaussian indices (the keys were sorted in registers)
+  // G stash (fused kernel, lists of <= kStash splats -- three quarters of a SLAM view's tiles): such a list is staged in the first 864
+  // bytes and never uses the sorted-index area, so the 4.2 KB behind it hold exp(power) of every (splat, pixel) pair the forward
+  // walk evaluates (row = list position, kStashStride floats apart: rows two banks apart, conflict-free 8-byte reads of a group's
+  // pixel pair), with -1 where power > 0.  The backward reads it back instead of re-evaluating the quadratic form, the exponential and
+  // the sign test: 11 of the ~76 instructions of an iteration.  The same bits the backward would recompute: results unchanged.
+  float* stash = (float*)(slice + kStashOffset);
+  static_assert(!FUSED || kStashOffset + kStash * kStashStride * 4 <= kWave * 48 + SORT_MAX * kKeyBytes, "the stash overlays unused staging + index space");
 
   // ground truth of the fused loss epilogue: fetched NOW so that the round trip hides behind sorting and blending
   const float* __restrict__ gt_image = lt.gt_image[vw];
@@ -717,6 +745,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         point_list[begin + i] = (uint32_t)__hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
+  const bool use_stash = FUSED && mode == 0 && count <= kStash && !n_touched;
   float T = 1.f;
   v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, Dd = {0.f, 0.f};   // (even, odd) list positions, added at the end
   uint32_t last = 0;
@@ -749,7 +778,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
     // Two splats per trip, branch free.  blend_fwd is VALU-issue bound like the backward, so the footprint (the same
     // operation sequence, packed), alpha * T and the four accumulate FMAs issue once per PAIR (v_pk_*_f32); exp, the
     // tests and the transmittance chain stay per splat.  The "every pixel finished" exit is polled every 4 splats.
-    auto walk = [&](auto count_touched) {
+    auto walk = [&](auto count_touched, auto stash_g) {
 #pragma clang fp contract(off)      // the two instantiations must round alike (T * (1 - alpha) is not to become an fma in one)
       for (int j = 0; j < n; j += 2) {
         if ((j & 3) == 0 && __builtin_amdgcn_ballot_w64(!done) == 0) break;
@@ -761,6 +790,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         const v2f bdxdy = ((v2f){q1.z, q1.w} * dx) * dy;
         const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
         const v2f G = {exp2_fast(power.x), exp2_fast(power.y)};      // (the staged conic carries log2(e))
+        if (decltype(stash_g)::value) {
+          float* sp = stash + j * kStashStride + lane;
+          sp[0] = power.x <= 0.0f ? G.x : -1.f;
+          sp[kStashStride] = power.y <= 0.0f ? G.y : -1.f;
+        }
         const v2f og = (v2f){q2.z, q2.w} * G;
         const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
         const bool ok0 = (power.x <= 0.0f) && (og.x >= kAlphaMin);          // (<=> alpha >= 1/255; the backward tests the same value)
@@ -794,7 +828,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         last = comp1 ? (uint32_t)(base + j + 2) : (comp0 ? (uint32_t)(base + j + 1) : last);
       }
     };
-    if (n_touched) walk(std::true_type{}); else walk(std::false_type{});
+    if (n_touched) walk(std::true_type{}, std::false_type{});
+    else if (use_stash) walk(std::false_type{}, std::true_type{});
+    else walk(std::false_type{}, std::false_type{});
     __builtin_amdgcn_wave_barrier();
     if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
   }
@@ -872,7 +908,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
       }
     }
     if (eff == 0) return;
-    tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixA, pixB, src, L, partials);
+    tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixA, pixB, src, L, partials, use_stash ? stash : nullptr);
   } else {
     const SrcKeys src = {mode == 1 && REGSORT ? ids : nullptr, mode == 1 && !REGSORT ? keys : nullptr, entries + begin, grec, saved, tx, ty, cap};
     for (int idx = eff + lane; idx < count; idx += kWave) {
