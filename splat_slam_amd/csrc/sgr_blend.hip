@@ -513,13 +513,12 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
   }
   // The list is cut into chunks of 64 / 32 / 16 / 8 / 4 splats from the far end: a lane = a splat, and a chunk of width GW works
   // on 64 / GW pixel pairs at once, so a chunk costs 32 * GW / 64 iterations of the loop above whatever part of its lanes is
-  // filled.  One 64-wide chunk per started 64 splats left the lists of a converged map (33-256) at 55-75 % lane use; the
-  // remainder now takes the narrowest chunks that hold it (70 splats: 64 + 8 lanes = 36 iterations instead of 64).  A width is
-  // rounded up when the chunk would be at least 3/4 full (the per-chunk epilogue costs about one iteration).
+  // filled -- and an iteration costs nearly the same at every width (85 instructions at 64 lanes, 68 at 8: only the scan depth
+  // differs).  So the plan is the binary expansion of the list length (24 splats: 16 + 8 = 12 iterations, not one 32-wide chunk of
+  // 16), rounded up to the next width only when fewer lanes stay empty than a chunk's prologue + epilogue (~95 instructions) costs.
   int end = eff;
   while (end > 0) {
-    const int gw = (L.dbg & 1024) ? (end >= 61 ? 64 : (end >= 29 ? 32 : (end >= 13 ? 16 : (end >= 5 ? 8 : 4))))
-                                  : (end >= 48 ? 64 : (end >= 24 ? 32 : (end >= 12 ? 16 : (end >= 5 ? 8 : 4))));
+    const int gw = end >= 61 ? 64 : (end >= 29 ? 32 : (end >= 13 ? 16 : (end >= 5 ? 8 : 4)));
     const int start = gw >= end ? 0 : end - gw;
     const bool carry = start > 0;
     if constexpr (std::is_same<SRC, SrcStaged>::value) {
@@ -661,11 +660,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const uint64_t* __restrict__ bucket = (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
   static_assert(kBucket >= kWave, "the first 64 entries of a bucket are fetched one per lane");
   uint64_t key_spec = lane < 32 ? bucket[lane] : ~0ull;
-  uint2 rng = ranges[(size_t)tile * kRngStride];
-  if (L.dbg & 512) {             // EXPERIMENT (results wrong): no range / key round trip either (synthetic 11-entry lists)
-    key_spec = ((uint64_t)(uint32_t)(lane * 7 + 3) << 32) | (uint32_t)((tile * 11 + lane) % L.N);
-    rng = make_uint2((uint32_t)tile * 11u, (uint32_t)tile * 11u + 11u);
-  }
+  const uint2 rng = ranges[(size_t)tile * kRngStride];
   const int64_t begin = rng.x & ~kOverfull;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
   const int count = endc > begin ? (int)(endc - begin) : 0;
@@ -691,18 +686,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
     uint32_t slot = 0xffffffffu;
     if (lane < count) {
-      if (L.dbg & 256) {         // EXPERIMENT (results wrong): no record gather -- what the second dependent round trip of a tile costs
-        m = make_float4(pxf + 0.25f * (float)(lane & 7) - 1.f, pyf - 0.25f * (float)(lane & 3), 0.f, 0.f);
-        co = make_float4(0.08f, 0.01f, 0.06f, 0.3f);
-        cd = make_float4(0.5f, 0.4f, 0.3f, 1.f + (float)lane);
-        slot = (uint32_t)(((uint64_t)tile * 16u + (uint32_t)lane) % (uint64_t)cap);
-      } else {
       const float4* rec = (const float4*)(grec + g);
       m = rec[0];
       co = rec[1];
       cd = rec[2];
       if (FUSED) slot = pair_slot(saved, L, g, ((const uint32_t*)(rec + 3))[1], __float_as_uint(m.z), __float_as_uint(m.w), tx, ty, cap);
-      }
     }
     if (lane >= count) rank = (uint32_t)lane;        // lane == count files the zero splat that pads an odd list
     if (!FUSED && lane < count) point_list[begin + rank] = g;      // (the fused backward reads the staged records instead)

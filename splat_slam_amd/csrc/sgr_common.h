@@ -172,8 +172,8 @@ struct Common {
 //   bit 3: the cull uses the old per-Gaussian projection test instead of the plane test (results stay correct)
 //   bit 4: the cull does not zero radii / n_touched     bit 5: no counting atomics (every rank 0)
 //   bit 6: counting atomics add 0 and nobody consumes the ranks (atomics issued, lists stay empty)     bit 7: no record writes
-//   bit 8: the tile kernels stage synthetic splats instead of gathering the tile's 64-byte records (what the second dependent
-//          round trip of a tile costs)     bit 9: ... and synthetic 11-entry lists instead of the range / key loads (the first)
+//   bit 11: the fused tile kernel skips the forward walk and the backward     bit 12: ... the backward only
+//           (scripts/micro/pmc_tile.py under these bits: which part of a tile's wave the instructions belong to)
 int debug_flags();
 
 // Everything later stages gather BY GAUSSIAN for one view, as ONE 64-byte record (= one HBM sector pair, one L2 line
