@@ -25,7 +25,7 @@
 #include "sgr_common.h"
 
 #ifndef SGR_TILE_WAVES
-#define SGR_TILE_WAVES 5      // fused tile kernel / forward: 95 VGPRs; 4 waves per SIMD measured 10 % slower (no spills either way)
+#define SGR_TILE_WAVES 5      // fused tile kernel: 84 VGPRs; 4 waves per SIMD measured 10 % slower, 6 (80 VGPRs, 4 spilled) no faster
 #endif
 #ifndef SGR_BWD_WAVES
 #define SGR_BWD_WAVES 5       // stand-alone backward
@@ -35,8 +35,8 @@ namespace sgr {
 
 // Lists the wave sorts on chip: three builds of the forward kernel, picked per launch from the LONGEST list the caller has
 // measured for these cameras (SgrWorkspace.max_list_hint).  "light": up to 512 keys sorted IN REGISTERS (below), only the
-// sorted Gaussian indices (4 B each) go to LDS -- 5 workgroups per CU stay resident and it is the build that runs forward
-// and backward of a tile in one wave; "mid" / "heavy": 1024 / 4096 64-bit keys bitonic in LDS (3 / 1 workgroups per CU).
+// sorted Gaussian indices (4 B each) go to LDS -- 7 KB per wave, 20 waves per CU stay resident -- and it is the build that runs forward
+// and backward of a tile in one wave; "mid" / "heavy": 1024 / 4096 64-bit keys bitonic in LDS (11 / 35 KB per wave).
 constexpr int kSortLight = 512, kSortMid = 1024, kSortHeavy = 4096;
 constexpr bool sort_in_registers(int sort_max) { return sort_max <= kSortLight; }
 
@@ -557,8 +557,8 @@ __device__ __forceinline__ float sign_code(uint32_t c, float k) { return (c & 1u
 // registers and the tile's sorted splats are still staged in LDS, so the wave goes straight on with tile_backward():
 // no final_T / n_contrib / code-byte / index-list round trip through HBM, no second launch, one tile prologue.
 // The compact visible list of a view (what the dense backward iterates) rides in the tile kernel's launch: `kCompSegs` segments
-// per 256-thread block, 16 lanes per segment copy that segment's list (K1) to its place -- segment base = the visible counts of
-// the segments in front, which the block adds up itself (<= a few thousand values).  It used to be a set of blocks of K2, on the
+// per single-wave block, 16 lanes per segment copy that segment's list (K1) to its place -- segment base = the visible counts of
+// the segments in front, which the wave adds up itself (<= a few thousand values).  It used to be a set of blocks of K2, on the
 // critical path between K1 and the tile kernels (K2 17.6 -> 13.6 us without them); nothing before the backward reads the list.
 constexpr int kCompSegs = 4;
 __device__ __forceinline__ int comp_blocks(const LOff& L) { return (((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7; }   // (x8: XCD mapping)

@@ -197,7 +197,7 @@ struct Layout {
   int N, H, W;
   int64_t cap;
   int gx, gy, ntiles;      // 8x8 tile grid
-  int sgx, sgy;            // 16x16 super-tile grid (one 256-thread workgroup)
+  int sgx, sgy;            // 16x16 super-tile grid (the reference's tiles; four of our 8x8 tiles each)
   int tile_bits;
   // saved
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
