@@ -589,12 +589,17 @@ __device__ __forceinline__ void compact_visible_list(char* saved, const LOff& L,
 // super tile differ in length -- the counters showed 3.7 resident waves per SIMD on average where the registers allow 5.
 // tile_of_block(): hardware places block b on XCD b % 8; every XCD gets a contiguous run of super tiles and walks it tile by tile, so
 // neighbouring tiles (which share Gaussians) still hit the same 4 MiB L2 at about the same time.
-__device__ __forceinline__ bool tile_of_block(int b, int sgx, int sgy, int& tx, int& ty) {
-  const int nsuper = sgx * sgy, per = (nsuper + 7) >> 3;
+__device__ __forceinline__ bool tile_of_block(int b, const LOff& L, int& tx, int& ty) {
+  // everything here is wave-uniform and must STAY in SGPRs (the tile's coordinates feed most of the kernel's address arithmetic):
+  // the division by the super-tile row length is a multiply-high by a host-made reciprocal -- the compiler's integer division goes
+  // through the VALU's float reciprocal and left tx / ty (and everything derived from them) in vector registers, ~35 instructions
+  const int sgx = L.sgx, nsuper = L.sgx * L.sgy, per = (nsuper + 7) >> 3;
   const int j = b >> 3, st = (b & 7) * per + (j >> 2), wv = j & 3;
   if (st >= nsuper || j >= 4 * per) return false;
-  tx = (st % sgx) * 2 + (wv & 1);
-  ty = (st / sgx) * 2 + (wv >> 1);
+  const int row = (int)__builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)st, L.sgx_magic));      // st / sgx  (st * sgx < 2^32)
+  const int col = st - row * sgx;
+  tx = __builtin_amdgcn_readfirstlane(col * 2 + (wv & 1));
+  ty = __builtin_amdgcn_readfirstlane(row * 2 + (wv >> 1));
   return true;
 }
 __device__ __forceinline__ int tile_blocks(int sgx, int sgy) { return 8 * 4 * ((sgx * sgy + 7) >> 3); }
@@ -622,7 +627,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const int ncomp = comp_blocks(L);             // the first blocks of the launch: the view's compact visible list (see above)
   if ((int)blockIdx.x < ncomp) { compact_visible_list(saved, L, (int)blockIdx.x); return; }
   int tx, ty;
-  if (!tile_of_block((int)blockIdx.x - ncomp, sgx, sgy, tx, ty)) return;
+  if (!tile_of_block((int)blockIdx.x - ncomp, L, tx, ty)) return;
   const int lane = threadIdx.x;
   constexpr int kLdsSortMax = SORT_MAX;
   char* slice = smem;
@@ -930,7 +935,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_BWD
   float4* __restrict__ partials = (float4*)(tab.scratch[vw] + L.o_partials);
   __shared__ float4 pixbuf[2][kWave];         // pixel gradients + running (T, S) carries
   int tx, ty;
-  if (!tile_of_block((int)blockIdx.x, sgx, sgy, tx, ty)) return;
+  if (!tile_of_block((int)blockIdx.x, L, tx, ty)) return;
   const int lane = threadIdx.x;
   if (tx >= gx || ty >= gy) return;
   const int tile = ty * gx + tx;

@@ -148,6 +148,7 @@ struct ViewTab {
 // device-visible copy of the Layout offsets (identical for all views of a batch: same N, H, W, capacity)
 struct LOff {
   int N, H, W, gx, gy, gxp, sgx, sgy, ntiles, pre_blocks, nseg, dbg, mean_hint, k1_parts;
+  uint32_t sgx_magic;      // floor(2^32 / sgx) + 1: q = mulhi(st, sgx_magic) = st / sgx exactly for st * sgx < 2^32 (a scalar multiply instead of a VALU division)
   // the caller's measured longest list (0: unknown): everything derived from it changes with it, in ONE place
   __host__ void set_hint(int h) { mean_hint = h; k1_parts = k1_parts_for(nseg, h); }
   int64_t cap;
@@ -256,7 +257,7 @@ struct Layout {
   }
   __host__ LOff dev() const {
     LOff d;
-    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags(); d.mean_hint = 0; d.k1_parts = k1_parts_for(nseg);
+    d.N = N; d.H = H; d.W = W; d.gx = gx; d.gy = gy; d.gxp = (gx + 1) / 2; d.sgx = sgx; d.sgy = sgy; d.ntiles = ntiles; d.pre_blocks = pre_blocks; d.nseg = nseg; d.dbg = debug_flags(); d.mean_hint = 0; d.k1_parts = k1_parts_for(nseg); d.sgx_magic = (uint32_t)((1ull << 32) / (uint64_t)(sgx > 0 ? sgx : 1)) + 1u;
     d.cap = cap;
     d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_grec = o_grec;
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;
