@@ -27,7 +27,7 @@ h = hashlib.sha256()
 gm = loop.gaussians
 for name in ("_xyz", "_features_dc", "_scaling", "_rotation", "_opacity"):
     h.update(getattr(gm, name).detach().cpu().numpy().tobytes())
-r = B.profiled(loop, 40, 1 << bench.PK_FUSED, True)
+r = B.profiled(loop, 40, (1 << bench.PK_FUSED) | 1 | (1 << 6), True)
 el, _ = B.timed(loop, 100)
 print(json.dumps({"lib": os.environ.get("SPLAT_HIP_LIB", "in-tree"), "scale_add": a.scale_add, "sha256": h.hexdigest()[:16],
-                  "fused_ms": round(r[bench.PK_FUSED][0], 5), "ms_per_step": round(1e3 * el / 100, 4)}))
+                  "fused_ms": round(r[bench.PK_FUSED][0], 5), "k1_ms": round(r[0][0], 5), "dense_adam_ms": round(r[6][0], 5), "ms_per_step": round(1e3 * el / 100, 4)}))
