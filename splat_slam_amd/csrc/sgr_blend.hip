@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   float T = 1.f;
   v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, Dd = {0.f, 0.f};   // (even, odd) list positions, added at the end
   uint32_t last = 0;
-  bool done = !inside || (L.dbg & 2048);       // (bit 11, EXPERIMENT: no walk, no backward -- what the rest of a tile's wave costs)
+  unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside || (L.dbg & 2048));      // finished pixels, one bit per lane (bit 11 of SGR_DEBUG, EXPERIMENT: no walk, no backward -- what the rest of a tile's wave costs)
   const v2f px2 = splat2(pxf), py2 = splat2(pyf);
 
   for (int base = 0; base < count; base += kWave) {
@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
     auto walk = [&](auto count_touched, auto stash_g) {
 #pragma clang fp contract(off)      // the two instantiations must round alike (T * (1 - alpha) is not to become an fma in one)
       for (int j = 0; j < n; j += 2) {
-        if ((j & 3) == 0 && __builtin_amdgcn_ballot_w64(!done) == 0) break;
+        if ((j & 3) == 0 && ~done_m == 0ull) break;
         const float4* e = lds + (j >> 1) * 6;
         const float4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4];
         const float2 q5 = *(const float2*)&e[5];
@@ -790,20 +790,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         }
         const v2f og = (v2f){q2.z, q2.w} * G;
         const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
-        const bool ok0 = (power.x <= 0.0f) && (og.x >= kAlphaMin);          // (<=> alpha >= 1/255; the backward tests the same value)
-        const bool ok1 = (power.y <= 0.0f) && (og.y >= kAlphaMin);
+        // Who contributes is decided on wave masks in SGPRs (every lane of the wave is active here: a ballot is the whole comparison):
+        // the and / andn2 / or of the termination logic are scalar instructions, and the compiler no longer issues the
+        // complement of a floating-point compare as a second compare.  (<=> alpha >= 1/255; the backward tests the same value)
+        const unsigned long long ok0 = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(og.x >= kAlphaMin);
+        const unsigned long long ok1 = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(og.y >= kAlphaMin);
         const v2f one_m = splat2(1.f) - alpha;
         const float test0 = T * one_m.x;
-        const bool live0 = !done && ok0;
-        const bool term0 = live0 && (test0 < kTEps);
-        const bool comp0 = live0 && !term0;
-        done = done || term0;
+        const unsigned long long live0 = ok0 & ~done_m, lt0 = __builtin_amdgcn_ballot_w64(test0 < kTEps);
+        const unsigned long long comp0_m = live0 & ~lt0;
+        done_m |= live0 & lt0;
+        const bool comp0 = __builtin_amdgcn_inverse_ballot_w64(comp0_m);
         const float T1 = comp0 ? test0 : T;
         const float test1 = T1 * one_m.y;
-        const bool live1 = !done && ok1;
-        const bool term1 = live1 && (test1 < kTEps);
-        const bool comp1 = live1 && !term1;
-        done = done || term1;
+        const unsigned long long live1 = ok1 & ~done_m, lt1 = __builtin_amdgcn_ballot_w64(test1 < kTEps);
+        const unsigned long long comp1_m = live1 & ~lt1;
+        done_m |= live1 & lt1;
+        const bool comp1 = __builtin_amdgcn_inverse_ballot_w64(comp1_m);
         v2f w = alpha * (v2f){T, T1};
         w.x = comp0 ? w.x : 0.f;
         w.y = comp1 ? w.y : 0.f;
@@ -812,9 +815,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         Cb = __builtin_elementwise_fma((v2f){q5.x, q5.y}, w, Cb);
         Dd = __builtin_elementwise_fma((v2f){q3.x, q3.y}, w, Dd);
         if (decltype(count_touched)::value) {
-          unsigned long long tm = __builtin_amdgcn_ballot_w64(comp0 && test0 > kTouchedT);
+          unsigned long long tm = comp0_m & __builtin_amdgcn_ballot_w64(test0 > kTouchedT);
           if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.z)], (int)__popcll(tm));
-          tm = __builtin_amdgcn_ballot_w64(comp1 && test1 > kTouchedT);
+          tm = comp1_m & __builtin_amdgcn_ballot_w64(test1 > kTouchedT);
           if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.w)], (int)__popcll(tm));
         }
         T = comp1 ? test1 : T1;
@@ -825,7 +828,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
     else if (use_stash) walk(std::false_type{}, std::true_type{});
     else walk(std::false_type{}, std::false_type{});
     __builtin_amdgcn_wave_barrier();
-    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+    if (~done_m == 0ull) break;
   }
   const float C0 = Cr.x + Cr.y, C1 = Cg.x + Cg.y, C2 = Cb.x + Cb.y, D = Dd.x + Dd.y;
 
