@@ -741,7 +741,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const bool use_stash = FUSED && mode == 0 && count <= kStash && !n_touched;
   float T = 1.f;
   v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, Dd = {0.f, 0.f};   // (even, odd) list positions, added at the end
-  uint32_t last = 0;
+  // last contributor of this pixel = 2 * (its last contributing trip, counted from 1 over the whole list) - (1 if that trip's FIRST
+  // splat was the last one): the trip per lane (one select per trip), which half as a wave mask (scalar) -- two selects and two
+  // moves per trip less than tracking the index itself
+  uint32_t last_trip = 0;
+  unsigned long long last_first_m = 0ull;
   unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside || (L.dbg & 2048));      // finished pixels, one bit per lane (bit 11 of SGR_DEBUG, EXPERIMENT: no walk, no backward -- what the rest of a tile's wave costs)
   const v2f px2 = splat2(pxf), py2 = splat2(pyf);
 
@@ -821,7 +825,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
           if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.w)], (int)__popcll(tm));
         }
         T = comp1 ? test1 : T1;
-        last = comp1 ? (uint32_t)(base + j + 2) : (comp0 ? (uint32_t)(base + j + 1) : last);
+        const unsigned long long any_m = comp0_m | comp1_m;
+        last_trip = __builtin_amdgcn_inverse_ballot_w64(any_m) ? (uint32_t)(((base + j) >> 1) + 1) : last_trip;
+        last_first_m = (last_first_m & ~any_m) | (comp0_m & ~comp1_m);
       }
     };
     if (n_touched) walk(std::true_type{}, std::false_type{});
@@ -831,6 +837,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
     if (~done_m == 0ull) break;
   }
   const float C0 = Cr.x + Cr.y, C1 = Cg.x + Cg.y, C2 = Cb.x + Cb.y, D = Dd.x + Dd.y;
+  const uint32_t last = 2u * last_trip - (__builtin_amdgcn_inverse_ballot_w64(last_first_m) ? 1u : 0u);      // (no contributor: 0; the mask bit is then clear)
 
   // per-tile bound for the backward: it never has to look past the last contributor of any pixel
   const uint32_t mx = wave_max_u32(last);
