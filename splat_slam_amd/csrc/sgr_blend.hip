@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
                                                         LossCoef lc) {
   const int vw = blockIdx.y;
   char* saved = tab.saved[vw];
-  const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
+  const int H = L.H, W = L.W, gx = L.gx, gy = L.gy;
   const int64_t cap = L.cap;
   const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
   uint64_t* __restrict__ entries = (uint64_t*)(tab.scratch[vw] + L.o_entries);
@@ -933,7 +933,7 @@ template <bool PACKED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES))) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
   const int vw = blockIdx.y;
   const char* saved = tab.saved[vw];
-  const int H = L.H, W = L.W, gx = L.gx, gy = L.gy, sgx = L.sgx, sgy = L.sgy;
+  const int H = L.H, W = L.W, gx = L.gx, gy = L.gy;
   const int64_t cap = L.cap;
   const uint2* __restrict__ ranges = (const uint2*)(saved + L.o_ranges);
   const uint32_t* __restrict__ point_list = (const uint32_t*)(saved + L.o_point_list);
