@@ -676,17 +676,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   int mode = 0;                               // 0: registers, 1: LDS, 2: global
   if (count <= kWave) {
     // One chunk.  Every lane keeps ITS (unsorted) key and finds the key's position in the sorted list by counting
-    // smaller keys (keys are unique; broadcast through SGPRs: count short steps and no LDS round trips instead of a
-    // 21-step shuffle network), fetches the key's record and files it under that position.
+    // smaller keys (keys are unique), fetches the key's record and files it under that position.  The keys are broadcast through
+    // LDS (the sorted-index area, which a one-chunk tile does not use): four per 16-byte read, so a key costs the compare and the
+    // add -- two v_readlane per key through SGPRs were half of the loop's instructions on a unit that is the kernel's bottleneck.
     if (count > 32 && lane >= 32 && lane < count) key_spec = bucket[lane];
     const uint64_t key = lane < count ? key_spec : ~0ull;       // (ranks below kBucket are in the bucket whatever the tile's final count)
     const uint32_t g = (uint32_t)key;
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
     uint32_t rank = 0;
-    for (int j = 0; j < count; ++j) {
-      const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, j) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
-      rank += kj < key ? 1u : 0u;
+    {
+      uint64_t* kl = (uint64_t*)ids;
+      kl[lane] = key;                            // (lanes behind the list hold ~0: smaller than nothing)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < count; j += 4) {
+        const uint4 a = *(const uint4*)(kl + j), b = *(const uint4*)(kl + j + 2);
+        rank += ((((uint64_t)a.y << 32) | a.x) < key ? 1u : 0u) + ((((uint64_t)a.w << 32) | a.z) < key ? 1u : 0u) +
+                ((((uint64_t)b.y << 32) | b.x) < key ? 1u : 0u) + ((((uint64_t)b.w << 32) | b.z) < key ? 1u : 0u);
+      }
+      __builtin_amdgcn_wave_barrier();           // (the stash may overwrite the keys once the walk starts)
     }
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f), co = m, cd = m;
     uint32_t slot = 0xffffffffu;
