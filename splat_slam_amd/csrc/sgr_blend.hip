@@ -753,6 +753,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   // moves per trip less than tracking the index itself
   uint32_t last_trip = 0;
   unsigned long long last_first_m = 0ull;
+  uint32_t mx_trip = 0, mx_second = 0;        // the same for the whole tile (its maximum over the pixels), kept by the scalar unit
   unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside || (L.dbg & 2048));      // finished pixels, one bit per lane (bit 11 of SGR_DEBUG, EXPERIMENT: no walk, no backward -- what the rest of a tile's wave costs)
   const v2f px2 = splat2(pxf), py2 = splat2(pyf);
 
@@ -835,6 +836,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         const unsigned long long any_m = comp0_m | comp1_m;
         last_trip = __builtin_amdgcn_inverse_ballot_w64(any_m) ? (uint32_t)(((base + j) >> 1) + 1) : last_trip;
         last_first_m = (last_first_m & ~any_m) | (comp0_m & ~comp1_m);
+        if (any_m != 0ull) { mx_trip = (uint32_t)(((base + j) >> 1) + 1); mx_second = comp1_m != 0ull ? 1u : 0u; }
       }
     };
     if (n_touched) walk(std::true_type{}, std::false_type{});
@@ -847,13 +849,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const uint32_t last = 2u * last_trip - (__builtin_amdgcn_inverse_ballot_w64(last_first_m) ? 1u : 0u);      // (no contributor: 0; the mask bit is then clear)
 
   // per-tile bound for the backward: it never has to look past the last contributor of any pixel
-  const uint32_t mx = wave_max_u32(last);
+  const uint32_t mx = mx_trip ? 2u * mx_trip - 1u + mx_second : 0u;       // = the maximum of `last` over the wave
   if (lane == 0) tile_maxc[tile] = mx;
 
   float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;
   const uint32_t tpix = (uint32_t)tile * 64u + (uint32_t)lane;
   if (!FUSED) pix_state[tpix] = make_float2(T, __uint_as_float(last));       // (lanes outside the image: T = 1, no contributor)
   uint32_t code = 0;
+  float pxA[4] = {0.f, 0.f, 0.f, 0.f};        // FUSED: dL/dC (r, g, b) and dL/dD of this pixel, straight from the residuals' signs
   if (inside) {
     const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
     const float I[3] = {C0 + T * bg[0], C1 + T * bg[1], C2 + T * bg[2]};
@@ -872,20 +875,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
       // scratch and rebuilds the same floats (16 -> 1 byte per pixel written here and read there).
       const float g[3] = {gt0, gt1, gt2};
       const bool m = (g[0] + g[1] + g[2]) > lc.thr;
+      const float k_rgb = lc.w_rgb * ea;           // (the float blend_bwd<true> rebuilds from the code byte)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float r = m ? (ea * I[c] + eb) - g[c] : 0.f;
         l_rgb += fabsf(r);
-        float sgn = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
-        code |= ((r > 0.f) ? 1u : ((r < 0.f) ? 2u : 0u)) << (2 * c);
-        float dab = lc.w_rgb * sgn;
-        l_da += dab * ea * I[c];
+        const bool pos = r > 0.f, neg = r < 0.f;
+        if (!FUSED) code |= (pos ? 1u : (neg ? 2u : 0u)) << (2 * c);
+        // dL/dC_c = sign(r) * w * e^a and its share of d/da, d/db: selects and ONE explicit fma, so that the fused and the un-fused
+        // instantiation cannot round differently ((w * sgn) * e^a = sgn * (w * e^a) exactly: sgn is 0 or +-1)
+        const float dab = pos ? lc.w_rgb : (neg ? -lc.w_rgb : 0.f), dk = pos ? k_rgb : (neg ? -k_rgb : 0.f);
+        if (FUSED) pxA[c] = dk;
+        l_da = __fmaf_rn(dk, I[c], l_da);
         l_db += dab;
       }
       const float gd = gtd;
       const float rd = (gd > 0.01f) ? D - gd : 0.f;
       l_dep = fabsf(rd);
-      code |= ((rd > 0.f) ? 1u : ((rd < 0.f) ? 2u : 0u)) << 6;
+      if (FUSED) pxA[3] = (rd > 0.f) ? lc.w_dep : ((rd < 0.f) ? -lc.w_dep : 0.f);
+      else code |= ((rd > 0.f) ? 1u : ((rd < 0.f) ? 2u : 0u)) << 6;
       if (!FUSED && !code_bytes_tiled(L)) ((uint8_t*)lt.dimage[vw])[pix] = (uint8_t)code;
     }
   }
@@ -902,8 +910,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const int eff = (L.dbg & 4096) ? 0 : min(count, (int)mx);      // (bit 12, EXPERIMENT: no backward)
   float4* __restrict__ partials = (float4*)(tab.scratch[vw] + L.o_partials);
   // pairs the walk never reached (behind every pixel's last contributor) still own a slot: define it as zero
-  const float k_rgb = lc.w_rgb * (lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f);     // the floats blend_bwd<true> rebuilds from the code byte
-  float pxA[4] = {sign_code(code, k_rgb), sign_code(code >> 2, k_rgb), sign_code(code >> 4, k_rgb), sign_code(code >> 6, lc.w_dep)};
   float pxB[3] = {T, 0.f, __uint_as_float(last)};
   float4* pixA = (float4*)(slice + (size_t)SORT_MAX * kKeyBytes + kWave * 48);
   float4* pixB = pixA + kWave;
