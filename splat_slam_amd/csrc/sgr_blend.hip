@@ -651,9 +651,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const float* __restrict__ gt_image = lt.gt_image[vw];
   float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, gtd = 0.f, ea = 1.f, eb = 0.f;
   if (gt_image && inside) {
-    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px, hw = (uint32_t)H * (uint32_t)W;   // 32-bit: uniform base + lane offset
-    gt0 = gt_image[pix]; gt1 = gt_image[hw + pix]; gt2 = gt_image[2 * hw + pix];
-    gtd = lt.gt_depth[vw][pix];
+    // uniform base (SGPR pair) + ONE 32-bit byte offset per lane: the planes are reached by moving the base, not the lane's address
+    const uint32_t off = ((uint32_t)py * (uint32_t)W + (uint32_t)px) * 4u;
+    const size_t plane = (size_t)H * (size_t)W * 4u;
+    const char* g0 = (const char*)gt_image;
+    gt0 = *(const float*)(g0 + off); gt1 = *(const float*)(g0 + plane + off); gt2 = *(const float*)(g0 + 2 * plane + off);
+    gtd = *(const float*)((const char*)lt.gt_depth[vw] + off);
     ea = lt.exp_a[vw] ? __expf(lt.exp_a[vw][0]) : 1.f;
     eb = lt.exp_b[vw] ? lt.exp_b[vw][0] : 0.f;
   }
