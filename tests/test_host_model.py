@@ -158,21 +158,108 @@ def test_register_blocked_tile_sort_network():
 
 
 def test_backward_chunk_plan_covers_every_list_position_once():
-    """csrc/sgr_blend.hip tile_backward: a list of `eff` splats is cut from the far end into chunks of 64 / 32 / 16 / 8 / 4 lanes
-    (width rounded up when the chunk would be at least 3/4 full).  Every position belongs to exactly one chunk, chunks run
-    back to front, and the iteration count (32 * width / 64 per chunk) never exceeds the one-64-chunk-per-64-splats plan."""
-    for eff in range(1, 700):
-        end, seen, iters = eff, [], 0
+    """csrc/sgr_blend.hip tile_backward: a list of `eff` splats is cut from the far end into chunks of 64 / 32 / 16 / 8 / 4 lanes --
+    the binary expansion of the length, a width rounded up only from 13 / 29 / 61 splats (round 4; round 3 rounded up from 3/4 full).
+    Every position belongs to exactly one chunk, chunks run back to front, and the plan never takes more loop iterations (32 * width
+    / 64 per chunk) than round 3's."""
+    def plan(eff, cut):
+        # instructions of one loop iteration by chunk width (ISA of the round-4 build, un-stashed loops) and of a chunk's prologue + epilogue
+        per_iteration, per_chunk = {64: 85, 32: 83, 16: 76, 8: 69, 4: 71}, 95
+        end, seen, iters, cost = eff, [], 0, 0
         while end > 0:
-            gw = 64 if end >= 48 else 32 if end >= 24 else 16 if end >= 12 else 8 if end >= 5 else 4
+            gw = 64 if end >= cut[0] else 32 if end >= cut[1] else 16 if end >= cut[2] else 8 if end >= 5 else 4
             start = 0 if gw >= end else end - gw
             assert end - start <= gw
             seen = list(range(start, end)) + seen
             iters += 32 * gw // 64
+            cost += (32 * gw // 64) * per_iteration[gw] + per_chunk
             end = start
         assert seen == list(range(eff))
-        old = 32 * ((eff + 63) // 64) if eff > 32 else (16 if eff > 16 else 8 if eff > 8 else 4 if eff > 4 else 2)
-        assert iters <= old + (2 if eff <= 32 else 0), (eff, iters, old)
+        return iters, cost
+
+    for eff in range(1, 700):
+        iters, cost = plan(eff, (61, 29, 13))
+        old_iters, old_cost = plan(eff, (48, 24, 12))
+        assert iters <= old_iters, (eff, iters, old_iters)
+        assert cost <= old_cost, (eff, cost, old_cost)        # (fewer iterations always pay for the extra chunk prologues)
+
+
+def test_narrow_backward_groups_interleaved_in_their_dpp_row():
+    """csrc/sgr_blend.hip bwd_chunk2: for GW = 8 / 4 the 16 / GW groups of a DPP row own the lanes l16 % (16 / GW); a lane's position in
+    its group is l16 / (16 / GW).  (lane -> (group, position)) must be a bijection onto 64 / GW groups x GW positions, "the previous
+    lane of my group" must be the lane 16 / GW below IN THE SAME ROW (what row_shr:(16/GW) reads) and must not exist for position 0
+    (the DPP source is then out of the row: the lane keeps its value), and the quad_perm pairing of the chunk's final reduction must
+    meet all groups of a row."""
+    for GW in (8, 4):
+        gpr = 16 // GW
+        seen = {}
+        for lane in range(64):
+            row, l16 = lane >> 4, lane & 15
+            sub, sl = row * gpr + (l16 & (gpr - 1)), l16 // gpr
+            assert 0 <= sub < 64 // GW and 0 <= sl < GW
+            assert (sub, sl) not in seen
+            seen[(sub, sl)] = lane
+        assert len(seen) == 64
+        for (sub, sl), lane in seen.items():
+            src = (lane & 15) - gpr                         # row_shr:gpr
+            if sl == 0:
+                assert src < 0                              # out of the row: the lane is disabled, keeps its value
+            else:
+                assert src >= 0 and seen[(sub, sl - 1)] == (lane & ~15) + src
+        # final reduction: lanes l ^ 1 (GW = 8) or l ^ 2 then l ^ 1 (GW = 4) hold the same position of the row's other groups
+        for lane in range(64):
+            row, l16 = lane >> 4, lane & 15
+            partners = {lane, lane ^ 1} if GW == 8 else {lane, lane ^ 1, lane ^ 2, lane ^ 3}
+            assert {((p & 15) // gpr) for p in partners} == {l16 // gpr}
+            assert {row * gpr + ((p & 15) & (gpr - 1)) for p in partners} == set(range(row * gpr, row * gpr + gpr))
+
+
+def test_tile_of_block_is_a_bijection_and_its_division_is_exact():
+    """csrc/sgr_blend.hip tile_of_block: workgroup b (hardware places it on XCD b % 8) -> 8x8 tile.  Every XCD walks a contiguous run of
+    16x16 super tiles, four tiles each; every tile of the image is owned by exactly one block of the grid 8 * 4 * ceil(nsuper / 8);
+    the division by the super-tile row length is a multiply-high by floor(2^32 / sgx) + 1 (LOff.sgx_magic), exact while
+    st * sgx < 2^32."""
+    for W, H in ((640, 480), (640, 320), (512, 384), (320, 240), (96, 64), (50, 37), (16, 16), (1296, 968), (4000, 3000)):
+        sgx, sgy = (W + 15) // 16, (H + 15) // 16
+        gx, gy = (W + 7) // 8, (H + 7) // 8
+        nsuper = sgx * sgy
+        per = (nsuper + 7) >> 3
+        magic = (1 << 32) // sgx + 1
+        assert nsuper * sgx < 1 << 32
+        owners = {}
+        for b in range(8 * 4 * per):
+            j = b >> 3
+            st, wv = (b & 7) * per + (j >> 2), j & 3
+            if st >= nsuper or j >= 4 * per:
+                continue
+            row = (st * magic) >> 32
+            assert row == st // sgx
+            tx, ty = (st - row * sgx) * 2 + (wv & 1), row * 2 + (wv >> 1)
+            if tx >= gx or ty >= gy:
+                continue
+            assert (tx, ty) not in owners
+            owners[(tx, ty)] = b
+        assert len(owners) == gx * gy
+        # the four tiles of a super tile sit on ONE XCD, in consecutive slots of its queue
+        for (tx, ty), b in owners.items():
+            assert owners.get((tx ^ 1, ty), b) & 7 == b & 7 and owners.get((tx, ty ^ 1), b) & 7 == b & 7
+
+
+def test_g_stash_fits_the_unused_part_of_the_wave_slice():
+    """csrc/sgr_blend.hip: a list of <= 16 splats is staged pair-interleaved (96 bytes per pair, an odd list padded by one splat) in the
+    first 864 bytes of the wave's LDS slice; the stash (16 rows of 64 pixels, 66 floats apart) must end before the pixel state that
+    follows the staging (64 x 48 B) and sorted-index (512 x 4 B) areas, and a row stride of 66 floats keeps the 16 lanes of a group on
+    distinct bank pairs for their 8-byte reads."""
+    staging = ((16 >> 1) + 1) * 96
+    assert staging == 864
+    assert staging + 16 * 66 * 4 <= 64 * 48 + 512 * 4
+    for gp in range(32):
+        banks = set()
+        for idx in range(16):
+            a = idx * 66 + 2 * gp
+            assert a % 2 == 0                              # 8-byte aligned
+            banks |= {a % 64, (a + 1) % 64}
+        assert len(banks) == 32
 
 
 def test_plane_cull_is_conservative_for_the_exact_rectangle_test():
