@@ -246,13 +246,15 @@ __device__ __forceinline__ float group_shr1<4>(float v, float fill, int) { retur
 //   prev_plus(): prev(q) + c, the first lane gets 0 + c (bound_ctrl:0 reads an out-of-range source as zero).
 // GW = 32 has a first lane in the middle of the wave-wide shift (lane 32): one select puts it right.
 #define SGR_PREV2(INS, CTRL, TAIL) "s_nop 1\n\t" INS " %0, %2, %4 " CTRL " row_mask:0xf bank_mask:0xf" TAIL "\n\t" INS " %1, %3, %5 " CTRL " row_mask:0xf bank_mask:0xf" TAIL "\n\ts_nop 1"
+// (in place: r enters as m and is its own second source, so no copy of m is made unless the caller still needs it)
+#define SGR_PREVT2(CTRL) "s_nop 1\n\tv_mul_f32_dpp %0, %2, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_mul_f32_dpp %1, %3, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\ts_nop 1"
 template <int GW>
 __device__ __forceinline__ v2f prev_times(float p0, float p1, v2f m, int lane) {
   v2f r = m;
-  if constexpr (GW == 16) asm(SGR_PREV2("v_mul_f32_dpp", "row_shr:1", "") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1), "v"(m.x), "v"(m.y));
-  else if constexpr (GW == 8) asm(SGR_PREV2("v_mul_f32_dpp", "row_shr:2", "") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1), "v"(m.x), "v"(m.y));
-  else if constexpr (GW == 4) asm(SGR_PREV2("v_mul_f32_dpp", "row_shr:4", "") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1), "v"(m.x), "v"(m.y));
-  else asm(SGR_PREV2("v_mul_f32_dpp", "wave_shr:1", "") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1), "v"(m.x), "v"(m.y));
+  if constexpr (GW == 16) asm(SGR_PREVT2("row_shr:1") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1));
+  else if constexpr (GW == 8) asm(SGR_PREVT2("row_shr:2") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1));
+  else if constexpr (GW == 4) asm(SGR_PREVT2("row_shr:4") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1));
+  else asm(SGR_PREVT2("wave_shr:1") : "+v"(r.x), "+v"(r.y) : "v"(p0), "v"(p1));
   if (GW == 32 && lane == 32) r = m;
   return r;
 }
@@ -330,7 +332,7 @@ struct SrcStaged {
 // One chunk = the list positions [start, start + GW) (those below `end`) against the 64 pixels of the tile, 2*64/GW pixels
 // per iteration.  Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix
 // scan.  Chunks run back to front; `carry`: more (nearer) chunks follow, leave (T, S) in front of this chunk per pixel.
-// LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | nc0,nc1, x0,y) for pair g.
+// LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | x0,y, nc0,nc1) for pair g.
 template <int GW, typename SRC, bool STASH = false>
 __device__ __forceinline__ void bwd_chunk2(
     int lane, int start, int end, bool carry, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
@@ -364,12 +366,13 @@ __device__ __forceinline__ void bwd_chunk2(
     const float4 b0 = pixB2[gp * 2];
     float4 b1 = pixB2[gp * 2 + 1];
     asm volatile("" : "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));      // (one ds_read_b128: the compiler split it into three reads)
-    const int nc0 = __float_as_int(b1.x), nc1 = __float_as_int(b1.y);
+    const int nc0 = __float_as_int(b1.z), nc1 = __float_as_int(b1.w);
     if (GW == kWave && __builtin_amdgcn_readfirstlane(max(nc0, nc1)) <= start) continue;   // both ended before this chunk
-    // pixels 2 gp, 2 gp + 1 (same row): their coordinates were staged with the pixel state (b1.z = x of the first, b1.w = y; both
-    // exact integers) -- rebuilding them from gp cost 8 of an iteration's instructions
-    const v2f dx = splat2(mx) - (v2f){b1.z, b1.z + 1.f};
-    const v2f dy = splat2(my) - splat2(b1.w);
+    // pixels 2 gp, 2 gp + 1 (same row): their coordinates were staged with the pixel state (b1.x = x of the first, b1.y = y; both
+    // exact integers) -- rebuilding them from gp cost 8 of an iteration's instructions.  x sits in the EVEN register of the read and
+    // y is consumed first, so the pair (x, x + 1) forms in place: with (nc0, nc1, x, y) the compiler moved three registers around
+    const v2f dy = splat2(my) - splat2(b1.y);
+    const v2f dx = splat2(mx) - (v2f){b1.x, b1.x + 1.f};
     v2f G, power = {0.f, 0.f};
     if constexpr (STASH) {
       const float2 gs = *(const float2*)(my_stash + 2 * gp);     // what the forward walk computed for these two pixels (-1: power > 0)
@@ -506,8 +509,8 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
     float* fa = (float*)pixA + (lane >> 1) * 8 + (lane & 1);
     float* fb = (float*)pixB + (lane >> 1) * 8 + (lane & 1);
     fa[0] = pxA[0]; fa[2] = pxA[1]; fa[4] = pxA[2]; fa[6] = pxA[3];
-    fb[0] = pxB[0]; fb[2] = pxB[1]; fb[4] = pxB[2];
-    fb[6] = (lane & 1) ? (float)(ty * kTile + (lane >> 3)) : (float)(tx * kTile + (lane & 7));     // the pair's x0 | y
+    fb[0] = pxB[0]; fb[2] = pxB[1]; fb[6] = pxB[2];
+    fb[4] = (lane & 1) ? (float)(ty * kTile + (lane >> 3)) : (float)(tx * kTile + (lane & 7));     // the pair's x0 | y
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
