@@ -9,7 +9,7 @@
 //   * a bin is 8x8 pixels = exactly one wave64 = one workgroup (no __syncthreads in either kernel); the four tiles of a
 //     16x16 reference tile run back to back on the same XCD (tile_of_block).
 //   * FORWARD first sorts its tile's (depth bits | Gaussian) keys: <= 64 keys in registers (every lane ranks its key
-//     against the others, broadcast through SGPRs), <= 256 / 4096 keys bitonic in the wave's LDS slice, longer lists in
+//     against the others, broadcast through LDS), <= 512 keys bitonic in registers, <= 1024 / 4096 in the wave's LDS slice, longer lists in
 //     place in HBM (slow path).  Then it is pixel-parallel (lane = pixel): 64 sorted splats at a time are staged into LDS
 //     pair-interleaved and walked TWO splats per trip with broadcast ds_read_b128 + packed fp32 (v_pk_*_f32); per-pixel
 //     accumulators stay in VGPRs.  n_touched is one ballot+popcount+atomic per (wave, splat), not per pixel.
