@@ -1,0 +1,113 @@
+"""The tile kernels are VALU-issue bound: their time IS their instruction count, and a good part of round 4 was
+removing instructions the compiler had added on its own (a canonicalising v_max behind fminf, copies around DPP operands, compares
+issued twice, 64-bit address arithmetic).  This test compiles csrc/sgr_blend.hip to gfx950 assembly (no GPU needed) and holds the hot
+loops of the fused tile kernel to their measured budgets, so that a source change or a compiler update that undoes that work fails
+HERE and not as a slower bench line."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FUSED = "_ZN3sgr16blend_fwd_kernelILi512ELb1EEE"
+
+
+@pytest.fixture(scope="module")
+def fused_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("isa") / "blend.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", out,
+                    os.path.join(ROOT, "splat_slam_amd", "csrc", "sgr_blend.hip")], check=True, capture_output=True)
+    text = open(out).read()
+    lines = text.split("\n")
+    a = next(i for i, l in enumerate(lines) if l.startswith(FUSED) and l.rstrip().endswith(":") or l.startswith(FUSED) and ":" in l[:len(FUSED) + 80])
+    b = next(i for i in range(a, len(lines)) if "s_endpgm" in lines[i])
+    meta = text[text.index(".name:           " + FUSED):]
+    meta = meta[:meta.index("\n  - ") if "\n  - " in meta else len(meta)]
+    return lines[a:b + 1], text, meta
+
+
+def _valu(block):
+    return sum(1 for l in block if re.match(r"\s+v_", l))
+
+
+def _loops(lines):
+    """(instructions, has v_rcp, has v_exp) of every innermost loop body that evaluates splats."""
+    out = []
+    for h, l in enumerate(lines):
+        if "Inner Loop Header: Depth=2" not in l:
+            continue
+        label = None
+        for k in range(h, max(h - 4, 0), -1):
+            m = re.match(r"(\.LBB\d+_\d+):", lines[k])
+            if m:
+                label = m.group(1)
+                break
+        if label is None:
+            continue
+        # the body = from the block that branches (s_branch) to the header up to the loop's last back edge
+        s = h
+        while s > h - 80 and s > 0 and not re.match(r"\s+s_branch\s+" + re.escape(label) + r"\s*$", lines[s]):
+            s -= 1
+        if not re.match(r"\s+s_branch\s+" + re.escape(label) + r"\s*$", lines[s]):
+            continue                              # (not the rotated loop shape of the chunk loops)
+        e = h
+        while e < len(lines) - 1 and (not re.match(r"\s+s_c?branch\w*\s+\.LBB", lines[e]) or e < h + 20):
+            e += 1
+        body = lines[s + 1:e + 1]
+        out.append((_valu(body), any("v_rcp_f32" in x for x in body), any("v_exp_f32" in x for x in body)))
+    return out
+
+
+def test_fused_tile_kernel_keeps_its_registers_and_has_no_scratch(fused_asm):
+    _, _, meta = fused_asm
+    vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+    spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
+    assert vgpr <= 96, f"{vgpr} VGPRs: fewer than 5 waves per SIMD"
+    assert spill == 0 and scratch == 0, (spill, scratch)
+
+
+def test_backward_loops_stay_within_their_instruction_budget(fused_asm):
+    lines, _, _ = fused_asm
+    loops = _loops(lines)
+    bwd = [n for n, rcp, ex in loops if rcp and ex]            # re-evaluates the footprint: 64 / 32 / 16 / 8 / 4 lanes, two sources
+    stash = [n for n, rcp, ex in loops if rcp and not ex]      # reads exp(power) back from the G stash: 16 / 8 / 4 lanes
+    assert len(bwd) >= 10 and len(stash) >= 3, loops
+    assert max(bwd) <= 88, sorted(bwd)                         # (round 3: 97; measured at the end of round 4: 81-83 at 64 lanes)
+    assert min(bwd) <= 68, sorted(bwd)                         # (8 lanes: 65)
+    assert max(stash) <= 65, sorted(stash)                     # (16 lanes: 62; 75 without the stash)
+
+
+def test_forward_walk_stays_within_its_instruction_budget(fused_asm):
+    lines, _, _ = fused_asm
+    # walk bodies: basic blocks with two v_exp_f32 and no v_rcp_f32 that read the pair-interleaved staging area
+    walks = []
+    for i, l in enumerate(lines):
+        if not re.match(r"\.LBB\d+_\d+:", l):
+            continue
+        j = i + 1
+        while j < len(lines) and not re.match(r"\.LBB\d+_\d+:", lines[j]) and "s_cbranch" not in lines[j]:
+            j += 1
+        block = lines[i:j + 1]
+        if sum("v_exp_f32" in x for x in block) == 2 and not any("v_rcp_f32" in x for x in block) and sum("ds_read_b128" in x for x in block) >= 4:
+            walks.append((_valu(block), any("ds_write" in x for x in block), any("global_atomic" in x for x in block)))
+    plain = [n for n, st, at in walks if not st and not at]
+    stashing = [n for n, st, at in walks if st and not at]
+    assert plain and stashing, walks
+    assert min(plain) <= 37, walks                             # (two splats per trip: 35; 45 in round 3)
+    assert min(stashing) <= 41, walks                          # (+3: the masked exp(power) of both splats goes to the stash)
+
+
+def test_no_v_readlane_in_the_rank_sort(fused_asm):
+    """A one-chunk tile ranks its keys through LDS broadcasts: no loop of the kernel may read a lane per iteration through SGPRs (a
+    v_readlane costs the VALU-saturated SIMD more than its issue slot: -2.5 % of the kernel when they went)."""
+    lines, _, _ = fused_asm
+    for h, l in enumerate(lines):
+        if "Inner Loop Header" in l:
+            body = lines[h:h + 12]
+            assert not any("v_readlane_b32" in x for x in body), body
