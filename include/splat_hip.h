@@ -382,7 +382,10 @@ typedef struct SgrMapStep {
                                   optimiser-only step follow)
                                   -3: like -2, but the pass STORES the sums (zeros for Gaussians no view of the batch sees)
                                   into the sinks of all num_gaussians rows instead of adding: the sinks need not be zeroed
-                                  between two iterations (one 56 B x N memset per exchange less) */
+                                  between two iterations (one 56 B x N memset per exchange less).  A batch that cannot take the
+                                  fused gather pass (a view asks for dL_dtau, heterogeneous views, > 16 views) has its sinks
+                                  zeroed by the library first and is then accumulated: the sinks hold this call's sums on
+                                  every path */
 } SgrMapStep;
 int sgr_map_step(const SgrMapStep* step, void* stream);
 

@@ -344,9 +344,13 @@ int sgr_backward_views(int32_t num_views, const SgrBackwardView* views, const Sg
 }  // extern "C"
 
 // fused: optimiser tail to run inside the gather pass; *fused_done tells whether it did (uniform single-chunk batches only)
+// store_sinks: the caller promised its gradient sinks STORE semantics (SgrMapStep.grads_clean == -3: every row is overwritten, the
+// sinks need not be zero on entry).  Only the fused gather pass can store; whenever a batch does not take it (pose gradients asked
+// for, heterogeneous views, more than kMaxViews) the accumulating passes run instead -- onto sinks that are zeroed HERE first, so
+// that the promise holds on every path (it used to add this iteration's sums to the previous iteration's leftovers).
 static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrInputs* in, const SgrGradInputs* grads, float alpha,
                           float rgb_boundary_threshold, int32_t forward_only, FusedAdam* fused, bool* fused_done,
-                          void* stream) {
+                          void* stream, bool store_sinks = false) {
   if (fused_done) *fused_done = false;
   if (num_views < 0 || (num_views > 0 && (!views || !in)) || (!forward_only && !grads))
     return set_error(SGR_ERR_INVALID, "map_views: null argument");
@@ -369,6 +373,14 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
     for (int u = 0; u < v; ++u) uniform = uniform && views[u].ws.scratch != m.ws.scratch && views[u].ws.saved != m.ws.saved;
     if (!forward_only && grads && !grads->accumulate && num_views > 1)
       return set_error(SGR_ERR_INVALID, "map_views: several views need accumulate != 0");
+  }
+  if (store_sinks && !forward_only && grads && !(fused && uniform && f.settings.num_gaussians > 0 && num_views <= kMaxViews)) {
+    const size_t n = (size_t)f.settings.num_gaussians, m = (size_t)(f.settings.sh_coeffs > 0 ? f.settings.sh_coeffs : 1);
+    if (grads->dL_dmeans3D) HIP_TRY(hipMemsetAsync(grads->dL_dmeans3D, 0, n * 12, st));
+    if (grads->dL_dshs) HIP_TRY(hipMemsetAsync(grads->dL_dshs, 0, n * m * 12, st));
+    if (grads->dL_dopacities) HIP_TRY(hipMemsetAsync(grads->dL_dopacities, 0, n * 4, st));
+    if (grads->dL_dscales) HIP_TRY(hipMemsetAsync(grads->dL_dscales, 0, n * 12, st));
+    if (grads->dL_drotations) HIP_TRY(hipMemsetAsync(grads->dL_drotations, 0, n * 16, st));
   }
   if (!uniform || f.settings.num_gaussians == 0) {       // heterogeneous views: one after the other (shared scratch is fine)
     for (int v = 0; v < num_views; ++v) {
@@ -529,7 +541,7 @@ static int map_step_impl(const SgrMapStep* p, bool skip_activate, bool grads_cle
   bool fused = false;
   if (p->num_views > 0)
     if (int rc = map_views_impl(p->num_views, p->views, p->in, p->grads, p->alpha, p->rgb_boundary_threshold, p->forward_only,
-                                try_fuse ? &fa : nullptr, &fused, stream))
+                                try_fuse ? &fa : nullptr, &fused, stream, p->grads_clean == -3 && !p->adam_groups))
       return rc;
   if (p->adam_groups && !fused)
     if (int rc = gaussian_adam_step_act(p->num_gaussians, p->adam_groups, p->beta1, p->beta2, p->eps, p->iso_weight,

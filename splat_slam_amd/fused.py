@@ -264,11 +264,14 @@ class FusedMappingLoop(MappingLoop):
         self._flat_dirty = False  # ZeRO-1 store-mode exchange: the flat sinks hold the last local sums, not zeros (see _exchange_and_adam)
         self._scratch = None
         self._since_check = 0
-        # True: the PERIODIC capacity check of map() posts its header read-back and looks at it one check later (no host wait).
-        # Off by default: with the batched read-back the synchronous check costs the session nothing measurable (71.2 vs 71.5 ms
-        # per keyframe), and a late report leaves a truncated view in the optimisation for one more interval.
-        self.async_checks = os.environ.get("SPLAT_ASYNC_CHECKS", "0") == "1"
-        self._pending_check = None
+        # Never drop (round 5): everything enqueued since the last capacity check is a TRANSACTION -- a snapshot of the optimisation
+        # state taken before its first launch plus a journal of the launches.  A check that finds a truncated forward restores the
+        # snapshot, grows the capacity and re-issues the journal (_txn_commit), so a view that overflowed takes part in every step
+        # after all, like upstream's rasterizer, which sizes its buffers inside the call (README.md:88-92 module).
+        self._txn = None
+        self._txn_pool = None      # snapshot buffers, reused while the tensor shapes stay
+        self._replaying = False
+        self.replayed_transactions = 0
         self._hdr_pinned = None
         self._gen = 0              # bumped whenever cached launch structs go stale (capacity, hints, buffers)
         self._pair_hint = {}       # camera uid -> (measured pair count, map size it was measured at)
@@ -306,7 +309,7 @@ class FusedMappingLoop(MappingLoop):
         self._plan_key = self._plan_obj = None
         self._ws_owners.clear()
         self._slots = []
-        self._pending_check = None
+        self._txn = None
 
     # ------------------------------------------------------------------------------------------------ state
     def set_parallel(self, world, rank, split_views=True, sync="zero1", comm=None):
@@ -597,7 +600,8 @@ class FusedMappingLoop(MappingLoop):
             self._probe(cam, vb)
             return
         vb.pairs, vb.estimated = est, True
-        self._since_check = max(self._since_check, self.check_every - 2)      # measure soon
+        if self.world == 1:        # (several ranks: the checks carry a collective and must fall on the same iterations everywhere)
+            self._since_check = max(self._since_check, self.check_every - 2)      # measure soon
 
     def _probe(self, cam, vb):
         """One synchronous forward to learn this camera's pair count at the current map size."""
@@ -762,9 +766,9 @@ class FusedMappingLoop(MappingLoop):
             self._plan_obj, self._plan_key = pl, key
         return self._plan_obj
 
-    def _setup(self, pl, iso_weight, adam, skip, stats, forward_only, exposure, bump=True):
+    def _setup(self, pl, iso_weight, adam, skip, stats, forward_only, exposure, bump=True, lrs=None):
         """Fills the view-independent part of pl.step.  bump: advance the Adam step counters here (one iteration);
-        sgr_map_run advances them itself."""
+        sgr_map_run advances them itself.  lrs: learning rates by group name (default: the optimiser's current ones)."""
         st = pl.step
         st.forward_only = int(forward_only)
         st.grads_clean = int(self._acc_clean) if self.fuse_tail else -1
@@ -772,7 +776,7 @@ class FusedMappingLoop(MappingLoop):
         if adam and not forward_only:
             for k, (g, stt) in enumerate(pl.states):
                 grp = pl.groups[k]
-                grp.lr = float(g["lr"])
+                grp.lr = float(g["lr"]) if lrs is None else lrs[_GROUPS[k]]
                 if _GROUPS[k] in skip:
                     grp.skip = 1
                 else:
@@ -816,20 +820,30 @@ class FusedMappingLoop(MappingLoop):
             raise RuntimeError("_run_span is the single-GPU fast path")
         self._settle_capacity(list(window_cams) + list(pool_cams))               # estimates for new cameras, ONE capacity
         per0 = len(picks) // n_it if picks else 0
-        if n_it > 1 and not verified and any(self._views[c.uid].estimated for c in
-                                             list(window_cams) + [pool_cams[k] for k in picks[:per0]]):
+        if (n_it > 1 and not verified and not self._replaying
+                and any(self._views[c.uid].estimated for c in list(window_cams) + [pool_cams[k] for k in picks[:per0]])):
             self._run_span(window_cams, pool_cams, picks[:per0], lrs[:1], iso_weight, exposure, stats, initialization, verified=True)
             # the launch structs of the rest are built while that iteration runs; the read-back then only decides whether they stand
             rest = (window_cams, pool_cams, picks[per0:], lrs[1:], iso_weight, exposure, stats, initialization)
             prep = self._prepare_span(*rest)
-            gen = self._gen
-            if not self.check_overflow():
+            if not self._txn_commit():               # (an estimate that was short: the iteration has been re-run at the right capacity)
                 for k in picks[:per0]:               # (rendered in the slots that were just read back: their estimates held)
                     self._views[pool_cams[k].uid].estimated = False
-            if self._gen != gen:                     # capacity / sort build changed: the structs are stale
-                prep = self._prepare_span(*rest)
-            return self._launch_span(prep)
-        return self._launch_span(self._prepare_span(window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats, initialization))
+            return self._span_entry(rest, prep)
+        return self._span_entry((window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats, initialization))
+
+    def _span_entry(self, args, prep=None):
+        """Enqueues a span as part of the open transaction.  `prep`: launch structs built ahead of time -- used if the capacity /
+        sort build they were made for still stands (a replay after a correction builds its own)."""
+        args = tuple(list(a) if isinstance(a, (list, tuple)) else a for a in args)
+        box = [prep]
+
+        def fn():
+            pr, box[0] = box[0], None
+            if pr is None or pr[-1] != self._gen:
+                pr = self._prepare_span(*args)
+            self._launch_span(pr)
+        return self._txn_do(fn)
 
     def _prepare_span(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats, initialization):
         """Everything sgr_map_run needs, as ctypes objects (kept alive by the returned tuple)."""
@@ -862,10 +876,10 @@ class FusedMappingLoop(MappingLoop):
                 (self._exp.row_of(c) if self._exp is not None and self._exp.row_of(c) in self._exp_rows else -1)
                 for c in pool_cams])
             run.pool_exp_row = rows
-        return run, pl, n_it, per, list(window_cams), list(pool_cams), list(picks), (win, pool, pk, lr, slots, rows)
+        return run, pl, n_it, per, list(window_cams), list(pool_cams), list(picks), (win, pool, pk, lr, slots, rows), self._gen
 
     def _launch_span(self, prep):
-        run, pl, n_it, per, window_cams, pool_cams, picks, _keep = prep
+        run, pl, n_it, per, window_cams, pool_cams, picks, _keep, _gen = prep
         self._clean_flat()
         rc = self.lib.sgr_map_run(C.byref(run), self._stream())
         nat.check(rc, "sgr_map_run")
@@ -880,6 +894,10 @@ class FusedMappingLoop(MappingLoop):
         pl.frest_state["step"] += n_it
 
     def _run_span_ranks(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True):
+        args = (list(window_cams), list(pool_cams), list(picks), list(lrs), iso_weight, exposure, stats)
+        return self._txn_do(lambda: self._run_span_ranks_impl(*args))
+
+    def _run_span_ranks_impl(self, window_cams, pool_cams, picks, lrs, iso_weight, exposure, stats=True):
         """The multi-GPU form of _run_span.  Per iteration: (1) this rank's share of the views, gradient sums added into the
         flat buffer (the gather pass of the fused form, no optimiser; the loss sums ride in that launch); (2) the exchange:
         reduce-scatter -> Adam on this rank's rows -> all-gather (or all-reduce -> replicated Adam); (3) the exposure rows,
@@ -899,7 +917,7 @@ class FusedMappingLoop(MappingLoop):
         C.memmove(C.byref(views_st), C.byref(st), C.sizeof(st))
         # store mode (-3) while the sinks hold nothing that must survive: the gather pass overwrites every row, nobody zeroes the
         # flat buffer between iterations; a prune pass's leftovers (not _acc_clean) are ADDED to (-2) and the buffer zeroed after
-        stored = self._acc_clean and self._zero is not None
+        stored = self._acc_clean and self._zero is not None and self.keyframe_optimizers is None      # (pose gradients: no fused gather pass, see _step)
         if not stored:
             self._clean_flat()
         views_st.adam_groups, views_st.grads_clean, views_st.exp_rows = None, (-3 if stored else -2), 0
@@ -940,7 +958,17 @@ class FusedMappingLoop(MappingLoop):
 
     def _step(self, cams, iso_weight=0.0, adam=True, skip=(), initialization=False, stats=True, forward_only=False,
               exposure="none", activate=True):
-        """ONE host call: activate -> batched views (forward / loss / backward) -> Adam -> exposure Adam."""
+        """ONE host call: activate -> batched views (forward / loss / backward) -> Adam -> exposure Adam.  Anything but a
+        forward-only render is part of the open transaction (see _txn_commit); the learning rates it steps with are the ones of
+        THIS moment, also when it is issued again."""
+        if forward_only:
+            return self._step_impl(cams, iso_weight, adam, skip, initialization, stats, True, exposure, activate, None)
+        cams = list(cams)
+        exposure = list(exposure) if isinstance(exposure, list) else exposure
+        lrs = {g["name"]: float(g["lr"]) for g in self.gaussians.optimizer.param_groups}
+        return self._txn_do(lambda: self._step_impl(cams, iso_weight, adam, tuple(skip), initialization, stats, False, exposure, activate, lrs))
+
+    def _step_impl(self, cams, iso_weight, adam, skip, initialization, stats, forward_only, exposure, activate, lrs):
         pl = self._plan()
         par = self._parallel() and not forward_only
         all_cams = cams
@@ -951,7 +979,7 @@ class FusedMappingLoop(MappingLoop):
         arr = self._views_array(cams, initialization)
         if adam and not forward_only and "scaling" not in skip and self._stale_iso:
             iso_weight, self._stale_iso = iso_weight + self._stale_iso, 0.0     # the prune pass's share rides in this step
-        st = self._setup(pl, iso_weight, adam, skip, stats, forward_only, exposure)
+        st = self._setup(pl, iso_weight, adam, skip, stats, forward_only, exposure, lrs=lrs)
         st.num_views, st.views = len(cams), arr
         if not activate:
             sc, st.scaling = st.scaling, None
@@ -964,7 +992,11 @@ class FusedMappingLoop(MappingLoop):
             iso = st.iso_weight if do_adam else 0.0
             st.adam_groups, st.exp_rows = None, 0
             # store mode (see _run_span_ranks): this rank's views overwrite every row of the sinks, which hold nothing to keep
-            stored = do_adam and self.fuse_tail and self._acc_clean and self._zero is not None and len(cams) > 0
+            # (only the fused gather pass can store, and a batch that asks for pose gradients -- mapping.BA -- does not take it: the
+            #  library then zeroes the sinks itself before its accumulating passes (sgr_api.hip: store_sinks), but there is nothing to
+            #  gain, so such iterations keep the add mode)
+            stored = (do_adam and self.fuse_tail and self._acc_clean and self._zero is not None and len(cams) > 0
+                      and self.keyframe_optimizers is None)
             if not stored:
                 self._clean_flat()
             if do_adam and self.fuse_tail:
@@ -972,8 +1004,8 @@ class FusedMappingLoop(MappingLoop):
             rc = self.lib.sgr_map_step(C.byref(st), self._stream()) if (len(cams) or activate) else 0
             if rc == 0 and do_adam:
                 self._exchange_and_adam(pl, iso, skip, stored=stored)
-                if exposure != "none" and len(all_cams):
-                    self._exposure_step(all_cams, only_rendered=isinstance(exposure, list))
+                if exposure != "none" and len(all_cams):     # (never with pose optimisation: map() then passes "none" and steps after)
+                    self._exposure_slab_step(all_cams, only_rendered=isinstance(exposure, list))
         else:
             if not forward_only:
                 self._clean_flat()
@@ -1067,6 +1099,16 @@ class FusedMappingLoop(MappingLoop):
             sl.ran = False
 
     def _exposure_step(self, cams, only_rendered=False):
+        """The keyframe optimisers' step after an iteration that did not carry it in its own launch: exposure rows (slab, part of
+        the open transaction) and -- with mapping.BA -- the pose deltas (torch Adam; the transaction is closed first, so the pose
+        gradients it consumes come from forwards that are known to be complete)."""
+        cams = list(cams)
+        self._txn_do(lambda: self._exposure_slab_step(cams, only_rendered))
+        if self.keyframe_optimizers is not None:
+            self._txn_commit()
+            self._pose_step(cams)
+
+    def _exposure_slab_step(self, cams, only_rendered=False):
         if self._exp is None or not self._exp_rows:
             pass
         elif only_rendered:       # final_refine: torch's Adam only touches parameters that HAVE a gradient: the rendered
@@ -1083,12 +1125,24 @@ class FusedMappingLoop(MappingLoop):
             self._exp.add_stale(self._exp_rows)
             self._exposure_exchange(self._exp_rows)
             self._exp.step_mask(self.lib, self._exp_rows, self._stream())
+
+    def _pose_step(self, cams):
         if self.keyframe_optimizers is not None:
-            for cam in cams:
-                vb = self._views[cam.uid]
+            if self._parallel() and self.split_views:
+                # every camera of the iteration was rendered by ONE rank (view i by rank i mod world): the pose gradients meet in one
+                # small all-reduce, every rank then takes the identical pose step (replicas stay bitwise equal)
+                tau = torch.zeros((len(cams), 6), dtype=torch.float32, device=self.device)
+                for i, cam in enumerate(cams):
+                    if i % self.world == self.rank:
+                        tau[i] = self._views[cam.uid].d_tau
+                self.comm.all_reduce(tau)
+                taus = [tau[i] for i in range(len(cams))]
+            else:
+                taus = [self._views[cam.uid].d_tau for cam in cams]
+            for cam, t in zip(cams, taus):
                 if cam.cam_rot_delta.requires_grad:
-                    cam.cam_trans_delta.grad = vb.d_tau[:3].clone()
-                    cam.cam_rot_delta.grad = vb.d_tau[3:].clone()
+                    cam.cam_trans_delta.grad = t[:3].clone()
+                    cam.cam_rot_delta.grad = t[3:].clone()
             self.keyframe_optimizers.step()
             self.keyframe_optimizers.zero_grad(set_to_none=True)
 
@@ -1109,19 +1163,18 @@ class FusedMappingLoop(MappingLoop):
         ev.record(torch.cuda.current_stream(self.device))
         return host, ev
 
-    def _apply_headers(self, todo, host, fresh):
-        """What a capacity check does with the headers it read.  fresh: the map has not changed size since the read was posted
-        (otherwise the counts describe workspaces that no longer exist: only the overflow words still mean something)."""
+    def _apply_headers(self, todo, host):
+        """What a capacity check does with the headers it read: pair counts and list hints are refreshed, the capacity follows the
+        largest count, and the cameras whose forward was truncated are returned (the caller replays the transaction)."""
         words = host.numpy().view(np.uint32).reshape(-1, 16)
         worst, overflowed = 0, []
         for (uid, vb), w in zip(todo, words):
             ov = int(w[1])
-            if fresh:
-                self._apply_header(uid, vb, w)
-                if vb.pairs > self.max_pairs:
-                    raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
-                                       "the map has degenerated")
-                worst = max(worst, vb.pairs)
+            self._apply_header(uid, vb, w)
+            if vb.pairs > self.max_pairs:
+                raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
+                                   "the map has degenerated")
+            worst = max(worst, vb.pairs)
             if ov == 2:
                 raise RuntimeError(f"camera {uid}: more than 65280 splats on one 8x8 tile -- the map has degenerated")
             if ov:
@@ -1130,58 +1183,146 @@ class FusedMappingLoop(MappingLoop):
         if worst * 1.5 > self._cap or (worst > 0 and 8 * worst < self._cap and self._cap > (1 << 16)):
             self._cap = max(1 << 16, int(2.5 * worst))
             self._views_dirty()
-        elif overflowed and not fresh:
-            self._cap = int(1.5 * self._cap)           # (stale counts: grow blindly, the next check measures)
+        elif overflowed:                               # (cannot happen: an overflowed header carries a count beyond the capacity)
+            self._cap = int(1.5 * self._cap)
             self._views_dirty()
-        if overflowed:
-            import warnings
-            warnings.warn(f"FusedMappingLoop: the forward of camera(s) {overflowed} exceeded the (tile, Gaussian) pair capacity; those "
-                          "views took no part in the optimiser steps since the previous check (the workspace has been grown)",
-                          RuntimeWarning, stacklevel=3)
         return overflowed
 
-    def _harvest(self, wait):
-        """Looks at the read-back a periodic check posted earlier.  Returns the overflowed cameras ([] if nothing was pending or
-        the transfer has not finished and wait is False)."""
-        pend = self._pending_check
-        if pend is None:
-            return []
-        todo, host, ev, n_posted, bufs = pend
-        if not wait and not ev.query():
-            return []
-        ev.synchronize()
-        self._pending_check = None
-        fresh = n_posted == self.gaussians._xyz.shape[0] and all(vb.saved is not None and vb.saved.data_ptr() == b for (_, vb), b in zip(todo, bufs))
-        return self._apply_headers(todo, host, fresh)
-
-    def check_overflow(self, wait=True):
-        """Did any camera's forward exceed the pair capacity since the last check?  wait=True: one synchronisation, the answer
-        covers everything enqueued so far.  wait=False (the periodic check of the loops): the read-back is posted behind the
-        enqueued work and looked at by the NEXT check -- the host never waits and the GPU never idles; an overflow is reported
-        (and the capacity corrected) one check interval later."""
-        self._since_check = 0
-        overflowed = self._harvest(wait=True) if wait else self._harvest(wait=False)
-        if self._pending_check is not None:           # (wait=False and the previous read-back is still in flight: keep it)
-            return overflowed
+    def _read_overflows(self):
+        """One synchronisation: the headers of every workspace that ran a forward at this map size.  Returns the cameras (or
+        slots) whose last forward was truncated; the capacity has been corrected."""
         todo = self._check_targets()
         if not todo:
-            return overflowed
+            return []
         host, ev = self._post_headers(todo)
-        if wait:
-            ev.synchronize()
-            return overflowed + self._apply_headers(todo, host, True)
-        self._pending_check = (todo, host, ev, self.gaussians._xyz.shape[0], [vb.saved.data_ptr() for _, vb in todo])
-        return overflowed
+        ev.synchronize()
+        return self._apply_headers(todo, host)
+
+    # ---- transactions: never drop a view (see __init__) -----------------------------------------------------------------------
+    def _txn_tensors(self):
+        """Every device tensor an iteration of any of the loops mutates in place (parameters, Adam moments, densification
+        statistics, next-iteration activations, the exposure slab, the gradient sinks when they hold something)."""
+        gm = self.gaussians
+        ts = []
+        for g in gm.optimizer.param_groups:
+            p = g["params"][0]
+            if p.numel() == 0:
+                continue
+            ts.append(p.data)
+            st = gm.optimizer.state.get(p)
+            if st:
+                ts += [st["exp_avg"], st["exp_avg_sq"]]
+        ts += [gm.xyz_gradient_accum, gm.denom, gm.max_radii2D]
+        a = self._acc
+        if a is not None:
+            ts += [a["act_scale"], a["act_rot"], a["act_opac"]]
+        if self._exp is not None:
+            e = self._exp
+            ts += [e.param, e.grad, e.m, e.v, e.step, e.stale]
+        return ts
+
+    def _txn_begin(self):
+        """Opens a transaction in front of the first state-changing launch after a check (no-op while one is open)."""
+        if self._txn is not None or self._replaying:
+            return
+        gm = self.gaussians
+        ts = self._txn_tensors()
+        # the sinks are all-zero between optimiser steps unless a prune pass / a store-mode exchange left something in them: only
+        # then are they copied (56 B per Gaussian); otherwise a restore zeroes them
+        flat_live = self._acc is not None and ((not self._acc_clean) or self._flat_dirty)
+        if flat_live:
+            ts.append(self._acc["flat"])
+        pool = self._txn_pool
+        if pool is None or len(pool) != len(ts) or any(b.shape != t.shape or b.dtype != t.dtype for b, t in zip(pool, ts)):
+            pool = self._txn_pool = [torch.empty_like(t) for t in ts]
+        with torch.no_grad():
+            for dt in {t.dtype for t in ts}:
+                torch._foreach_copy_([b for b, t in zip(pool, ts) if t.dtype == dt], [t for t in ts if t.dtype == dt])
+        txn = _Plan()
+        txn.tensors, txn.saved, txn.flat_live, txn.journal = ts, pool, flat_live, []
+        steps = [gm.optimizer.state[g["params"][0]]["step"] for g in gm.optimizer.param_groups
+                 if gm.optimizer.state.get(g["params"][0])]
+        pl = self._plan_obj if self._plan_key is not None else None
+        txn.py = {"steps": [(t, float(t)) for t in steps], "plan": pl,
+                  "grp": [(int(pl.groups[k].step), float(pl.groups[k].lr), int(pl.groups[k].skip)) for k in range(5)] if pl is not None else None,
+                  "stale_iso": self._stale_iso, "acc_clean": self._acc_clean, "flat_dirty": self._flat_dirty,
+                  "exp_stale_rows": set(self._exp.stale_rows) if self._exp is not None else None,
+                  "stale_moments": self._zero.get("stale_moments") if self._zero is not None else None}
+        self._txn = txn
+
+    def _txn_do(self, fn):
+        """Runs a state-changing piece of enqueue work as part of the open transaction (opens one if needed)."""
+        if self._replaying:
+            return fn()
+        self._txn_begin()
+        self._txn.journal.append(fn)
+        return fn()
+
+    def _txn_restore(self):
+        txn = self._txn
+        with torch.no_grad():
+            for dt in {t.dtype for t in txn.tensors}:
+                torch._foreach_copy_([t for t in txn.tensors if t.dtype == dt], [b for b, t in zip(txn.saved, txn.tensors) if t.dtype == dt])
+            if not txn.flat_live and self._acc is not None:
+                self._acc["flat"].zero_()
+        py = txn.py
+        for t, v in py["steps"]:
+            t.fill_(v)
+        if py["plan"] is not None and py["plan"] is self._plan_obj:
+            for k, (step, lr, skip) in enumerate(py["grp"]):
+                g = py["plan"].groups[k]
+                g.step, g.lr, g.skip = step, lr, skip
+        self._stale_iso, self._acc_clean, self._flat_dirty = py["stale_iso"], py["acc_clean"], py["flat_dirty"]
+        if self._exp is not None and py["exp_stale_rows"] is not None:
+            self._exp.stale_rows = set(py["exp_stale_rows"])
+        if self._zero is not None:
+            self._zero["stale_moments"] = py["stale_moments"]
+        self.gaussians.invalidate_activations()
+
+    def _txn_commit(self):
+        """The capacity check that closes a transaction.  Returns the cameras whose forward was truncated at the FIRST look
+        ([] in the regular case).  If there are any -- on any rank -- the state is put back to where the transaction began and its
+        launches are issued again at the corrected capacity, until a check comes back clean: the optimisation ends bit for bit
+        where a run with ample capacity ends (tests/test_gpu_round5.py)."""
+        self._since_check = 0
+        first = None
+        for attempt in range(6):
+            overflowed = self._read_overflows()
+            if first is None:
+                first = overflowed
+            again = bool(overflowed)
+            if self.world > 1 and self.comm is not None:       # the ranks replay together (their collectives are part of the journal)
+                import torch.distributed as dist
+                flag = torch.tensor([1.0 if again else 0.0], dtype=torch.float32, device=self.device)
+                self.comm.all_reduce(flag, op=dist.ReduceOp.MAX)
+                again = bool(flag.item() > 0)
+            if not again or self._txn is None or not self._txn.journal:
+                break
+            if attempt == 5:
+                raise RuntimeError("FusedMappingLoop: the pair capacity still overflows after five corrections")
+            self.replayed_transactions += 1
+            self._txn_restore()
+            self._replaying = True
+            try:
+                for fn in self._txn.journal:
+                    fn()
+            finally:
+                self._replaying = False
+        self._txn = None
+        return first or []
+
+    def check_overflow(self, wait=True):
+        """Did any camera's forward exceed the pair capacity since the last check?  One synchronisation; the answer covers
+        everything enqueued so far, and whatever was affected has been re-run (see _txn_commit) when this returns."""
+        return self._txn_commit()
 
     def _periodic_check(self, steady=False):
-        """steady: called from map() (a converged window: pair counts drift slowly, a check that reports one interval late is
-        fine); initialize_map / final_refine / single iterations keep the synchronous check."""
-        self.check_overflow(wait=not (steady and self.async_checks))
+        self._txn_commit()
 
     def _tick(self):
         self._since_check += 1
         if self._since_check >= self.check_every:
-            self._periodic_check()
+            self._txn_commit()
 
     # ------------------------------------------------------------------------------------------------ loops
     def initialize_map(self, cur_frame_idx, viewpoint, iters=None):
@@ -1220,7 +1361,7 @@ class FusedMappingLoop(MappingLoop):
                 nt = vb.n_touched
                 self._since_check += n
                 if self._since_check >= self.check_every:
-                    self._periodic_check()
+                    self._txn_commit()
                 continue
             self.iteration_count += 1
             self._ensure_state()
@@ -1232,6 +1373,7 @@ class FusedMappingLoop(MappingLoop):
                 # the reference densifies / resets between backward and optimizer.step (mapper.py:339-352): tensors
                 # re-created there have grad None and are skipped by Adam
                 self._step([viewpoint], adam=False, initialization=True)
+                self._txn_commit()            # the surgery below consumes statistics and gradients: verified complete first
                 vb = self._views[viewpoint.uid]
                 nt = vb.n_touched
                 with torch.no_grad():
@@ -1249,6 +1391,7 @@ class FusedMappingLoop(MappingLoop):
                 vb = self._views[viewpoint.uid]
                 nt = vb.n_touched
             self._tick()
+        self._txn_commit()
         # like the reference, visibility comes from the LAST iteration's render (mapper.py:355)
         self.occ_aware_visibility[cur_frame_idx] = (nt > 0).long()
         return {"render": vb.color, "depth": vb.depth, "opacity": vb.opacity, "radii": vb.radii, "n_touched": nt}
@@ -1295,12 +1438,12 @@ class FusedMappingLoop(MappingLoop):
                 self.last_used = list(viewpoint_stack) + [random_viewpoint_stack[k] for k in picks[len(picks) - per:]]
                 gaussian_split = False               # (regular iterations: mapper.py:491 resets the flag every iteration)
                 it += n - 1
+                self._since_check += n
+                if it == iters - 1 or self._since_check >= self.check_every:
+                    self._txn_commit()               # (before anybody looks at what these iterations left behind)
                 if it == iters - 1:
                     self.occ_aware_visibility = self._window_visibility(current_window, viewpoint_stack)
                     self._sync_moments()
-                self._since_check += n
-                if self._since_check >= self.check_every:
-                    self._periodic_check(steady=True)
                 continue
             self.iteration_count += 1
             gaussian_split = False
@@ -1312,6 +1455,7 @@ class FusedMappingLoop(MappingLoop):
                 # mapper.py:490-520: the whole iteration up to loss.backward(), then `return False` before the statistics,
                 # optimizer.step() and zero_grad(): the gradients stay where they are
                 self._step(used, adam=False, stats=False)
+                self._txn_commit()
                 self._stale_iso += 10.0
                 if self._exp is not None:
                     self._exp.keep_stale([r for r in (self._exp.row_of(c) for c in used) if r is not None])
@@ -1329,6 +1473,7 @@ class FusedMappingLoop(MappingLoop):
             if exp_stale and not (special or pose_opt):
                 self._exposure_step(used)
             if special or pose_opt or it == iters - 1:
+                self._txn_commit()                   # map surgery / pose steps / the caller consume this iteration's results
                 with torch.no_grad():
                     if it == iters - 1 or update_gaussian:
                         # the reference rebuilds this dict every iteration (mapper.py:494-498); only the value that
@@ -1433,7 +1578,9 @@ class FusedMappingLoop(MappingLoop):
         if views_per_step == 1:
             self._replicated += 1
             try:
-                return self._final_refine(iters)
+                self._final_refine(iters)
+                self._txn_commit()
+                return
             finally:
                 self._replicated -= 1
         split, self.split_views = self.split_views, True       # (a rank renders ITS picks of the step whatever map() does)
@@ -1448,9 +1595,11 @@ class FusedMappingLoop(MappingLoop):
         self._replicated += 1
         try:
             done = self._final_refine_stale(iters)
+            self._txn_commit()                  # (a transaction never spans a change of the execution mode: its launches are re-issued as recorded)
         finally:
             self._replicated -= 1
         self._final_refine_multi(iters - done, views_per_step)
+        self._txn_commit()
         self._sync_moments()
 
     def _final_refine_stale(self, iters):
@@ -1505,7 +1654,7 @@ class FusedMappingLoop(MappingLoop):
             self.last_used = [stack[picks[-1]]]
             self._since_check += n
             if self._since_check >= self.check_every:
-                self._periodic_check()
+                self._txn_commit()
             done += n
         for _ in range(iters - done):
             self.iteration_count += 1
