@@ -674,7 +674,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const uint2 rng = ranges[(size_t)tile * kRngStride];
   const int64_t begin = rng.x & ~kOverfull;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
-  const int count = endc > begin ? (int)(endc - begin) : 0;
+  // A view whose pairs did not fit the workspace (header.overflow, set by K2) is not composited at all: its lists are incomplete --
+  // keys that K1 could not append to the overflow list were never filed, so a run may hold whatever the block held before, and a
+  // stale "Gaussian index" must not be dereferenced.  The view renders as background; every caller discards it (the gather passes
+  // mask it out, the loops re-run it at a larger capacity).  One scalar load per wave.
+  const uint32_t view_overflow = ((const SavedHeader*)(saved + L.o_hdr))->overflow;
+  const int count = (endc > begin && view_overflow == 0u) ? (int)(endc - begin) : 0;
   const bool overfull = (rng.x & kOverfull) != 0;
   const uint64_t* __restrict__ keys_in = overfull ? entries + begin : bucket;
 
@@ -994,7 +999,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_BWD
   const int64_t begin = rng.x & ~kOverfull;
   const int64_t endc = (int64_t)rng.y < cap ? (int64_t)rng.y : cap;
   const int count = endc > begin ? (int)(endc - begin) : 0;
-  if (count == 0) return;
+  if (count == 0 || ((const SavedHeader*)(saved + L.o_hdr))->overflow != 0u) return;      // (a truncated view: see blend_fwd_kernel)
   const int eff = min(count, (int)tile_maxc[tile]);
 
   // pairs the forward never reached (behind every pixel's last contributor) still own a slot: define it as zero

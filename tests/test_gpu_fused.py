@@ -580,9 +580,10 @@ def test_views_that_overflow_the_pair_capacity_are_rerun_not_dropped():
     f._views_dirty()
     before = {n: getattr(gm, n).detach().clone() for n in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")}
     ev, rp = f.overflow_events, f.replayed_transactions
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")              # (the round-4 loop dropped the views and warned)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
         f.map(f.current_window, iters=3)
+    assert not [w for w in caught if "capacity" in str(w.message)]      # (the round-4 loop dropped the views and warned)
     torch.cuda.synchronize()
     assert f.overflow_events > ev and f.replayed_transactions > rp and f._cap >= 1.5 * real
     lr = {g["name"]: g["lr"] for g in gm.optimizer.param_groups}
