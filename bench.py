@@ -310,10 +310,13 @@ class Bench:
         return roof, roof_f
 
     # ------------------------------------------------------------------------------------------------ legs
-    def dropin_leg(self, steps=6):
+    def dropin_leg(self, steps=6, share_activations=True):
         """The same map() iteration through the drop-in autograd API: splat_slam_amd.mapper.MappingLoop keeps the reference's
-        loop structure (render() per view -> GaussianRasterizer, loss, backward, torch.optim.Adam)."""
+        loop structure (render() per view -> GaussianRasterizer, loss, backward, torch.optim.Adam).
+        share_activations=False: the scene model computes its activations anew on every getter call, like the reference's own
+        GaussianModel (scene/gaussian_model.py:76-101) -- every render hands the rasterizer different tensor objects."""
         loop, cams = self.build("autograd", self.args.scale_add)
+        loop.gaussians.share_activations = bool(share_activations)
         self.run_steps(loop, 6)
         # host-bound: one-off stalls of the first iterations (lazy kernel loads, allocator growth: tens of ms once) would swamp a
         # 6-iteration average -- the better of two timed blocks is the steady state
@@ -578,8 +581,16 @@ def main():
                 out["dropin_keyframes_per_s"] = drop.pop("dropin_keyframes_per_s")
                 out["dropin"] = drop
                 del dloop, dcams
+                torch.cuda.empty_cache()
+                # the same iteration under the reference's OWN scene model (activations recomputed per getter call): the renders of
+                # an iteration join one batch by autograd provenance (dgr_native.cpp Batch::matches) instead of twelve batches of one
+                ref, dloop, dcams = B.dropin_leg(share_activations=False)
+                drop["reference_getters_ms_per_iteration"] = ref["ms_per_iteration"]
+                drop["reference_getters_ms_per_iteration_blocks"] = ref["ms_per_iteration_blocks"]
+                drop["reference_getters_keyframes_per_s"] = ref["dropin_keyframes_per_s"]
+                del dloop, dcams
             except Exception as e:      # noqa: BLE001
-                out["dropin"] = {"error": repr(e)}
+                out.setdefault("dropin", {})["error"] = repr(e)
             trace("dropin done")
             torch.cuda.empty_cache()
             out["extra"] = {}

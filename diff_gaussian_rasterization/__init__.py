@@ -95,6 +95,16 @@ _OVERFLOW_MSG = ("a rasterizer forward exceeded the (tile, Gaussian) pair capaci
                  "(SPLAT_RASTER_SYNC=1 sizes every forward synchronously and never drops pairs)")
 
 
+class CapacityOverflow(RuntimeError):
+    """A forward dropped (tile, Gaussian) pairs and nothing could repair it: no gradient was produced, the capacity has been raised."""
+
+
+def is_capacity_overflow(exc):
+    """True for the error both node implementations raise when a truncated forward cannot be repaired (the C++ half raises it as a
+    plain RuntimeError with the same text).  Callers that retry an iteration ask THIS, not the message."""
+    return isinstance(exc, CapacityOverflow) or (isinstance(exc, RuntimeError) and str(exc).startswith(_OVERFLOW_MSG[:60]))
+
+
 class _Lease:
     """Returns a saved block to its pool when the autograd node that holds it dies."""
     __slots__ = ("pool", "block")
@@ -196,7 +206,7 @@ class _DeviceState:
             self.drain(wait)
         if self.unreported:
             self.unreported = 0
-            raise RuntimeError(_OVERFLOW_MSG)
+            raise CapacityOverflow(_OVERFLOW_MSG)
 
     def post(self, saved_ptr, cap, stream):
         if len(self.pending) >= _RING - 1:
@@ -213,7 +223,19 @@ _states = {}
 
 # ---- the C++ half ----------------------------------------------------------------------------------------------------------------
 NATIVE = os.environ.get("SPLAT_RASTER_NATIVE", "1") != "0"
+# Renders whose parameter tensors are NEW objects with the same autograd provenance (the unmodified reference getters build their
+# activations per call: scene/gaussian_model.py:76-101) join the batch of the iteration (C++ nodes; Batch::matches in dgr_native.cpp).
+# 0: tensor identity only, i.e. one backward pass per render under those getters.
+PROVENANCE = os.environ.get("SPLAT_RASTER_PROVENANCE", "1") != "0"
 _ext, _ext_tried = None, False
+
+
+def set_provenance_batching(on):
+    """Run-time switch of PROVENANCE (tests / A-B measurements)."""
+    global PROVENANCE
+    PROVENANCE = bool(on)
+    if _ext is not None:
+        _ext.set_provenance(PROVENANCE)
 
 
 def native_extension():
@@ -235,6 +257,7 @@ def native_extension():
             if mod.abi_version() != nat.lib().sgr_abi_version():
                 raise ImportError("diff_gaussian_rasterization/_dgr.so was built against another libsplat_hip.so ABI: rebuild")
             _ext = mod
+            mod.set_provenance(PROVENANCE)
         else:
             import warnings
             warnings.warn("diff_gaussian_rasterization/_dgr.so is not built (python -m splat_slam_amd.build): the rasterizer's autograd "

@@ -18,6 +18,7 @@
 #include <torch/extension.h>
 #include <torch/csrc/autograd/function.h>
 #include <torch/csrc/autograd/variable.h>
+#include <torch/csrc/autograd/functions/accumulate_grad.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/core/DeviceGuard.h>
 
@@ -101,7 +102,7 @@ struct PendingHeader {
   int64_t cap;                          // capacity the forward ran with
   std::weak_ptr<ViewRecord> rec;        // the forward's record, if a backward may follow (it can be re-run when it was truncated)
 };
-static void mark_truncated(const std::weak_ptr<ViewRecord>& rec, int64_t need);
+static bool mark_truncated(const std::weak_ptr<ViewRecord>& rec, int64_t need);
 
 struct DeviceState {
   std::mutex mu;
@@ -121,6 +122,7 @@ struct DeviceState {
   int64_t reruns = 0;                                // truncated forwards re-run inside a backward pass
   int next_slot = 0;
   int64_t overflowed = 0, unreported = 0;
+  int64_t lost = 0;                                  // truncated forwards nobody can re-run (no graph / outputs dropped): warned about at the next call
   std::shared_ptr<Batch> batch;                      // the batch forwards currently join
   int64_t forwards = 0, batches = 0, backwards = 0;  // counters for tests / profiling
 
@@ -196,7 +198,9 @@ struct DeviceState {
       if (kCapFactor * R > capacity) capacity = kCapFactor * R;
       if (R > cap) {
         ++bad;
-        mark_truncated(pending.front().rec, R);
+        // a forward whose record is gone (rendered without a graph, or its outputs were dropped before a backward): nothing will
+        // re-run it -- its image was consumed as it was and the caller is told at the very next call (try_rasterize)
+        if (!mark_truncated(pending.front().rec, R)) ++lost;
       }
       pending.pop_front();
     }
@@ -254,9 +258,16 @@ struct ViewRecord {
   bool m2d_deferred = false;       // means2D is a hook-free leaf and deferral is on: the node writes `.grad` itself
   int64_t truncated_need = 0;      // > 0: the forward exceeded its capacity (pairs it needed): re-run before its backward
 };
-static void mark_truncated(const std::weak_ptr<ViewRecord>& rec, int64_t need) {
-  if (auto r = rec.lock()) r->truncated_need = need;
+static bool mark_truncated(const std::weak_ptr<ViewRecord>& rec, int64_t need) {       // false: nobody is left to re-run it
+  if (auto r = rec.lock()) {
+    r->truncated_need = need;
+    return true;
+  }
+  return false;
 }
+
+static bool g_provenance = true;      // renders whose inputs are new tensors of the same provenance join the open batch (SPLAT_RASTER_PROVENANCE=0: identity only)
+static void set_provenance(bool on) { g_provenance = on; }
 
 // The forwards that share one set of input tensors (the renders of a mapping iteration).  `inputs` holds the caller's tensors
 // (identity decides membership), `alias` the collector's outputs the forwards consume.  A record belongs to its forward's autograd
@@ -274,10 +285,65 @@ struct Batch {
   Tensor m2d_arena;                // [views, N, 3] zeros: ONE memset for the means2D gradients of all views of the backward pass
   int64_t m2d_used = 0, m2d_slots = 0;
 
-  bool matches(const Tensor* t) const {
+  // Which leaves the batch's inputs were computed from, and at which version (recorded when the batch is made): a later render
+  // whose tensors are NEW objects computed the same way from the same leaves at the same versions holds the same values.
+  std::vector<std::pair<const torch::autograd::Node*, uint32_t>> leaf_versions;
+
+  // The reference's scene model builds its activations anew on every getter call (exp / sigmoid / normalize / cat:
+  // /root/reference/thirdparty/gaussian_splatting/scene/gaussian_model.py:76-101) and render() calls the getters per view
+  // (gaussian_renderer/__init__.py:89-111): twelve renders of one iteration hand in twelve sets of DIFFERENT tensors with IDENTICAL
+  // values.  By identity they were batches of one (twelve backward passes).  They join one batch when every tensor is the batch's own
+  // or has the same autograd provenance: the same chain of (pure, deterministic, whitelisted) operations over the same leaves at the
+  // same versions.  The later views' own activation tensors then simply get no gradient: all of it flows through the FIRST view's
+  // chain, summed over the views -- exact, because the views' chains apply the same linear map to their gradients
+  // (sum_k J g_k = J sum_k g_k, up to fp32 summation order).
+  static bool pure_op(const std::string& n) {
+    static const char* ok[] = {"ExpBackward0", "SigmoidBackward0", "CatBackward0", "RepeatBackward0", "DivBackward0", "ExpandBackward0",
+                               "ClampMinBackward0", "LinalgVectorNormBackward0", "NormBackward1", "TransposeBackward0", "ViewBackward0",
+                               "UnsafeViewBackward0", "ReshapeAliasBackward0", "CloneBackward0", "AliasBackward0", "PermuteBackward0",
+                               "UnsqueezeBackward0", "SqueezeBackward1"};
+    for (auto* k : ok)
+      if (n == k) return true;
+    return false;
+  }
+  void record_leaves(const torch::autograd::Node* fn, int depth) {
+    if (!fn || depth > 8) return;
+    if (auto* acc = dynamic_cast<const torch::autograd::AccumulateGrad*>(fn)) {
+      leaf_versions.emplace_back(fn, acc->variable._version());
+      return;
+    }
+    for (const auto& e : fn->next_edges()) record_leaves(e.function.get(), depth + 1);
+  }
+  bool same_provenance(const torch::autograd::Node* a, const torch::autograd::Node* b, int depth) const {
+    if (!a || !b || depth > 8) return false;
+    if (a == b) {                                   // the same leaf (or a shared intermediate result)
+      if (auto* acc = dynamic_cast<const torch::autograd::AccumulateGrad*>(a)) {
+        for (const auto& lv : leaf_versions)
+          if (lv.first == a) return acc->variable._version() == lv.second;
+        return false;
+      }
+      return true;
+    }
+    if (a->name() != b->name() || !pure_op(a->name()) || a->num_outputs() != b->num_outputs()) return false;
+    for (uint32_t j = 0; j < a->num_outputs(); ++j) {
+      const auto& ea = a->next_edge(j);
+      const auto& eb = b->next_edge(j);
+      // (an operand without a graph -- a plain tensor -- could differ in value between the two renders: not accepted)
+      if (!ea.is_valid() || !eb.is_valid() || ea.input_nr != eb.input_nr) return false;
+      if (!same_provenance(ea.function.get(), eb.function.get(), depth + 1)) return false;
+    }
+    return true;
+  }
+  bool matches(const Tensor* t, bool provenance) const {
     if (closed) return false;
-    for (int i = 0; i < 5; ++i)
-      if (t[i].unsafeGetTensorImpl() != inputs[i].unsafeGetTensorImpl() || t[i]._version() != versions[i]) return false;
+    for (int i = 0; i < 5; ++i) {
+      if (t[i].unsafeGetTensorImpl() == inputs[i].unsafeGetTensorImpl() && t[i]._version() == versions[i]) continue;
+      if (!provenance || inputs[i]._version() != versions[i]) return false;
+      const auto& fa = t[i].grad_fn();
+      const auto& fb = inputs[i].grad_fn();
+      if (!fa || !fb || t[i].output_nr() != inputs[i].output_nr() || t[i].sizes() != inputs[i].sizes() || !t[i].is_contiguous()) return false;
+      if (!same_provenance(fa.get(), fb.get(), 0)) return false;
+    }
     return true;
   }
   // zero-filled [N,3] for one view's dL/dmeans2D: slices of one arena per backward pass (a memset per view was 12 launches)
@@ -584,6 +650,15 @@ static py::object try_rasterize(const Tensor& means3D, const c10::optional<Tenso
   DeviceState& st = state(dev);
   std::lock_guard<std::mutex> lk(st.mu);
   st.drain(false);         // (headers that have landed; the forwards of an iteration are all waited for inside their backward)
+  if (st.lost) {
+    // (the Python nodes raise here -- _forward / report(); a forward-only evaluation loop has no backward in which the C++ nodes
+    //  could re-run the render, so it is told NOW, not in some later backward pass or never: ADVICE r4)
+    TORCH_WARN("diff_gaussian_rasterization: ", st.lost, " earlier render(s) without a backward pass exceeded the (tile, Gaussian) pair "
+               "capacity (now ", st.capacity, "): the images they returned were not composited (background only).  Render them again; "
+               "SPLAT_RASTER_SYNC=1 sizes every forward synchronously");
+    st.unreported = std::max<int64_t>(0, st.unreported - st.lost);
+    st.lost = 0;
+  }
 
   Tensor bg, view, proj, praw, campos;
   {
@@ -596,7 +671,7 @@ static py::object try_rasterize(const Tensor& means3D, const c10::optional<Tenso
   std::shared_ptr<Batch> b;
   if (want_grad) {
     b = st.batch;
-    if (!b || !b->matches(in5)) {
+    if (!b || !b->matches(in5, g_provenance)) {
       b = std::make_shared<Batch>();
       b->dev = dev;
       b->N = N;
@@ -607,6 +682,7 @@ static py::object try_rasterize(const Tensor& means3D, const c10::optional<Tenso
       for (int i = 0; i < 5; ++i) {
         b->inputs[i] = in5[i];
         b->versions[i] = in5[i]._version();
+        if (in5[i].grad_fn()) b->record_leaves(in5[i].grad_fn().get(), 0);
         at::AutoDispatchBelowADInplaceOrView below;
         b->alias[i] = in5[i].detach();
       }
@@ -635,6 +711,8 @@ static py::object try_rasterize(const Tensor& means3D, const c10::optional<Tenso
   // A new map: learn its pair count before trusting the capacity.  Close to the limit (the last measured count is beyond half the
   // capacity -- never the case once a map's count has been seen, capacity = 4 x the largest): wait as well, like upstream does
   // for every forward, instead of risking a truncated image.  Otherwise asynchronous.
+  // (A render that can have no backward pass -- grad mode off, evaluation -- runs asynchronously too: capacity is 4 x the largest
+  //  count this map has shown, and should it be exceeded anyway the caller is warned at the next call, above.)
   const bool wait = sync || this_map != st.last_map || 2 * st.last_pairs > st.capacity;
   ForwardRun fr = run_forward(st, s, inp, out, wait, stream);
   if (wait) st.last_map = this_map;
@@ -691,6 +769,23 @@ static py::object saved_block_of(const Tensor& output) {
   auto* vn = dynamic_cast<ViewNode*>(fn.get());
   if (!vn || !vn->rec) return py::none();
   return py::make_tuple(vn->rec->lease->block, vn->rec->cap);
+}
+
+// would a render that hands in `t` join a batch that was opened with `ref` in the same argument slot?  provenance_open(ref) plays
+// the first render of an iteration (the leaves' versions are recorded THEN), provenance_joins(t) a later one.  CPU-testable: no kernel.
+static std::unique_ptr<Batch> g_probe;
+static void provenance_open(const Tensor& ref) {
+  g_probe = std::make_unique<Batch>();
+  for (int i = 0; i < 5; ++i) {
+    g_probe->inputs[i] = ref;
+    g_probe->versions[i] = ref._version();
+  }
+  if (ref.grad_fn()) g_probe->record_leaves(ref.grad_fn().get(), 0);
+}
+static bool provenance_joins(const Tensor& t) {
+  TORCH_CHECK(g_probe, "provenance_open first");
+  const Tensor in5[5] = {t, t, t, t, t};
+  return g_probe->matches(in5, true);
 }
 
 static void check_overflow() {
@@ -892,6 +987,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("sh_degree"), py::arg("campos"), py::arg("prefiltered"), py::arg("debug"), py::arg("sync"), py::arg("defer_pose"));
   m.def("saved_block_of", &dgr::saved_block_of);
   m.def("check_overflow", &dgr::check_overflow);
+  m.def("set_provenance", &dgr::set_provenance);
+  m.def("provenance_open", &dgr::provenance_open);
+  m.def("provenance_joins", &dgr::provenance_joins);
   m.def("stats", &dgr::stats);
   m.def("set_capacity", &dgr::set_capacity, py::arg("device"), py::arg("capacity"), py::arg("forget_map") = false, py::arg("floor_override") = -1,
         py::arg("last_pairs") = -1);

@@ -77,12 +77,12 @@ def build_dropin_ext(force=False, verbose=True):
         return DROPIN_LIB
     build_native(verbose=verbose)
     import sysconfig
-    import pybind11
     import torch
     from torch.utils import cpp_extension as ce
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     cxx = os.environ.get("CXX", "g++")
-    inc = ce.include_paths() + [pybind11.get_include(), sysconfig.get_paths()["include"], os.path.join(rocm, "include")]
+    # (torch ships the pybind11 headers it was built with under its own include path: no separate pybind11 package needed)
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], os.path.join(rocm, "include")]
     tlib = ce.library_paths()[0]
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-sign-compare",
            "-DTORCH_EXTENSION_NAME=_dgr", "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",

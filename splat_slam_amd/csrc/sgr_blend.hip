@@ -599,7 +599,8 @@ __device__ __forceinline__ bool tile_of_block(int b, const LOff& L, int& tx, int
   const int sgx = L.sgx, nsuper = L.sgx * L.sgy, per = (nsuper + 7) >> 3;
   const int j = b >> 3, st = (b & 7) * per + (j >> 2), wv = j & 3;
   if (st >= nsuper || j >= 4 * per) return false;
-  const int row = (int)__builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)st, L.sgx_magic));      // st / sgx  (st * sgx < 2^32)
+  // st / sgx  (st * sgx < 2^32; an image of one super-tile column -- W <= 16 -- has no 32-bit reciprocal: 2^32 / 1 + 1 wraps to 1)
+  const int row = sgx == 1 ? st : (int)__builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)st, L.sgx_magic));
   const int col = st - row * sgx;
   tx = __builtin_amdgcn_readfirstlane(col * 2 + (wv & 1));
   ty = __builtin_amdgcn_readfirstlane(row * 2 + (wv >> 1));

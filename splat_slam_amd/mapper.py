@@ -105,19 +105,25 @@ class MappingLoop:
         """loss = make_loss(); loss.backward() -- once more from scratch if the rasterizer reports that a forward of this iteration
         exceeded its pair capacity.  (Only the Python-node path of the drop-in package raises: inputs outside the reference's call
         shape.  It has produced no gradient for the batch that raised and has already grown the capacity; batches of one that ran
-        before it may have accumulated into `.grad`, so the gradients are cleared before the second attempt -- ADVICE r3.  The C++
-        nodes re-run a truncated forward inside backward() themselves.)"""
+        before it may have accumulated into `.grad`.  The second attempt must start from the gradients the iteration STARTED with --
+        a prune pass deliberately leaves its gradients behind for the next step, mapper.py:490-520 -- so those are kept aside first
+        and put back, and only what the failed attempt produced is dropped: ADVICE r3 / r4.  The C++ nodes re-run a truncated
+        forward inside backward() themselves.)"""
+        import diff_gaussian_rasterization as drg
+        params = [p for g in self.gaussians.optimizer.param_groups for p in g["params"]]
+        if self.keyframe_optimizers is not None:
+            params += [p for g in self.keyframe_optimizers.param_groups for p in g["params"]]
+        before = {id(p): p.grad.detach().clone() for p in params if p.grad is not None}     # (empty in a regular iteration: free)
         for attempt in (0, 1):
             out = make_loss()
             try:
                 out[0].backward()
                 return out
             except RuntimeError as e:
-                if attempt or "pair capacity" not in str(e):
+                if attempt or not drg.is_capacity_overflow(e):
                     raise
-                self.gaussians.optimizer.zero_grad(set_to_none=True)
-                if self.keyframe_optimizers is not None:
-                    self.keyframe_optimizers.zero_grad(set_to_none=True)
+                for p in params:
+                    p.grad = before.get(id(p))
 
     def _visible_stats(self, viewspace_points, vis, radii):
         """max_radii2D[vis] = max(max_radii2D[vis], radii[vis]) and add_densification_stats (mapper.py:332-335,523-529,

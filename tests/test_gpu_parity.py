@@ -21,6 +21,8 @@ CASES = [
     ("one", 1, 16, 16, dict(fx=20.0, fy=20.0, cx=8.0, cy=8.0, spread=0.2)),
     ("two", 2, 16, 16, dict(fx=20.0, fy=20.0, cx=8.0, cy=8.0, spread=0.3)),
     ("ragged", 60, 50, 37, dict(fx=44.0, fy=41.0, cx=24.1, cy=19.3)),          # H, W not multiples of 8/16
+    ("narrow", 60, 16, 64, dict(fx=18.0, fy=40.0, cx=7.6, cy=31.2)),           # ONE 16-pixel super-tile column (the tile
+                                                                                #  mapping's reciprocal of sgx wrapped for sgx = 1)
     ("dense", 1000, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, scale_range=(0.01, 0.12))),
     ("bg", 200, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, bg=torch.tensor([0.3, 0.6, 0.1]).double())),
     ("wide", 300, 96, 64, dict(fx=40.0, fy=40.0, cx=47.5, cy=31.5, spread=2.0, scale_range=(0.02, 0.6))),
