@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--settle", type=int, default=150, help="untimed iterations right after the scene is built, BEFORE the --warmup steps: "
                     "workspace capacities, list hints, allocator pools and the GPU's clocks reach the state a session is in from its "
                     "second keyframe on (a 20-step timed region that starts 5 steps after an idle GPU reads 8 %% slower)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 --pmc child passes that measure `roofline.traffic` "
+                    "(HBM bytes of the dominant kernel, FETCH_SIZE / WRITE_SIZE)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing protocol only, no GPU work (CPU test of --gpus N)")
     return ap.parse_args()
 
@@ -123,6 +125,52 @@ def dry_run(args):
                           "scaling": args.scaling if world > 1 else "none", "scaling_when_sharded": args.scaling}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_traffic(extra_args, kernels, timeout=240):
+    """HBM bytes per launch of `kernels`, measured NOW: two short rocprofv3 child passes of this same script (counters in their own
+    runs, --pmc + --kernel-trace only, from /tmp: MI355X_MICROARCH.md), FETCH_SIZE and WRITE_SIZE averaged over the batched
+    (largest-grid) launches, bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts a 128-byte request as 64 in FETCH_SIZE; both
+    counters are in KiB).  Returns ({kernel: bytes}, how) -- ({}, reason) when rocprofv3 is not on this box or a pass fails."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {}, "rocprofv3 not found on this box"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--settle", "20", "--no-cpu-baseline", "--no-extras",
+             "--refine-iters", "0", "--no-pmc"] + list(extra_args)
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
+            agg = collections.defaultdict(list)
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter:
+                    agg[row["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+            for k, v in agg.items():
+                g = max(x[0] for x in v)
+                sel = [x[1] for x in v if x[0] == g]
+                vals.setdefault(k, {})[counter] = sum(sel) / len(sel)
+        except Exception as e:      # noqa: BLE001
+            return {}, "rocprofv3 --pmc %s pass: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for want in kernels:
+        for k, c in vals.items():
+            if k.endswith(want) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                out[want] = int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    return out, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of `bench.py %s` (batched launches; "
+                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, MI355X_MICROARCH.md)" % " ".join(child[2:]))
 
 
 class Bench:
@@ -282,11 +330,13 @@ class Bench:
                 return None
         traffic = committed_traffic("sgr::blend_bwd_kernel<true>", bwd_ms)
         a = gbs(bytes_bwd, bwd_ms)
+        # `traffic` is filled in by main() from rocprofv3 --pmc child passes of THIS run (measure_traffic); the committed profile's
+        # figure is kept beside it under its own name
         roof = {"kernel": "blend_bwd_kernel<true>", "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic, "in_timed_region": False,
-                "traffic_source": "profiles/latest_pmc_hbm_bytes.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                  "(scripts/collect_profiles.py), not measured by this run; null unless that pass ran this workload "
-                                  "and its kernel duration agrees with this run's within 10 %",
+                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": None, "traffic_from_committed_profile": traffic, "in_timed_region": False,
+                "traffic_source": "not measured (see main(): --no-pmc, or rocprofv3 missing); traffic_from_committed_profile = "
+                                  "profiles/latest_pmc_hbm_bytes.json (scripts/collect_profiles.py on the builder's box), null unless "
+                                  "that pass ran this workload and its kernel duration agrees with this run's within 10 %",
                 "avg_launch_ms": round(bwd_ms, 5), "launches": bwd_n,
                 "views_per_launch": nv, "algorithmic_bytes": bytes_bwd, "own_formula_bytes": own_bytes,
                 "pixel_splat_pairs_per_launch": pair_evals,
@@ -298,8 +348,8 @@ class Bench:
         af = gbs(bytes_fused, fus_ms)
         roof_f = {"kernel": "blend_fwd_kernel<*, FUSED=true> (forward + loss + backward of a tile in one wave)", "bound": "hbm",
                   "achieved": round(af, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(af / HBM_PEAK_GBS, 5),
-                  "traffic": committed_traffic("sgr::blend_fwd_kernel<512, true>", fus_ms), "in_timed_region": True,
-                  "traffic_source": roof["traffic_source"],
+                  "traffic": None, "traffic_from_committed_profile": committed_traffic("sgr::blend_fwd_kernel<512, true>", fus_ms),
+                  "in_timed_region": True, "traffic_source": roof["traffic_source"],
                   "avg_launch_ms": round(fus_ms, 5), "launches": fus_n, "views_per_launch": nv, "algorithmic_bytes": bytes_fused,
                   "algorithmic_bytes_formula": "SURVEY 8d: blend-bwd 84 R_eff + 24 HW + 40 N  +  blend-fwd 48 R_eff + 28 HW, per view",
                   "pixel_splat_pairs_per_launch": pair_evals,
@@ -358,7 +408,7 @@ class Bench:
                 "tile_pairs_walked_R_eff": sum(p[2] for p in per_view) // nv, "tiles_by_walked_list_length_last_view": hist,
                 "blend_bwd_frac": roof["frac"], "blend_bwd_avg_launch_ms": roof["avg_launch_ms"],
                 "blend_fwd_avg_launch_ms": roof["blend_fwd_avg_launch_ms"], "fused_tile_kernel_avg_launch_ms": roof_f["avg_launch_ms"],
-                "fused_tile_kernel_frac": roof_f["frac"]}
+                "fused_tile_kernel_frac": roof_f["frac"], "_roofline_fused": roof_f}
 
 
     def session_leg(self, frames_n=40, refine_iters=200, step_of=160, warm_frames=12):
@@ -534,6 +584,16 @@ def main():
         # `roofline_unfused_blend_bwd` = the north-star's kernel as a stand-alone launch (SGR_OPT_FUSED_BLEND = 0 leg of this run);
         # `roofline_fused` stays as an alias of `roofline` so that earlier rounds' readers find it
         out["roofline"], out["roofline_unfused_blend_bwd"], out["roofline_fused"] = roof_f, roof_bwd, roof_f
+        if not args.no_pmc:
+            pass_args = ["--gaussians", str(N), "--camera", args.camera, "--views", str(args.views), "--scale-add", str(args.scale_add),
+                         "--order", args.order]
+            tr, how = measure_traffic(pass_args, ["blend_fwd_kernel<512, true>", "blend_bwd_kernel<true>"])
+            for roof, k in ((roof_f, "blend_fwd_kernel<512, true>"), (roof_bwd, "blend_bwd_kernel<true>")):
+                if k in tr:
+                    roof["traffic"], roof["traffic_source"] = tr[k], how
+                    roof["traffic_over_algorithmic"] = round(tr[k] / roof["algorithmic_bytes"], 4)
+                else:
+                    roof["traffic_source"] = "not measured: %s; " % how + roof["traffic_source"]
         trace("rooflines done")
         # ---- single-render timings through the drop-in autograd API + the loop's own forward-only render
         from splat_slam_amd.mapper import PipelineParams
@@ -604,6 +664,21 @@ def main():
                 trace(name + " done")
 
     ex = out.get("extra") or {}
+    for leg in ex.values():
+        if isinstance(leg, dict) and "_roofline_fused" in leg and leg is not ex.get("opaque_scene"):
+            leg.pop("_roofline_fused")
+    if isinstance(ex.get("opaque_scene"), dict) and "_roofline_fused" in ex["opaque_scene"]:
+        # the converged-map fraction as a contract key of its own: the SAME kernel and formula as `roofline`, on the same N with
+        # surface-covering splats (lists of 33-256 per tile: what a SLAM map is after a few hundred keyframes)
+        ro = dict(ex["opaque_scene"].pop("_roofline_fused"))
+        ro["workload"] = "same N, every log-scale + 1.6 (extra.opaque_scene): %d walked (tile, Gaussian) pairs per view" % ex["opaque_scene"]["tile_pairs_walked_R_eff"]
+        if not args.no_pmc:
+            tr, how = measure_traffic(["--gaussians", str(N), "--camera", args.camera, "--views", str(args.views), "--scale-add",
+                                       str(args.scale_add + 1.6), "--order", args.order], ["blend_fwd_kernel<512, true>"])
+            if tr:
+                ro["traffic"], ro["traffic_source"] = tr["blend_fwd_kernel<512, true>"], how
+                ro["traffic_over_algorithmic"] = round(ro["traffic"] / ro["algorithmic_bytes"], 4)
+        out["roofline_opaque"] = ro
     if ex:        # the headline scene is a FRESH map (mean list 11); what a converged map costs belongs next to the number
         out["value_context"] = {
             "headline_scene": "fresh map: ~18 k of 300 k Gaussians visible, ~54 k (tile, Gaussian) pairs per view, lists <= 32",

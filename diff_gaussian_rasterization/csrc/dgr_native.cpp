@@ -653,11 +653,14 @@ static py::object try_rasterize(const Tensor& means3D, const c10::optional<Tenso
   if (st.lost) {
     // (the Python nodes raise here -- _forward / report(); a forward-only evaluation loop has no backward in which the C++ nodes
     //  could re-run the render, so it is told NOW, not in some later backward pass or never: ADVICE r4)
-    TORCH_WARN("diff_gaussian_rasterization: ", st.lost, " earlier render(s) without a backward pass exceeded the (tile, Gaussian) pair "
-               "capacity (now ", st.capacity, "): the images they returned were not composited (background only).  Render them again; "
-               "SPLAT_RASTER_SYNC=1 sizes every forward synchronously");
+    const std::string msg = c10::str("diff_gaussian_rasterization: ", st.lost, " earlier render(s) without a backward pass exceeded the (tile, "
+                                     "Gaussian) pair capacity (now ", st.capacity, "): the images they returned were not composited (background "
+                                     "only).  Render them again; SPLAT_RASTER_SYNC=1 sizes every forward synchronously");
     st.unreported = std::max<int64_t>(0, st.unreported - st.lost);
     st.lost = 0;
+    // (a Python warning -- this function is called from Python with the GIL held; TORCH_WARN outside an autograd / dispatcher frame only
+    //  prints to stderr, where `warnings` filters and tests cannot see it)
+    if (PyErr_WarnEx(PyExc_RuntimeWarning, msg.c_str(), 1) < 0) throw py::error_already_set();
   }
 
   Tensor bg, view, proj, praw, campos;

@@ -269,6 +269,13 @@ class FusedMappingLoop(MappingLoop):
         # snapshot, grows the capacity and re-issues the journal (_txn_commit), so a view that overflowed takes part in every step
         # after all, like upstream's rasterizer, which sizes its buffers inside the call (README.md:88-92 module).
         self._txn = None
+        # True: a span whose views run on carried-over pair-count ESTIMATES sends its first iteration ahead and reads its headers back
+        # before the rest is enqueued (round 3: an estimate that was short then cost one iteration, not a span of dropped views).
+        # With transactions nothing is ever dropped -- a short estimate costs a replay of the span, once in tens of keyframes -- and the
+        # extra synchronisation per keyframe (GPU idle ~1 ms behind it, scripts/session_timeline.py) is the more expensive of the two.
+        self.verify_estimates = os.environ.get("SPLAT_VERIFY_ESTIMATES", "0") == "1"
+        self._span_cache = None    # (window, pool) SgrMapView arrays of the spans of one map() call (_span_arrays)
+        self.cache_span_arrays = os.environ.get("SPLAT_SPAN_CACHE", "1") != "0"      # (0: A/B measurements of the host path)
         self._txn_pool = None      # snapshot buffers, reused while the tensor shapes stay
         self._replaying = False
         self.replayed_transactions = 0
@@ -300,6 +307,7 @@ class FusedMappingLoop(MappingLoop):
         self._acc_ids = None        # the five parameter tensors the sinks belong to (held, so that identity checks are sound)
         self._stale_iso = 0.0       # isotropy weight whose gradient a prune pass left on the current `_scaling` tensor
         self.max_pairs = 1 << 28    # a view with more (tile, Gaussian) pairs than this is a degenerate map: fail loudly, not by OOM
+        self.capacity_floor = 1 << 16      # the pair capacity never goes below this (tests: a floor no view can reach = a run without overflow)
 
     def reset(self):
         super().reset()
@@ -310,6 +318,7 @@ class FusedMappingLoop(MappingLoop):
         self._ws_owners.clear()
         self._slots = []
         self._txn = None
+        self._span_cache = None
 
     # ------------------------------------------------------------------------------------------------ state
     def set_parallel(self, world, rank, split_views=True, sync="zero1", comm=None):
@@ -615,7 +624,7 @@ class FusedMappingLoop(MappingLoop):
         nat.check(self.lib.sgr_activate(N, gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
                                         a["act_scale"].data_ptr(), a["act_rot"].data_ptr(), a["act_opac"].data_ptr(),
                                         self._stream()), "sgr_activate")
-        cap, R = max(self._cap, 1 << 16), C.c_int64(0)
+        cap, R = max(self._cap, self.capacity_floor), C.c_int64(0)
         while True:
             ws = self._workspace(vb, N, H, W, cap)
             rc = self.lib.sgr_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(R), self._stream())
@@ -713,18 +722,43 @@ class FusedMappingLoop(MappingLoop):
             vb = self._view(c)
             if vb.pairs < 0:                          # buffers are new (camera, or every camera after the map changed size)
                 self._estimate_pairs(c, vb)
-            need = max(need, 1 << 16, 2 * vb.pairs)
+            need = max(need, self.capacity_floor, 2 * vb.pairs)
         if need > self._cap:
             self._cap = int(need * 1.25)
             self._views_dirty()
 
-    def _views_array(self, cams, initialization, images=True, slot=False):
+    def _views_array(self, cams, initialization, images=True, slot=False, settle=True):
         n = len(cams)
-        self._settle_capacity(cams)
+        if settle:
+            self._settle_capacity(cams)
         if not slot:
             self._ws_protect = {id(self._view(c)) for c in cams}
             self.max_live_ws = max(self.max_live_ws, n + 8)
         return (nat.SgrMapView * n)(*[self._map_view(c, initialization, images, slot) for c in cams])
+
+    def _span_arrays(self, window_cams, pool_cams, initialization):
+        """(window array, pool array) of a span -- SgrMapView structs for sgr_map_run -- built ONCE for the spans that share them: a
+        keyframe's map() call goes out as 2 + 6 + 52 iterations (plus a verified first iteration), all with the same window and the
+        same pool (every other keyframe: hundreds late in a session).  Re-making both arrays and re-settling the capacity per span
+        cost a 20-keyframe session 7 ms of host time per keyframe, most of it with the GPU idle behind the keyframe-selection
+        read-back (scripts/session_timeline.py).  Valid while nothing they point into has changed: map size, capacity / hints
+        generation, the cameras' own versions and buffers."""
+        N = self.gaussians._xyz.shape[0]
+        cams = list(window_cams) + list(pool_cams)
+        ident = (N, bool(initialization), len(window_cams), tuple(id(c) for c in cams), tuple(c._version for c in cams))
+        hit = self._span_cache if self.cache_span_arrays else None
+        if hit is not None and hit[0] == ident and hit[1] == self._gen and all(self._views[c.uid].gen == g for c, g in zip(window_cams, hit[2])):
+            self._ws_protect = hit[5]
+            for i, c in enumerate(window_cams):          # (the array holds COPIES of the cached structs: a block that has been through a
+                if self._views[c.uid].clean:             #  forward since needs no zeroing launch in front of the next span)
+                    hit[3][i].ws.counters_clean = 1
+            return hit[3], hit[4]
+        self._settle_capacity(cams)                                              # estimates for new cameras, ONE capacity
+        win = self._views_array(window_cams, initialization, images=False, settle=False) if window_cams else None
+        protect = self._ws_protect
+        pool = self._views_array(pool_cams, initialization, images=False, slot=True, settle=False) if pool_cams else None
+        self._span_cache = (ident, self._gen, [self._views[c.uid].gen for c in window_cams], win, pool, protect)
+        return win, pool
 
     def _slot_workspaces(self, count, N, H, W):
         """`count` shared workspace slots at the current capacity (SgrMapRun.pick_ws)."""
@@ -818,9 +852,9 @@ class FusedMappingLoop(MappingLoop):
         n_it = len(lrs)
         if self._parallel() or n_it == 0:
             raise RuntimeError("_run_span is the single-GPU fast path")
-        self._settle_capacity(list(window_cams) + list(pool_cams))               # estimates for new cameras, ONE capacity
+        self._span_arrays(window_cams, pool_cams, initialization)                # estimates for new cameras, ONE capacity (cached per map size)
         per0 = len(picks) // n_it if picks else 0
-        if (n_it > 1 and not verified and not self._replaying
+        if (n_it > 1 and not verified and not self._replaying and self.verify_estimates
                 and any(self._views[c.uid].estimated for c in list(window_cams) + [pool_cams[k] for k in picks[:per0]])):
             self._run_span(window_cams, pool_cams, picks[:per0], lrs[:1], iso_weight, exposure, stats, initialization, verified=True)
             # the launch structs of the rest are built while that iteration runs; the read-back then only decides whether they stand
@@ -849,9 +883,7 @@ class FusedMappingLoop(MappingLoop):
         """Everything sgr_map_run needs, as ctypes objects (kept alive by the returned tuple)."""
         n_it = len(lrs)
         pl = self._plan()
-        self._settle_capacity(list(window_cams) + list(pool_cams))               # ONE capacity for the window and the pool
-        win = self._views_array(window_cams, initialization, images=False) if window_cams else None
-        pool = self._views_array(pool_cams, initialization, images=False, slot=True) if pool_cams else None
+        win, pool = self._span_arrays(window_cams, pool_cams, initialization)    # (ONE capacity for the window and the pool)
         st = self._setup(pl, iso_weight, True, (), stats, False, exposure, bump=False)
         per = len(picks) // n_it if picks else 0
         run = nat.SgrMapRun()
@@ -1180,8 +1212,8 @@ class FusedMappingLoop(MappingLoop):
             if ov:
                 self.overflow_events += 1
                 overflowed.append(uid)
-        if worst * 1.5 > self._cap or (worst > 0 and 8 * worst < self._cap and self._cap > (1 << 16)):
-            self._cap = max(1 << 16, int(2.5 * worst))
+        if worst * 1.5 > self._cap or (worst > 0 and 8 * worst < self._cap and self._cap > self.capacity_floor):
+            self._cap = max(self.capacity_floor, int(2.5 * worst))
             self._views_dirty()
         elif overflowed:                               # (cannot happen: an overflowed header carries a count beyond the capacity)
             self._cap = int(1.5 * self._cap)
@@ -1242,9 +1274,7 @@ class FusedMappingLoop(MappingLoop):
         txn.tensors, txn.saved, txn.flat_live, txn.journal = ts, pool, flat_live, []
         steps = [gm.optimizer.state[g["params"][0]]["step"] for g in gm.optimizer.param_groups
                  if gm.optimizer.state.get(g["params"][0])]
-        pl = self._plan_obj if self._plan_key is not None else None
-        txn.py = {"steps": [(t, float(t)) for t in steps], "plan": pl,
-                  "grp": [(int(pl.groups[k].step), float(pl.groups[k].lr), int(pl.groups[k].skip)) for k in range(5)] if pl is not None else None,
+        txn.py = {"steps": [(t, float(t)) for t in steps],
                   "stale_iso": self._stale_iso, "acc_clean": self._acc_clean, "flat_dirty": self._flat_dirty,
                   "exp_stale_rows": set(self._exp.stale_rows) if self._exp is not None else None,
                   "stale_moments": self._zero.get("stale_moments") if self._zero is not None else None}
@@ -1268,10 +1298,14 @@ class FusedMappingLoop(MappingLoop):
         py = txn.py
         for t, v in py["steps"]:
             t.fill_(v)
-        if py["plan"] is not None and py["plan"] is self._plan_obj:
-            for k, (step, lr, skip) in enumerate(py["grp"]):
-                g = py["plan"].groups[k]
-                g.step, g.lr, g.skip = step, lr, skip
+        # the launch structs' own step counters (sgr_map_run advances them in place) follow torch's restored ones -- whichever plan is
+        # current: the plan of a new parameter set is only made INSIDE the transaction's first launch (after the snapshot), so a
+        # comparison with the plan seen at the snapshot would leave its counters advanced (found by a session-level run: a replay
+        # right after a keyframe's new Gaussians was off by a span's worth of Adam bias correction)
+        pl = self._plan_obj if self._plan_key is not None else None
+        if pl is not None:
+            for k, (g, stt) in enumerate(pl.states):
+                pl.groups[k].step = int(float(stt["step"]))
         self._stale_iso, self._acc_clean, self._flat_dirty = py["stale_iso"], py["acc_clean"], py["flat_dirty"]
         if self._exp is not None and py["exp_stale_rows"] is not None:
             self._exp.stale_rows = set(py["exp_stale_rows"])

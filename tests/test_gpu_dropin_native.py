@@ -308,6 +308,7 @@ def test_truncated_render_without_a_backward_is_reported_at_the_next_call():
     finally:
         drg.SYNC = old
     assert ext.stats(0)["last_pairs"] > 2000
+    drg.check_overflow()                                   # (folds the header of the render above: nothing pending)
     try:
         ext.set_capacity(0, 256, forget_map=False, floor_override=256, last_pairs=0)      # a jump nobody could foresee
         with torch.no_grad():

@@ -174,11 +174,12 @@ def _sabotage(f, estimated):
     f._views_dirty()
 
 
-def _drive(kind, sabotage, estimated=False):
+def _drive(kind, sabotage, estimated=False, fresh_plan=False):
     import numpy as np
     from splat_slam_amd.fused import FusedMappingLoop
     syn, params, cams = _dense_scene()
     f = _loop(FusedMappingLoop, syn, params, cams, [0, 1, 2])
+    f.verify_estimates = bool(estimated)       # (the first iteration of a span on estimated counts goes ahead and is checked on its own)
     f.iteration_count = 50
     torch.manual_seed(3)
     np.random.seed(3)
@@ -188,8 +189,12 @@ def _drive(kind, sabotage, estimated=False):
     ev0 = f.overflow_events
     if sabotage:
         _sabotage(f, estimated)
+    if fresh_plan:                 # the launch structs of the parameter set are made inside the transaction's first launch (what
+        f._plan_key = None         # happens after every keyframe's new Gaussians): their step counters must follow a restore too
     if kind == "map":
         f.map(f.current_window, iters=4)
+    elif kind == "map_three_spans":            # a keyframe's 60 iterations go out as 2 + 6 + 52: one transaction, three launches
+        f.map(f.current_window, iters=20)
     elif kind == "prune_then_refine":          # single-step paths: a prune pass (gradients stay in the sinks), then final_refine
         f.map(f.current_window, prune=True, iters=1)
         if sabotage:
@@ -202,21 +207,60 @@ def _drive(kind, sabotage, estimated=False):
     return _full_state(f), f.overflow_events - ev0, f.replayed_transactions, f
 
 
-@pytest.mark.parametrize("kind,estimated", [("map", False), ("map", True), ("prune_then_refine", False), ("per_iteration", False)])
-def test_fused_loop_with_a_tiny_capacity_ends_bitwise_where_the_ample_run_ends(kind, estimated):
+@pytest.mark.parametrize("kind,estimated,fresh_plan", [("map", False, False), ("map", True, False), ("map", True, True), ("map_three_spans", False, True),
+                                                       ("prune_then_refine", False, False), ("per_iteration", False, True)])
+def test_fused_loop_with_a_tiny_capacity_ends_bitwise_where_the_ample_run_ends(kind, estimated, fresh_plan):
     """VERDICT r4 item 5 / SURVEY 8b ownership row: upstream's rasterizer never drops a view (it sizes its buffers inside the call).
     FusedMappingLoop learns of a truncated forward at its next check -- and then puts parameters, Adam moments, step counters,
     densification statistics and exposure rows back to where the transaction began, grows the workspace and issues the same
     iterations again.  Same seeds, one run with the capacity sabotaged down to the floor right before the iterations: every tensor
     of the optimisation must come out bit-identical to the ample-capacity run, with the overflow counted and nothing warned."""
     import warnings
-    ample, ev_a, rp_a, _ = _drive(kind, False)
+    ample, ev_a, rp_a, _ = _drive(kind, False, fresh_plan=fresh_plan)
     assert ev_a == 0 and rp_a == 0
     with warnings.catch_warnings(record=True) as caught:      # (recorded, not turned into errors: an exception raised from inside
         warnings.simplefilter("always")                        #  a torch C++ call that holds no GIL terminates the process)
-        tiny, ev_t, rp_t, f = _drive(kind, True, estimated)
+        tiny, ev_t, rp_t, f = _drive(kind, True, estimated, fresh_plan)
     assert not [w for w in caught if "capacity" in str(w.message)], [str(w.message) for w in caught]
     assert ev_t > 0 and rp_t > 0, (ev_t, rp_t)
     for k in ample:
         assert torch.equal(ample[k], tiny[k]), k
     assert f._cap > (1 << 16) and f.check_overflow() == []
+
+
+def test_session_with_a_replayed_transaction_ends_bitwise_where_an_overflow_free_session_ends():
+    """The same check one level up: 24 tracker frames through MappingSession (seeding, keyframe management, 60 + 1 iterations per
+    keyframe, densification).  With the default capacity rule one view's estimate falls short once in this stretch: the transaction
+    is replayed.  With a capacity floor no view reaches nothing overflows.  Map size and every parameter must agree bit for bit (this
+    is the run that found the launch structs' step counters missing from the restore when the parameter set's structs are made inside
+    the transaction -- which is the case after every keyframe's new Gaussians)."""
+    import numpy as np
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    from splat_slam_amd.session import MappingSession
+    intr = syn.INTRINSICS["metric"]
+    NF = 24
+
+    def run(floor):
+        torch.manual_seed(43)
+        np.random.seed(43)
+        frames = syn.keyframe_stream(NF, intr, DEV, n_world=400000, seed=43, sweep_deg=360.0 * (NF - 1) / 160)
+        torch.manual_seed(43)
+        np.random.seed(43)
+        loop = FusedMappingLoop(syn.DEFAULT_CONFIG, device=DEV)
+        loop.capacity_floor = floor
+        sess = MappingSession(loop, intr)
+        status = [sess.process(*f) for f in frames]
+        torch.cuda.synchronize()
+        gm = loop.gaussians
+        return ({k: getattr(gm, k).detach().clone() for k in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")},
+                loop.overflow_events, loop.replayed_transactions, status)
+
+    ample, ev_a, rp_a, st_a = run(1 << 22)
+    tight, ev_t, rp_t, st_t = run(1 << 16)
+    assert ev_a == 0 and rp_a == 0
+    assert ev_t >= 1 and rp_t >= 1, "no overflow in this stretch any more: pick a stretch / floor that has one"
+    assert st_a == st_t and st_a.count("mapped") >= 15
+    for k in ample:
+        assert ample[k].shape == tight[k].shape, (k, ample[k].shape, tight[k].shape)
+        assert torch.equal(ample[k], tight[k]), k
