@@ -17,7 +17,7 @@ config-sized view) as .npz files that hold, for each scene,
 and scripts/compare_with_upstream_cuda.py (part 2, ~60 lines, needs nothing from this repository) replays them through the
 real CUDA extension on an NVIDIA machine and prints the relative errors.
 
-    python scripts/export_parity_scenes.py [out_dir] [--big]
+    python scripts/export_parity_scenes.py [out_dir] [--big] [--only=tiny,two,...]
 """
 import math
 import os
@@ -79,8 +79,9 @@ def main():
     out_dir = args[0] if args else os.path.join(ROOT, "gpurun_out", "parity_kit")
     os.makedirs(out_dir, exist_ok=True)
     from test_gpu_parity import CASES
+    only = next((a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--only=")), None)
     for name, n, W, H, kw in CASES:
-        if kw.get("sh_degree", 0) > 0 or n > 1500:
+        if kw.get("sh_degree", 0) > 0 or n > 1500 or (only is not None and name not in only):
             continue                                     # degree-0 scenes small enough to mail around
         inp, s = random_scene(n, seed=11, W=W, H=H, **kw)
         inp, s = to_fp32_inputs(inp, s)

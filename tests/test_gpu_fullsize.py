@@ -259,11 +259,15 @@ def _decode_code_bytes(vb, H, W):
 
 
 def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_long_tiles=0, min_huge_tiles=0, opacity_const=None,
-                      by_l2=False, dump=None):
+                      by_l2=False, dump=None, prepare=None, own_depth_sort=False):
+    """prepare(syn, intr, params, cams): edits the raw parameters before the loops are built.  own_depth_sort: the oracle sorts by its
+    OWN depths (no hand-over of the HIP forward's keys) and nothing is excused as a knife edge."""
     import ctypes as C
     from splat_slam_amd import _native as nat
     from splat_slam_amd.fused import FusedMappingLoop
     syn, intr, params, cams = _room(n, camera, nviews, scale_add=scale_add, opacity_add=opacity_add)
+    if prepare is not None:
+        prepare(syn, intr, params, cams)
     if opacity_const is not None:       # every splat equally faint: nothing terminates early, whole lists are walked
         params["opacity"] = torch.full_like(params["opacity"], math.log(opacity_const / (1.0 - opacity_const)))
         cams = syn.make_views(params, nviews, intr, DEV, seed=43)
@@ -330,7 +334,10 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
         view = s.viewmatrix.t()
         check_depth_keys(keys, vb.radii.cpu(), inp["means3D"] @ view[2, :3] + view[2, 3])
         col, radii, dep, opa, nt = O.rasterize(x["means3D"], x["means2D"], x["opacities"], shs=x["shs"], scales=x["scales"],
-                                               rotations=x["rotations"], settings=s, depth_sort_key=keys, knife=knife)
+                                               rotations=x["rotations"], settings=s, depth_sort_key=None if own_depth_sort else keys,
+                                               knife=None if own_depth_sort else knife)
+        if own_depth_sort:
+            soft.check(torch.equal(vb.radii.cpu().long(), radii.long()), f"view {k}: radii (exact)")
         _check_radii(soft, vb.radii.cpu(), radii, f"view {k}")
         a = torch.tensor(float(cam.exposure_a.item()), dtype=torch.float64, requires_grad=True)
         b = torch.tensor(float(cam.exposure_b.item()), dtype=torch.float64, requires_grad=True)
@@ -371,7 +378,7 @@ def _run_batched_case(n, camera, nviews, scale_add=0.0, opacity_add=0.0, min_lon
         nt_h = vb.n_touched.cpu().long()
         soft.check((nt_h - nt.long()).abs().sum().item() <= max(2, n // 500), f"view {k}: n_touched differs by {(nt_h - nt.long()).abs().sum().item()}")
 
-    on_edge = knife_ids(knife, n)
+    on_edge = torch.zeros(n, dtype=torch.bool) if own_depth_sort else knife_ids(knife, n)      # (own_depth_sort: nobody is excused)
     nvis = int(seen.sum())
     soft.check(True, f"{int(on_edge.sum())} of {nvis} visible Gaussians sit on a knife edge in some view")
     pairs = (("xyz", "means3D", 3), ("f_dc", "shs", 3), ("opacity", "opacities", 1), ("scaling", "scales", 3), ("rotation", "rotations", 4))

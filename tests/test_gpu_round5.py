@@ -264,3 +264,82 @@ def test_session_with_a_replayed_transaction_ends_bitwise_where_an_overflow_free
     for k in ample:
         assert ample[k].shape == tight[k].shape, (k, ample[k].shape, tight[k].shape)
         assert torch.equal(ample[k], tight[k]), k
+
+
+# ------------------------------------------------------------------------------------------------ no depth-key hand-over, batched path
+def test_batched_mapping_path_matches_an_oracle_that_sorts_by_its_own_depths():
+    """the no-hand-over case of round 4 (tests/test_gpu_round4.py) runs the drop-in autograd API; this is the same
+    discipline on the path bench.py times -- one sgr_map_views batch: fused tile kernel (forward + loss epilogue + backward in one
+    wave), dense backward, gather with densification statistics.  The scene (configs[0] shape, one view) is first moved off every
+    knife edge and every overlapping near tie in depth; the oracle then sorts by its OWN depths, radii must be equal, and every
+    Gaussian's accumulated gradient and statistic is held to 1e-4 with no knife-edge list to hide behind."""
+    from gpu_utils import move_off_knife_edges_and_depth_ties
+    from oracle import raster_oracle as O
+    from test_gpu_fullsize import _activated_inputs, _oracle_settings, _run_batched_case
+
+    def prepare(syn, intr, params, cams):
+        for attempt in range(4):
+            gm = syn.model_from_parameters(params, device=DEV)
+            inp = _activated_inputs(gm)
+            s = _oracle_settings(cams[0], intr)
+            if attempt:
+                d = O.knife_edge_gaussians(inp["means3D"], inp["opacities"], shs=inp["shs"], scales=inp["scales"], rotations=inp["rotations"],
+                                           settings=s, detail=True)
+                if d["alpha"].numel() == 0 and d["geometric"].numel() == 0:
+                    return                      # what the GPU activates from the raw parameters is off every edge
+            move_off_knife_edges_and_depth_ties(inp, s)
+            # back to raw parameters (fp32): xyz as is, logit / log of the activated values
+            o = inp["opacities"].clamp(1e-6, 1 - 1e-6)
+            params["xyz"] = inp["means3D"].float().to(DEV)
+            params["opacity"] = torch.log(o / (1 - o)).float().to(DEV)
+            params["scaling"] = torch.log(inp["scales"]).float().to(DEV)
+        raise AssertionError("the raw parameters still activate onto a knife edge")
+
+    _run_batched_case(20000, "replica", 1, prepare=prepare, own_depth_sort=True)
+
+
+# ------------------------------------------------------------------------------------------------ never drop, several ranks
+def _mg_overflow_worker(rank, world, port, out, sabotage_rank):
+    import os
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from splat_slam_amd.fused import FusedMappingLoop
+    from splat_slam_amd.parallel import Comm
+    syn, params, cams = _dense_scene()
+    f = _loop(FusedMappingLoop, syn, params, cams, [0, 1, 2, 3])
+    f.set_parallel(world, rank, split_views=True, sync="zero1", comm=Comm(staged=True))
+    f.iteration_count = 50
+    torch.manual_seed(3)
+    np.random.seed(3)
+    f.map(f.current_window, iters=2)
+    torch.cuda.synchronize()
+    if rank == sabotage_rank:                  # ONE rank's capacity falls short: every rank must replay (the collectives are journaled)
+        _sabotage(f, False)
+    f.map(f.current_window, iters=3)
+    torch.cuda.synchronize()
+    st = _full_state(f)
+    st["events"], st["replays"] = torch.tensor(float(f.overflow_events)), torch.tensor(float(f.replayed_transactions))
+    out[rank] = {k: v.cpu() for k, v in st.items() if k != "flat"}
+    dist.destroy_process_group()
+
+
+def test_two_ranks_replay_together_when_one_rank_overflows():
+    """ZeRO-1 over two ranks (views dealt round-robin).  Rank 1's capacity is sabotaged before three iterations: its check finds the
+    truncated forwards, the flag is all-reduced, BOTH ranks put their state back and issue the span (with its reduce-scatter /
+    all-gather) again.  Replicas stay bitwise equal, and equal to the run in which nobody overflowed."""
+    a0, a1 = _spawn2(_mg_overflow_worker, -1)
+    t0, t1 = _spawn2(_mg_overflow_worker, 1)
+    assert a0["replays"].item() == 0 and a1["replays"].item() == 0
+    assert t1["events"].item() > 0 and t0["events"].item() == 0
+    assert t0["replays"].item() >= 1 and t1["replays"].item() >= 1, "both ranks replay"
+    skip = ("events", "replays", "accum", "denom", "maxr")       # (densification statistics are per rank until a densification)
+    for k in a0:
+        if k in skip:
+            continue
+        assert torch.equal(t0[k], t1[k]), ("ranks differ", k)
+        assert torch.equal(t0[k], a0[k]), ("replayed != overflow-free", k)
+    for k in ("accum", "denom", "maxr"):
+        assert torch.equal(t0[k], a0[k]) and torch.equal(t1[k], a1[k]), k
