@@ -127,7 +127,10 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
-def measure_traffic(extra_args, kernels, timeout=240):
+_PMC_BROKEN = []          # (a failed pass is not tried again in this run: a box whose profiler hangs must not cost the line minutes)
+
+
+def measure_traffic(extra_args, kernels, timeout=90):
     """HBM bytes per launch of `kernels`, measured NOW: two short rocprofv3 child passes of this same script (counters in their own
     runs, --pmc + --kernel-trace only, from /tmp: MI355X_MICROARCH.md), FETCH_SIZE and WRITE_SIZE averaged over the batched
     (largest-grid) launches, bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts a 128-byte request as 64 in FETCH_SIZE; both
@@ -140,6 +143,8 @@ def measure_traffic(extra_args, kernels, timeout=240):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return {}, "rocprofv3 not found on this box"
+    if _PMC_BROKEN:
+        return {}, _PMC_BROKEN[0]
     child = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--settle", "20", "--no-cpu-baseline", "--no-extras",
              "--refine-iters", "0", "--no-pmc"] + list(extra_args)
     env = dict(os.environ, TMPDIR="/tmp")
@@ -151,7 +156,8 @@ def measure_traffic(extra_args, kernels, timeout=240):
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return {}, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
+                _PMC_BROKEN.append("rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode))
+                return {}, _PMC_BROKEN[0]
             agg = collections.defaultdict(list)
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] == counter:
@@ -161,7 +167,8 @@ def measure_traffic(extra_args, kernels, timeout=240):
                 sel = [x[1] for x in v if x[0] == g]
                 vals.setdefault(k, {})[counter] = sum(sel) / len(sel)
         except Exception as e:      # noqa: BLE001
-            return {}, "rocprofv3 --pmc %s pass: %r" % (counter, e)
+            _PMC_BROKEN.append("rocprofv3 --pmc %s pass: %r" % (counter, e))
+            return {}, _PMC_BROKEN[0]
         finally:
             shutil.rmtree(d, ignore_errors=True)
     out = {}
