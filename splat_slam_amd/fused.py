@@ -8,10 +8,12 @@
                    (used around map surgery, with pose optimisation, and -- twice per iteration with one all-reduce in
                    between -- on several GPUs)
 
-instead of ~60 eager torch kernels and an autograd graph per view.  Nothing on this path synchronises with the host:
-outputs, saved blocks and gradient sinks are persistent device buffers sized once per map size (HBM is 288 GB;
-re-allocation only happens when densify / prune changes N), the pair capacity of every camera is learned by one
-synchronous probe forward and re-checked every `check_every` iterations.
+instead of ~60 eager torch kernels and an autograd graph per view.  Nothing on this path synchronises with the host
+between two capacity checks: outputs, saved blocks and gradient sinks are persistent device buffers (HBM is 288 GB), a
+camera's pair capacity is carried over from its last measured count.  The checks (end of every loop call, before map
+surgery, every `check_every` iterations) close a TRANSACTION: a forward that exceeded its capacity is never dropped from
+the optimisation -- the state is restored and the iterations since the last check are issued again at the corrected
+capacity, bit-identical to a run that never overflowed (_txn_begin / _txn_do / _txn_commit below).
 
 Numerically this is the same computation as the autograd loop (tests/test_gpu_fused.py compares gradients and parameter
 trajectories; the run / step / fused-tail / multi-rank variants are bitwise identical among themselves); only the order
@@ -602,8 +604,8 @@ class FusedMappingLoop(MappingLoop):
         session ~120 host-synchronised renders per keyframe (the 2 random views of every iteration are mostly cameras not yet
         seen at this size), so the count is carried over instead: the camera's last MEASURED count, scaled by the growth of
         the map; a camera never measured takes the largest estimate of the others (neighbouring views of one room); only
-        with nothing to go by is it probed.  Capacity is twice the estimate; an estimate that still falls short costs that
-        view one iteration (a truncated view contributes nothing, sgr_aux.hip) until the early check below corrects it."""
+        with nothing to go by is it probed.  Capacity is twice the estimate; an estimate that still falls short is found by the
+        check that closes the transaction, which re-runs the iterations at the corrected capacity (_txn_commit)."""
         est = estimate_pairs(self._pair_hint, cam.uid, self.gaussians._xyz.shape[0])
         if est is None:
             self._probe(cam, vb)
