@@ -30,6 +30,7 @@ CASES = [
     # the in-HBM sort path; 'heavy' selects the 4096-key build and the multi-chunk (64-lane) backward
     ("skewed", 2500, 256, 256, dict(fx=220.0, fy=220.0, cx=127.5, cy=127.5, spread=0.12, scale_range=(0.004, 0.03))),
     ("heavy", 3000, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, scale_range=(0.05, 0.3))),
+    ("sh1", 150, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, sh_degree=1)),
     ("sh2", 150, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, sh_degree=2)),
     ("sh3", 150, 64, 48, dict(fx=55.0, fy=52.0, cx=30.7, cy=24.9, sh_degree=3)),
 ]
@@ -67,6 +68,24 @@ def test_forward_and_backward_match_oracle(case):
         r = rel_linf(hip_g[k].reshape(-1), ref_g[k].reshape(-1))
         assert r <= REL or ref_g[k].abs().max() == 0, f"{name}: grad {k} rel err {r}"
     assert torch.all(hip_g["means2D"][:, 2] == 0)
+
+
+@pytest.mark.parametrize("mod", [0.6, 1.7])
+def test_scale_modifier_matches_oracle(mod):
+    """`scale_modifier` of GaussianRasterizationSettings (render(..., scaling_modifier), gaussian_renderer/__init__.py:24,63): S = diag(mod * s)
+    in the covariance, forward and backward (the scale gradient carries the factor)."""
+    inp, s = random_scene(300, seed=13, W=64, H=48)
+    inp, s = to_fp32_inputs(inp, s)
+    s = s._replace(scale_modifier=mod)
+    wc, wd = _weights(6, 48, 64)
+    hip_out, hip_g = run_hip(inp, s, wc, wd)
+    ref_out, ref_g = run_oracle(inp, s, wc, wd, dtype=torch.float64)
+    _check_images(hip_out, ref_out, f"mod{mod}")
+    for k in GRAD_KEYS:
+        r = rel_linf(hip_g[k].reshape(-1), ref_g[k].reshape(-1))
+        assert r <= REL or ref_g[k].abs().max() == 0, f"scale_modifier {mod}: grad {k} rel err {r}"
+    base_out, _ = run_hip(inp, s._replace(scale_modifier=1.0), wc, wd)
+    assert not torch.equal(base_out[0], hip_out[0])          # (the factor really changes the render)
 
 
 def test_precomputed_colour_and_covariance_inputs():

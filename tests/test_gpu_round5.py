@@ -343,3 +343,46 @@ def test_two_ranks_replay_together_when_one_rank_overflows():
         assert torch.equal(t0[k], a0[k]), ("replayed != overflow-free", k)
     for k in ("accum", "denom", "maxr"):
         assert torch.equal(t0[k], a0[k]) and torch.equal(t1[k], a1[k]), k
+
+
+def test_session_with_systematically_short_estimates_replays_often_and_still_ends_bitwise_equal(monkeypatch):
+    """Stress: every carried-over pair-count estimate is cut to a fifth (so that twice the estimate is still short), which makes
+    the first transaction after most keyframes overflow -- across seeding, densification / pruning and an opacity reset.  30 tracker
+    frames; the map must come out bit-identical to the session with a capacity floor that nothing reaches."""
+    import numpy as np
+    from splat_slam_amd import fused as fused_mod
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.session import MappingSession
+    intr = syn.INTRINSICS["metric"]
+    NF = 30
+    real = fused_mod.estimate_pairs
+
+    def run(floor, short):
+        monkeypatch.setattr(fused_mod, "estimate_pairs", (lambda h, u, n: (None if real(h, u, n) is None else max(1, real(h, u, n) // 5))) if short else real)
+        torch.manual_seed(43)
+        np.random.seed(43)
+        frames = syn.keyframe_stream(NF, intr, DEV, n_world=400000, seed=43, sweep_deg=360.0 * (NF - 1) / 160)
+        torch.manual_seed(43)
+        np.random.seed(43)
+        loop = fused_mod.FusedMappingLoop(syn.DEFAULT_CONFIG, device=DEV)
+        loop.capacity_floor = floor
+        sess = MappingSession(loop, intr)
+        status = []
+        for f in frames:
+            if short:              # the capacity only ever grows: forget it before every frame, so that the short estimates decide
+                loop._cap = loop.capacity_floor
+                loop._views_dirty()
+            status.append(sess.process(*f))
+        torch.cuda.synchronize()
+        gm = loop.gaussians
+        return ({k: getattr(gm, k).detach().clone() for k in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")},
+                loop.overflow_events, loop.replayed_transactions, status)
+
+    ample, ev_a, rp_a, st_a = run(1 << 22, False)
+    short, ev_s, rp_s, st_s = run(1 << 12, True)
+    print("replayed transactions with short estimates:", rp_s, "overflow events:", ev_s)
+    assert ev_a == 0 and rp_a == 0 and rp_s >= 5, (rp_s, ev_s)
+    assert st_a == st_s
+    for k in ample:
+        assert ample[k].shape == short[k].shape, (k, ample[k].shape, short[k].shape)
+        assert torch.equal(ample[k], short[k]), k
