@@ -145,6 +145,11 @@ def measure_traffic(extra_args, kernels, timeout=90):
         return {}, "rocprofv3 not found on this box"
     if _PMC_BROKEN:
         return {}, _PMC_BROKEN[0]
+    # never nest profilers: when this very process is being traced (somebody runs `rocprofv3 ... -- python bench.py`) its tool
+    # environment would be inherited by the child passes -- a --pmc pass inside a --stats / trace pass is the combination the
+    # GPU pool's launcher refuses
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {}, "this process runs under a profiler itself: no nested rocprofv3 passes"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--settle", "20", "--no-cpu-baseline", "--no-extras",
              "--refine-iters", "0", "--no-pmc"] + list(extra_args)
     env = dict(os.environ, TMPDIR="/tmp")

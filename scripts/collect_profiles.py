@@ -15,7 +15,7 @@ env = dict(os.environ, TMPDIR="/tmp")
 # the profiled command: the headline loop (fused tile kernel) + bench.py's own un-fused / fused roofline legs, so that the trace
 # holds blend_bwd_kernel<true> launches (the kernel `roofline` is quoted for) next to the fused kernel's
 BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "6", "--no-cpu-baseline", "--refine-iters", "0",
-         "--no-extras"]
+         "--no-extras", "--no-pmc"]
 
 
 def short(name):

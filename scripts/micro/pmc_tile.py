@@ -16,7 +16,7 @@ if "--passes" in extra:
     only = [int(x) for x in extra[i + 1].split(",")]
     extra = extra[:i] + extra[i + 2:]
 env = dict(os.environ, TMPDIR="/tmp")
-BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "6", "--no-cpu-baseline", "--refine-iters", "0", "--no-extras"] + extra
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "6", "--no-cpu-baseline", "--refine-iters", "0", "--no-extras", "--no-pmc"] + extra
 PASSES = [["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INST_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "SQ_INSTS_LDS"],
           ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC", "SQ_INSTS_BRANCH"],
           ["SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU_CVT"]]
