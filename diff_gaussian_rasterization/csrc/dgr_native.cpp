@@ -19,6 +19,7 @@
 #include <torch/csrc/autograd/function.h>
 #include <torch/csrc/autograd/variable.h>
 #include <torch/csrc/autograd/functions/accumulate_grad.h>
+#include <torch/csrc/autograd/generated/Functions.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/core/DeviceGuard.h>
 
@@ -306,6 +307,46 @@ struct Batch {
       if (n == k) return true;
     return false;
   }
+  // The whitelisted operators are pure functions of their tensor inputs AND of a few non-tensor arguments (cat / norm / squeeze
+  // dims, the clamp's minimum, repeat / expand / view sizes, permutations).  Two chains that differ only in such an argument -- a
+  // permute of a square tensor, another eps -- have the same node names and the same topology: the arguments are compared as
+  // well, and so is the shape of every intermediate result (a node's input metadata = its forward outputs).
+  static bool same_syms(const std::vector<c10::SymInt>& x, const std::vector<c10::SymInt>& y) {
+    if (x.size() != y.size()) return false;
+    for (size_t i = 0; i < x.size(); ++i)
+      if (x[i].expect_int() != y[i].expect_int()) return false;
+    return true;
+  }
+  static bool same_scalar(const at::Scalar& x, const at::Scalar& y) {
+    return x.isFloatingPoint() == y.isFloatingPoint() && x.isIntegral(true) == y.isIntegral(true) && x.toDouble() == y.toDouble();
+  }
+  static bool same_attributes(const torch::autograd::Node* a, const torch::autograd::Node* b) {
+    namespace G = torch::autograd::generated;
+    if (a->num_inputs() != b->num_inputs()) return false;
+    for (uint32_t i = 0; i < a->num_inputs(); ++i)
+      if (a->input_metadata(i).shape_as_dim_vector() != b->input_metadata(i).shape_as_dim_vector()) return false;
+#define DGR_SAME(T, EXPR)                                  \
+  if (auto* x = dynamic_cast<const G::T*>(a)) {            \
+    auto* y = dynamic_cast<const G::T*>(b);                \
+    return y != nullptr && (EXPR);                         \
+  }
+    DGR_SAME(CatBackward0, x->dim == y->dim && x->tensors_size_ == y->tensors_size_)
+    DGR_SAME(RepeatBackward0, same_syms(x->repeats, y->repeats) && same_syms(x->self_sym_sizes, y->self_sym_sizes))
+    DGR_SAME(ExpandBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
+    DGR_SAME(ClampMinBackward0, same_scalar(x->min, y->min))
+    DGR_SAME(LinalgVectorNormBackward0, x->keepdim == y->keepdim && same_scalar(x->ord, y->ord) && x->dim.list == y->dim.list)
+    DGR_SAME(NormBackward1, x->keepdim == y->keepdim && x->dim == y->dim && x->p.has_value() == y->p.has_value() &&
+                                (!x->p.has_value() || same_scalar(*x->p, *y->p)))
+    DGR_SAME(TransposeBackward0, x->dim0 == y->dim0 && x->dim1 == y->dim1)
+    DGR_SAME(ViewBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
+    DGR_SAME(UnsafeViewBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
+    DGR_SAME(ReshapeAliasBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
+    DGR_SAME(PermuteBackward0, x->dims == y->dims)
+    DGR_SAME(UnsqueezeBackward0, x->dim == y->dim)
+    DGR_SAME(SqueezeBackward1, x->dim == y->dim && same_syms(x->self_sym_sizes, y->self_sym_sizes))
+#undef DGR_SAME
+    return true;        // Exp, Sigmoid, Div, Clone, Alias: nothing but their tensor inputs
+  }
   void record_leaves(const torch::autograd::Node* fn, int depth) {
     if (!fn || depth > 8) return;
     if (auto* acc = dynamic_cast<const torch::autograd::AccumulateGrad*>(fn)) {
@@ -325,6 +366,7 @@ struct Batch {
       return true;
     }
     if (a->name() != b->name() || !pure_op(a->name()) || a->num_outputs() != b->num_outputs()) return false;
+    if (!same_attributes(a, b)) return false;
     for (uint32_t j = 0; j < a->num_outputs(); ++j) {
       const auto& ea = a->next_edge(j);
       const auto& eb = b->next_edge(j);

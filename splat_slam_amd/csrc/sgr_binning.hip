@@ -164,7 +164,12 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, in
       const uint32_t binned = *(volatile uint32_t*)&hdr->num_rendered, slots = *(volatile uint32_t*)&hdr->slot_total;
       hdr->num_binned = binned;
       if (slots > binned) hdr->num_rendered = slots;
-      if ((int64_t)slots > L.cap && hdr->overflow == 0u) hdr->overflow = 1u;
+      uint32_t ov = *(volatile uint32_t*)&hdr->overflow;
+      if ((int64_t)slots > L.cap && ov == 0u) hdr->overflow = ov = 1u;
+      // the sticky pair (see SavedHeader): this forward's verdict outlives the next forward's header
+      if (ov != 0u) hdr->overflow_events = hdr->overflow_events + 1u;
+      const uint32_t demanded = slots > binned ? slots : binned;
+      if (demanded > hdr->max_rendered) hdr->max_rendered = demanded;
     }
   }
 }

@@ -119,8 +119,15 @@ struct SavedHeader {
   uint32_t num_binned;     // pairs actually binned (K3; num_rendered then holds the capacity-relevant max(pairs binned, slot_total))
   uint32_t max_tile_count; // longest per-tile list of this forward (K2): what the caller picks the tile kernels' sort build by
   uint32_t k2_tickets;     // K2's blocks 0 and 1 take a ticket when done; the later one folds the header and resets this
-  uint32_t pad[4];
+  // STICKY across forwards (only zero_heads clears them, together with the tile counters of a fresh block): `overflow` describes the
+  // LAST forward only, and a workspace runs up to ~52 forwards between two host checks (sgr_map_run; a slot renders a different
+  // camera every iteration) -- a truncated forward in the middle of a span would be overwritten before anybody looks.  The host
+  // remembers the count it saw at its previous check: a changed count = some forward since then was truncated.
+  uint32_t overflow_events;   // forwards of this workspace whose `overflow` came out non-zero
+  uint32_t max_rendered;      // largest num_rendered of any forward of this workspace (what a replay sizes the capacity by)
+  uint32_t pad[2];
 };
+static_assert(sizeof(SavedHeader) == 64, "the header is one 64-byte record (sgr_query_header copies 16 words)");
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

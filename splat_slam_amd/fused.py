@@ -66,6 +66,7 @@ class _ViewBuffers:
         self.saved = None
         self.scratch = None
         self.clean = False         # the saved block went through a forward (its per-tile counters are zero)
+        self.ovf_seen = 0          # SavedHeader.overflow_events as of the last check (sticky on the device, see _apply_headers)
         self.capacity = 0
         self.gt_depth = None
         self.depth_src = None
@@ -137,6 +138,7 @@ class _Slot:
     def __init__(self):
         self.saved = self.scratch = None
         self.clean = self.ran = False
+        self.ovf_seen = 0
         self.capacity = 0
         self.mv = None
         self.gen = 0
@@ -554,15 +556,22 @@ class FusedMappingLoop(MappingLoop):
                     del self._ws_owners[k]
                     if old.saved is not None and old.saved.numel() >= sb and old.scratch.numel() >= tb and (vb.saved is None):
                         vb.saved, vb.scratch, vb.clean = old.saved, old.scratch, False     # (another (H, W) may have used it)
+                        vb.ran, vb.ovf_seen = False, 0      # (its header is the previous owner's until the next forward zeroes it)
                         vb.gen += 1
                     old.saved = old.scratch = None
                     old.clean = old.ran = False
+                    old.ovf_seen = 0
                     old.mv = None
+                    # whoever cached structs that point into the evicted blocks must not use them again (the span cache
+                    # holds COPIES of the window cameras' structs and is only validated by these generations)
+                    old.gen += 1
+                    self._span_cache = None
                     break
         if vb.saved is None or vb.saved.numel() < sb:
             vb.saved = torch.empty((int(sb * 1.3) + (1 << 20)) // 256 * 256, dtype=torch.uint8, device=self.device)
             vb.gen += 1
             vb.clean = False       # per-tile counters of a fresh block are garbage: the library zeroes them once
+            vb.ran, vb.ovf_seen = False, 0
         if vb.scratch is None or vb.scratch.numel() < tb:
             vb.scratch = torch.empty((int(tb * 1.3) + (1 << 20)) // 256 * 256, dtype=torch.uint8, device=self.device)
             vb.gen += 1
@@ -575,10 +584,15 @@ class FusedMappingLoop(MappingLoop):
         replaces depended on the probe history and flipped the build between two runs of the same scene)."""
         return max(self._list_hint.values()) if self._list_hint else 0
 
-    def _read_header(self, uid, vb):
-        """One synchronous header read of a camera's last forward: pair count, overflow word, longest list."""
+    def _read_header(self, uid, vb, own_attempts=False):
+        """One synchronous header read of a camera's last forward: pair count, overflow word, longest list.  The sticky event count
+        (SavedHeader.overflow_events) is acknowledged for THIS forward only -- or, `own_attempts`, for everything so far (a probe's
+        own failed attempts) -- so that a truncated forward of an open transaction on the same workspace still shows at the next
+        check (a forward-only render used to erase it together with the header)."""
         w = (C.c_uint32 * 16)()
         nat.check(self.lib.sgr_query_header(vb.saved.data_ptr(), w, self._stream()), "sgr_query_header")
+        events = int(w[12])
+        vb.ovf_seen = events if own_attempts else min(events, vb.ovf_seen + (1 if int(w[1]) else 0))
         return self._apply_header(uid, vb, w)
 
     def _apply_header(self, uid, vb, w):
@@ -636,7 +650,7 @@ class FusedMappingLoop(MappingLoop):
             nat.check(rc, "sgr_forward")
             break
         vb.clean = vb.ran = True
-        self._read_header(cam.uid, vb)            # (also the longest list: the sort build of the tile kernels)
+        self._read_header(cam.uid, vb, own_attempts=True)            # (also the longest list: the sort build of the tile kernels)
         if vb.pairs > self.max_pairs:
             gm = self.gaussians
             with torch.no_grad():
@@ -752,8 +766,11 @@ class FusedMappingLoop(MappingLoop):
         if hit is not None and hit[0] == ident and hit[1] == self._gen and all(self._views[c.uid].gen == g for c, g in zip(window_cams, hit[2])):
             self._ws_protect = hit[5]
             for i, c in enumerate(window_cams):          # (the array holds COPIES of the cached structs: a block that has been through a
-                if self._views[c.uid].clean:             #  forward since needs no zeroing launch in front of the next span)
+                vb = self._views[c.uid]                  #  forward since needs no zeroing launch in front of the next span)
+                if vb.clean:
                     hit[3][i].ws.counters_clean = 1
+                if id(vb) in self._ws_owners:            # a hit never goes through _workspace(): keep the window's blocks the most
+                    self._ws_owners.move_to_end(id(vb))  # recently used ones, or they become the likeliest eviction victims
             return hit[3], hit[4]
         self._settle_capacity(cams)                                              # estimates for new cameras, ONE capacity
         win = self._views_array(window_cams, initialization, images=False, settle=False) if window_cams else None
@@ -1203,8 +1220,17 @@ class FusedMappingLoop(MappingLoop):
         words = host.numpy().view(np.uint32).reshape(-1, 16)
         worst, overflowed = 0, []
         for (uid, vb), w in zip(todo, words):
+            # `overflow` (word 1) describes the workspace's LAST forward; words 12 / 13 are sticky (K2): the number of truncated
+            # forwards since the block was zeroed and the largest pair count any forward demanded.  A span runs ~52 forwards per
+            # workspace between two checks and a slot renders a different camera each time: the verdict is the CHANGE of the count.
+            events = int(w[12])
             ov = int(w[1])
+            if events != vb.ovf_seen and ov == 0:
+                ov = 1
+            vb.ovf_seen = events
             self._apply_header(uid, vb, w)
+            if ov == 1:
+                vb.pairs = max(vb.pairs, int(w[13]))          # size the replay by the worst forward, not by the last one
             if vb.pairs > self.max_pairs:
                 raise RuntimeError(f"camera {uid}: {vb.pairs} (tile, Gaussian) pairs -- more than max_pairs = {self.max_pairs}; "
                                    "the map has degenerated")
@@ -1443,6 +1469,8 @@ class FusedMappingLoop(MappingLoop):
         random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in cw]
         pose_opt = self.keyframe_optimizers is not None
         gaussian_split = False
+        self._span_cache = None      # the span arrays are shared by the spans of ONE map() call (between calls renders of other frames may
+                                     # have re-assigned workspaces; re-making them once per call is 0.14 ms)
         it = -1
         while it + 1 < iters:
             it += 1

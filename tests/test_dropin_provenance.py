@@ -68,3 +68,27 @@ def test_a_parameter_update_between_two_renders_ends_the_batch(ext):
     with torch.no_grad():
         p["scale"].add_(0.1)                                                       # (an optimiser step: bumps the leaf's version)
     assert not ext.provenance_joins(torch.exp(p["scale"]))
+
+
+def test_chains_that_differ_only_in_a_non_tensor_argument_do_not_batch(ext):
+    """node names + topology + leaf versions are not enough -- the whitelisted operators also depend on dims, sizes, a
+    clamp minimum, a norm order.  Same names, same leaves, same final shape, other values: must not join."""
+    g = torch.Generator().manual_seed(2)
+    sq = torch.randn(4, 4, generator=g).requires_grad_()
+    ext.provenance_open(torch.exp(sq.permute(1, 0)).contiguous())
+    assert ext.provenance_joins(torch.exp(sq.permute(1, 0)).contiguous())
+    assert not ext.provenance_joins(torch.exp(sq.permute(0, 1)).contiguous())                # another permutation of a square tensor
+    p = _leaves()
+    ext.provenance_open(F.normalize(p["rot"]))
+    assert ext.provenance_joins(F.normalize(p["rot"]))
+    assert not ext.provenance_joins(F.normalize(p["rot"], eps=1e-3))                         # another clamp minimum
+    assert not ext.provenance_joins(F.normalize(p["rot"], p=1.0))                            # another norm order
+    r4 = torch.randn(4, 4, generator=g).requires_grad_()
+    ext.provenance_open(F.normalize(r4, dim=1))
+    assert not ext.provenance_joins(F.normalize(r4, dim=0))                                  # another dim, same shapes throughout
+    c1, c2 = torch.randn(3, 3, generator=g).requires_grad_(), torch.randn(3, 3, generator=g).requires_grad_()
+    ext.provenance_open(torch.cat((c1, c2), dim=0).view(3, 6))
+    assert ext.provenance_joins(torch.cat((c1, c2), dim=0).view(3, 6))
+    assert not ext.provenance_joins(torch.cat((c1, c2), dim=1).view(3, 6))                   # cat along another dim, viewed to the same shape
+    ext.provenance_open(torch.exp(p["scale"]).repeat(1, 3).view(3, 7))
+    assert not ext.provenance_joins(torch.exp(p["scale"]).repeat(3, 1).view(3, 7))           # other repeats, same final shape

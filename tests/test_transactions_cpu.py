@@ -144,3 +144,29 @@ def test_two_ranks_replay_together_over_gloo():
         ref._txn_do(lambda: _fake_iteration(ref, rlog))
     ref._txn_commit()
     _equal(s0, _state(ref))
+
+
+def test_a_truncated_forward_in_the_middle_of_a_span_is_still_seen_at_the_check():
+    """SavedHeader.overflow is rewritten by every forward, a span puts ~52 forwards through one workspace between
+    two checks and a slot renders a different camera each time.  K2 therefore also keeps a STICKY count of truncated forwards
+    (header word 12) and the largest pair count demanded (word 13); _apply_headers reports a workspace whose count CHANGED since the
+    previous check even though its last forward was fine, and sizes the replay by the worst forward."""
+    import numpy as np
+    from splat_slam_amd.fused import _Slot
+    f = _loop()
+    f._cap, f.capacity_floor, f.max_pairs = 1 << 16, 1 << 16, 1 << 30
+    sl = _Slot()
+    sl.pairs, sl.estimated = 100, False
+
+    def header(last_R, last_ov, events, max_R, longest=7):
+        w = np.zeros(16, dtype=np.uint32)
+        w[0], w[1], w[10], w[12], w[13] = last_R, last_ov, longest, events, max_R
+        return torch.from_numpy(w.view(np.uint8).copy())
+
+    todo = [(("slot", 0), sl)]
+    assert f._apply_headers(todo, header(100, 0, 0, 100)) == []                       # nothing happened
+    got = f._apply_headers(todo, header(120, 0, 1, 90000))                            # a middle forward overflowed, the last one did not
+    assert got == [("slot", 0)] and f.overflow_events == 1
+    assert sl.pairs == 90000 and f._cap >= 2 * 90000                                  # the replay is sized by the worst forward
+    assert f._apply_headers(todo, header(120, 0, 1, 90000)) == []                     # acknowledged: the same count is not news
+    assert f._apply_headers(todo, header(95000, 1, 2, 95000)) == [("slot", 0)]        # the classic case: the last forward itself
