@@ -131,14 +131,37 @@ __device__ __forceinline__ void wave_sort_registers(const uint64_t* __restrict__
   for (int r = 0; r < KPL; ++r) ids[lane * KPL + r] = (uint32_t)k[r];
 }
 
-// The exponent of a splat's footprint is evaluated in base 2: both tile kernels take the conic (A, B, C) multiplied by log2(e) where they
-// stage / fetch a splat's record (three multiplies per (tile, splat) pair) and feed the quadratic form straight to v_exp_f32 -- the
-// multiply by log2(e) that __expf puts in front of every exponential was 2 of the ~95 issue slots of a backward iteration and 2 of
-// the ~45 of a forward trip.  Forward and backward scale the same way, so they still agree bit for bit on which pairs contribute;
-// the sign test `power <= 0` is unaffected.
+// The exponent of a splat's footprint is evaluated in base 2 and with its sign flipped: both tile kernels take the conic scaled to
+//   A' = A log2(e) / 2,  B' = B log2(e),  C' = C log2(e) / 2
+// where they stage / fetch a splat's record (three multiplies per (tile, splat) pair) and evaluate
+//   npow = dx (A' dx + B' dy) + (C' dy) dy  =  -log2(e) * power            (five operations where -(A dx^2 + C dy^2) / 2 - B dx dy took seven)
+//   G = exp2(-npow)                                                        (the negation is a source modifier of v_exp_f32)
+// Which pairs contribute -- the reference's `power > 0 -> skip` and `alpha < 1/255 -> skip` -- is ONE unsigned integer compare of the bit
+// patterns, bits(npow) <= bits(nthr) with nthr = log2(255 opacity) >= 0 per splat: a negative npow (power > 0) has its sign bit set and
+// is larger than any non-negative float's pattern, and for npow >= 0 the patterns are ordered like the values, so the compare is
+// 0 <= npow <= nthr  <=>  power <= 0 and opacity * G >= 1/255 (up to the rounding of the logarithm: the reference's own fp32 expf puts
+// the alpha = 1/255 level set no more exactly; parity tests move scenes off that knife edge).  It replaced two floating-point compares
+// (+ an and) per (pixel, splat) in both walks.  A splat with 255 * opacity < 1 can never contribute: it is staged as a splat far outside
+// any image with nthr = +0.  Forward and backward evaluate the same IEEE operation sequence, so they agree bit for bit on who contributes.
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int kStash = 16, kStashStride = 66, kStashOffset = 864;      // (864 = the staging bytes of 16 splats + the pad splat)
+constexpr int kStageFloats = 14;       // staged floats per splat (pair-interleaved: 7 float4 per PAIR of splats)
+constexpr int kStageBytes = kStageFloats * 4;
+constexpr int kStash = 16, kStashStride = 66, kStashOffset = (kStash / 2 + 1) * 2 * kStageBytes;      // (the staging bytes of 16 splats + the pad pair)
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+struct Shape { float mx, my, A, B, C, op, nthr; };
+__device__ __forceinline__ Shape stage_shape(float px, float py, float A, float B, float C, float opacity) {
+  const float x255 = 255.f * opacity;
+  Shape s;
+  if (x255 >= 1.f) {
+    s.mx = px; s.my = py; s.A = A * (0.5f * kLog2e); s.B = B * kLog2e; s.C = C * (0.5f * kLog2e); s.op = opacity;
+    s.nthr = __builtin_amdgcn_logf(x255);        // v_log_f32 = log2 (>= +0 for x255 >= 1)
+  } else {                                       // (also the zero splat that pads an odd list: npow is huge, +0 never reaches it)
+    s.mx = -1.0e6f; s.my = -1.0e6f; s.A = 1.f; s.B = 0.f; s.C = 1.f; s.op = 0.f; s.nthr = 0.f;
+  }
+  return s;
+}
+// bits(npow) <= bits(nthr) as unsigned integers (see above)
+__device__ __forceinline__ bool in_footprint(float npow, float nthr) { return __float_as_uint(npow) <= __float_as_uint(nthr); }
 
 // gfx950 has packed fp32 (v_pk_mul/add/fma_f32: two IEEE fp32 results per issue slot); both blend kernels use 2-vectors
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -284,7 +307,7 @@ __device__ __forceinline__ v2f prev_plus(float q0, float q1, v2f c, int lane) {
 
 // What a lane needs to know about ITS splat: footprint, colour, depth and the slot of this (tile, Gaussian) pair inside
 // the Gaussian's run of partials (0xffffffff: not stored -- beyond the capacity).
-struct SplatRec { float mx, my, A, B, C, op, r, g, b, dep; uint32_t slot; };
+struct SplatRec { float mx, my, A, B, C, op, nthr, r, g, b, dep; uint32_t slot; };      // (A, B, C, nthr: stage_shape())
 __device__ __forceinline__ uint32_t pair_slot(const char* __restrict__ saved, const LOff& L, uint32_t g, uint32_t rel, uint32_t rect01,
                                               uint32_t rect23, int tx, int ty, int64_t cap) {
   const Rect r = unpack_rect(rect01, rect23);
@@ -299,7 +322,8 @@ __device__ __forceinline__ SplatRec splat_from_grec(const GRec* __restrict__ gre
   const uint32_t rel = ((const uint32_t*)(rec + 3))[1];
   SplatRec s;
   s.slot = pair_slot(saved, L, g, rel, __float_as_uint(m.z), __float_as_uint(m.w), tx, ty, cap);
-  s.mx = m.x; s.my = m.y; s.A = co.x * kLog2e; s.B = co.y * kLog2e; s.C = co.z * kLog2e; s.op = co.w; s.r = cd.x; s.g = cd.y; s.b = cd.z; s.dep = cd.w;
+  const Shape sh = stage_shape(m.x, m.y, co.x, co.y, co.z, co.w);
+  s.mx = sh.mx; s.my = sh.my; s.A = sh.A; s.B = sh.B; s.C = sh.C; s.op = sh.op; s.nthr = sh.nthr; s.r = cd.x; s.g = cd.y; s.b = cd.z; s.dep = cd.w;
   return s;
 }
 // list position -> Gaussian through the index list the forward kernel published (blend_bwd_kernel)
@@ -316,15 +340,24 @@ struct SrcKeys {
   }
   __device__ __forceinline__ SplatRec load(int idx, const LOff& L) const { return splat_from_grec(grec, saved, L, gaussian(idx), tx, ty, cap); }
 };
-// fused kernel, list of one chunk (98 % of the tiles of a SLAM view): the forward walk's pair-interleaved staging area
-// still holds every splat of the tile (12 floats each, the 12th = the pair's partial slot): no second gather from HBM
+// The forward walk's staging area: kStageFloats floats per splat, PAIR-interleaved (element e of splats 2p, 2p + 1 side by side at float
+// 2 e of pair p's 7 float4): 0 mx  1 my | 2 A'  3 B' | 4 C'  5 opacity | 6 depth  7 Gaussian | 8 r  9 g | 10 b  11 nthr | 12 slot  13 -
+__device__ __forceinline__ float* staged_at(float4* lds, uint32_t pos) { return (float*)lds + (pos >> 1) * (2 * kStageFloats) + (pos & 1); }
+__device__ __forceinline__ void stage_splat(float4* lds, uint32_t pos, const float4& m, const float4& co, const float4& cd, uint32_t g, uint32_t slot) {
+  const Shape sh = stage_shape(m.x, m.y, co.x, co.y, co.z, co.w);
+  float* f = staged_at(lds, pos);
+  f[0] = sh.mx; f[2] = sh.my; f[4] = sh.A; f[6] = sh.B; f[8] = sh.C; f[10] = sh.op; f[12] = cd.w; f[14] = __uint_as_float(g);
+  f[16] = cd.x; f[18] = cd.y; f[20] = cd.z; f[22] = sh.nthr; f[24] = __uint_as_float(slot);
+}
+// fused kernel, list of one chunk (98 % of the tiles of a SLAM view): the staging area still holds every splat of the tile: no second
+// gather from HBM
 struct SrcStaged {
   const float* lds;
   __device__ __forceinline__ SplatRec load(int idx, const LOff&) const {
-    const float* f = lds + (idx >> 1) * 24 + (idx & 1);
+    const float* f = lds + (idx >> 1) * (2 * kStageFloats) + (idx & 1);
     SplatRec s;
     s.mx = f[0]; s.my = f[2]; s.A = f[4]; s.B = f[6]; s.C = f[8]; s.op = f[10]; s.dep = f[12];
-    s.r = f[16]; s.g = f[18]; s.b = f[20]; s.slot = __float_as_uint(f[22]);
+    s.r = f[16]; s.g = f[18]; s.b = f[20]; s.nthr = f[22]; s.slot = __float_as_uint(f[24]);
     return s;
   }
 };
@@ -332,12 +365,21 @@ struct SrcStaged {
 // One chunk = the list positions [start, start + GW) (those below `end`) against the 64 pixels of the tile, 2*64/GW pixels
 // per iteration.  Lanes are mapped to splats in REVERSE list order inside their group, so "everything behind me" is a prefix
 // scan.  Chunks run back to front; `carry`: more (nearer) chunks follow, leave (T, S) in front of this chunk per pixel.
-// LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | x0,y, nc0,nc1) for pair g.
+// LDS: pixA2[g] = (dCr0,dCr1, dCg0,dCg1 | dCb0,dCb1, dD0,dD1), pixB2[g] = (T0,T1, S0,S1 | -,-, nc0,nc1) for pair g.
+//
+// Round 6: the loop runs ROW by row of the tile.  Pixel pair g sits in row g / 4 at x = 2 (g % 4): a lane of a 64-wide chunk meets the
+// four pairs of a row one after the other (32 lanes: two), so everything that only depends on the row -- dy, B' dy, C' dy^2 and the
+// three gradient sums that carry a factor dy (sum G dL/dG dy, ... dx dy, ... dy^2 = dy * or dy^2 * a ROW's sum of G dL/dG (dx)) -- is
+// formed once per row, and the lane's dx against its (at most four) pair columns once per CHUNK; the coordinates come from the
+// tile's position, not from LDS.  80 -> 66 instructions per iteration at 64 lanes.
 template <int GW, typename SRC, bool STASH = false>
 __device__ __forceinline__ void bwd_chunk2(
-    int lane, int start, int end, bool carry, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
-    const LOff& L, float4* __restrict__ partials, const float* stash = nullptr /*LDS: exp(power) of the forward walk, see blend_fwd_kernel*/) {
-  constexpr int PP = kWave / GW;                 // pixel pairs processed per iteration
+    int lane, int start, int end, bool carry, int tx, int ty, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
+    const LOff& L, float4* __restrict__ partials, const float* stash = nullptr /*LDS: exp2(-npow) of the forward walk, see blend_fwd_kernel*/) {
+  constexpr int PP = kWave / GW;                 // pixel pairs the wave works on at once
+  constexpr int KPR = PP >= 4 ? 1 : 4 / PP;      // pairs of one row that ONE lane meets (64 lanes: 4, 32: 2, narrower: 1)
+  constexpr int KST = PP >= 4 ? 0 : PP;          // ... their distance in pair columns
+  constexpr int RPO = PP >= 4 ? PP / 4 : 1;      // rows the wave covers per outer iteration (8 lanes: 2, 4 lanes: 4)
   // (opaque to the optimiser: the five instantiations sit in one loop, and hoisting each one's lane arithmetic out of it
   //  cost more live registers than the kernel has at 5 waves per SIMD -- they were spilled to scratch: +37 MB of writes per launch)
   asm volatile("" : "+v"(lane));
@@ -346,11 +388,11 @@ __device__ __forceinline__ void bwd_chunk2(
   const int sl = GW < 16 ? (lane & 15) / GPR : lane % GW;                            // its position inside its group
   int idx = start + (GW - 1 - sl);               // list position of this lane's splat
   const bool valid = idx < end;
-  float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
+  float mx = 0.f, my = 0.f, A = 0.f, B = 0.f, Cc = 0.f, op = 0.f, nthr = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
   uint32_t slot = 0xffffffffu;                   // this (tile, Gaussian) pair's slot inside the Gaussian's run of partials
   if (valid) {
     const SplatRec sr = src.load(idx, L);
-    mx = sr.mx; my = sr.my; A = sr.A; B = sr.B; Cc = sr.C; op = sr.op; cr = sr.r; cg = sr.g; cb = sr.b; dep = sr.dep; slot = sr.slot;
+    mx = sr.mx; my = sr.my; A = sr.A; B = sr.B; Cc = sr.C; op = sr.op; nthr = sr.nthr; cr = sr.r; cg = sr.g; cb = sr.b; dep = sr.dep; slot = sr.slot;
   }
   const float* my_stash = STASH ? stash + (valid ? idx : start) * kStashStride : nullptr;
   if (!valid) idx = 0x7fffffff;                  // (an empty lane is behind every pixel's last contributor: `idx < nc` rejects it)
@@ -358,78 +400,121 @@ __device__ __forceinline__ void bwd_chunk2(
   asm("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0\n\t"
       "v_mov_b64 %5, 0\n\tv_mov_b64 %6, 0\n\tv_mov_b64 %7, 0\n\tv_mov_b64 %8, 0\n\tv_mov_b64 %9, 0"
       : "=v"(s_gx), "=v"(s_gy), "=v"(s_gxx), "=v"(s_gxy), "=v"(s_gyy), "=v"(a_o), "=v"(a_r), "=v"(a_g), "=v"(a_b), "=v"(a_d));
+  // this lane's pair columns: x of the pair's first pixel = 8 tx + 2 (column); both pixels of a pair share the row.  Narrow chunks keep
+  // dx = mx - x of their one or two columns in registers for the whole chunk; a 64-wide chunk meets all four columns, which are the same
+  // for every lane: their x live in SGPRs (eight VGPRs of dx put the fused kernel over its 96) and dx is ONE packed subtract per pair
+  const int k0 = sub & 3, row0 = sub >> 2;
+  v2f dxs[KPR];
+  float xs0[KPR], xs1[KPR];
+#pragma unroll
+  for (int h = 0; h < KPR; ++h) {
+    const float xf = (float)(tx * kTile + 2 * (k0 + h * KST));
+    if constexpr (GW == kWave) {
+      xs0[h] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xf)));
+      xs1[h] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xf + 1.f)));
+    } else {
+      dxs[h] = splat2(mx) - (v2f){xf, xf + 1.f};   // (the forward walk's subtraction: both sides are exact integers up to here)
+    }
+  }
+  // rows none of whose pixels has a contributor inside or behind this chunk need no work (a 64-wide chunk of a long list only: the
+  // far end of a list is behind the last contributor of most pixels once a tile saturates); one LDS read + compare per CHUNK
+  unsigned long long live = ~0ull;
+  if (GW == kWave) {
+    const int nc_mine = __float_as_int(((const float*)pixB2)[(lane >> 1) * 8 + 6 + (lane & 1)]);
+    live = __builtin_amdgcn_ballot_w64(nc_mine > start);
+  }
+  const int gp0 = row0 * 4 + k0;                 // this lane's pair in the wave's first outer iteration
+  float yf = (float)(ty * kTile + row0);
 
 #pragma unroll 1
-  for (int it = 0; it < 32 / PP; ++it) {
-    const int gp = it * PP + sub;                // this lane's pixel pair (same for the whole group)
-    const float4 a0 = pixA2[gp * 2], a1 = pixA2[gp * 2 + 1];     // LDS, broadcast inside the group
-    const float4 b0 = pixB2[gp * 2];
-    float4 b1 = pixB2[gp * 2 + 1];
-    asm volatile("" : "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));      // (one ds_read_b128: the compiler split it into three reads)
-    const int nc0 = __float_as_int(b1.z), nc1 = __float_as_int(b1.w);
-    if (GW == kWave && __builtin_amdgcn_readfirstlane(max(nc0, nc1)) <= start) continue;   // both ended before this chunk
-    // pixels 2 gp, 2 gp + 1 (same row): their coordinates were staged with the pixel state (b1.x = x of the first, b1.y = y; both
-    // exact integers) -- rebuilding them from gp cost 8 of an iteration's instructions.  x sits in the EVEN register of the read and
-    // y is consumed first, so the pair (x, x + 1) forms in place: with (nc0, nc1, x, y) the compiler moved three registers around
-    const v2f dy = splat2(my) - splat2(b1.y);
-    const v2f dx = splat2(mx) - (v2f){b1.x, b1.x + 1.f};
-    v2f G, power = {0.f, 0.f};
-    if constexpr (STASH) {
-      const float2 gs = *(const float2*)(my_stash + 2 * gp);     // what the forward walk computed for these two pixels (-1: power > 0)
-      G = (v2f){gs.x, gs.y};
-    } else {
-      // the forward walk's footprint evaluation on the pair, same operation order
-      const v2f adx = splat2(A) * dx;
-      const v2f cdy2 = (splat2(Cc) * dy) * dy;
-      const v2f qf = __builtin_elementwise_fma(adx, dx, cdy2);
-      const v2f bdxdy = (splat2(B) * dx) * dy;
-      power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
-      G = (v2f){exp2_fast(power.x), exp2_fast(power.y)};         // (the conic carries log2(e))
+  for (int o = 0; o < kTile / RPO; ++o, yf += (float)RPO) {
+    if (GW == kWave && ((live >> (8 * o)) & 0xffull) == 0ull) continue;
+    const float dy = my - yf;
+    const float Bdy = B * dy, Cdy2 = (Cc * dy) * dy, dysq = dy * dy;
+    v2f r_gg = {0.f, 0.f}, r_gx = {0.f, 0.f};    // the row's sums of G dL/dG and G dL/dG dx (KPR > 1)
+#pragma unroll
+    for (int h = 0; h < KPR; ++h) {
+      // (the unrolled pairs of a row stay one after the other: left alone, the scheduler moves the LDS reads of all four to the top and
+      //  the kernel spills ~200 registers)
+      if constexpr (KPR > 1) __builtin_amdgcn_sched_barrier(0);
+      const int gp = o * (RPO * 4) + gp0 + h * KST;      // this lane's pixel pair (same for the whole group)
+      const float4 a0 = pixA2[gp * 2], a1 = pixA2[gp * 2 + 1];     // LDS, broadcast inside the group
+      const float4 b0 = pixB2[gp * 2];
+      const int2 ncp = *(const int2*)((const float*)(pixB2 + gp * 2 + 1) + 2);
+      const int nc0 = ncp.x, nc1 = ncp.y;
+      v2f dx;
+      if constexpr (GW == kWave) dx = splat2(mx) - (v2f){xs0[h], xs1[h]};
+      else dx = dxs[h];
+      v2f G;
+      bool ok0 = idx < nc0, ok1 = idx < nc1;
+      if constexpr (STASH) {
+        const float2 gs = *(const float2*)(my_stash + 2 * gp);     // what the forward walk computed for these two pixels (0: outside the footprint)
+        G = (v2f){gs.x, gs.y};
+      } else {
+        // the forward walk's footprint evaluation on the pair, same operation order
+        const v2f u = __builtin_elementwise_fma(splat2(A), dx, splat2(Bdy));
+        const v2f npow = __builtin_elementwise_fma(u, dx, splat2(Cdy2));
+        G = (v2f){exp2_fast(-npow.x), exp2_fast(-npow.y)};
+        ok0 = ok0 && in_footprint(npow.x, nthr);
+        ok1 = ok1 && in_footprint(npow.y, nthr);
+      }
+      v2f og = splat2(op) * G;
+      // a pair that does not contribute takes part with opacity * G = 0: alpha = 0 (factor 1 in the product, weight 0 in the sums) and
+      // G dL/dG = 0 -- ONE select per pixel masks everything downstream
+      og.x = ok0 ? og.x : 0.f;
+      og.y = ok1 ? og.y : 0.f;
+      static_assert(kAlphaMax == 0.99f, "the literal 0x3f7d70a4 below is 0.99f");
+      v2f alpha;                                           // min(0.99, og) (as asm: behind a select fminf() first canonicalises its operand)
+      asm("v_min_f32 %0, 0x3f7d70a4, %2\n\tv_min_f32 %1, 0x3f7d70a4, %3" : "=&v"(alpha.x), "=v"(alpha.y) : "v"(og.x), "v"(og.y));
+      const v2f one_m = splat2(1.f) - alpha;
+      float P0 = one_m.x, P1 = one_m.y;
+      group_scan_mul2<GW>(P0, P1);                         // prod over this splat and all behind it (in chunk)
+      const v2f rP = {__builtin_amdgcn_rcpf(P0), __builtin_amdgcn_rcpf(P1)};
+      const v2f Tj = (v2f){b0.x, b0.y} * rP;               // transmittance in front of splat j
+      const v2f inv1ma = prev_times<GW>(P0, P1, rP, lane); // 1 / (1 - alpha_j) = (prod over all strictly behind it) / (prod incl. it)
+      const v2f dCr = {a0.x, a0.y}, dCg = {a0.z, a0.w}, dCb = {a1.x, a1.y}, dD = {a1.z, a1.w};
+      const v2f w = __builtin_elementwise_fma(dCr, splat2(cr), __builtin_elementwise_fma(dCg, splat2(cg),
+                    __builtin_elementwise_fma(dCb, splat2(cb), dD * splat2(dep))));
+      const v2f aT = alpha * Tj;                           // (Tj is finite: the product only spans contributing splats)
+      const v2f q = w * aT;
+      float Q0 = q.x, Q1 = q.y;
+      group_scan_add2<GW>(Q0, Q1);                         // inclusive: this splat and all behind it
+      const v2f Sc = {b0.z, b0.w};
+      const v2f Sx = prev_plus<GW>(Q0, Q1, Sc, lane);      // strictly behind (+ carried chunks + background term)
+      const v2f dL_dalpha = __builtin_elementwise_fma(Tj, w, -(Sx * inv1ma));
+      if (carry && sl == GW - 1) {
+        // carry to the next (nearer) chunk: the last lane of the group holds the nearest splat of this chunk
+        const v2f S2 = (v2f){Q0, Q1} + Sc;
+        pixB2[gp * 2] = make_float4(Tj.x, Tj.y, S2.x, S2.y);
+      }
+      a_r = __builtin_elementwise_fma(aT, dCr, a_r);
+      a_g = __builtin_elementwise_fma(aT, dCg, a_g);
+      a_b = __builtin_elementwise_fma(aT, dCb, a_b);
+      a_d = __builtin_elementwise_fma(aT, dD, a_d);
+      const v2f gg = og * dL_dalpha;                       // G * dL/dG = opacity * G * dL/dalpha (the alpha clamp is straight-through)
+      const v2f gxv = gg * dx;
+      s_gxx = __builtin_elementwise_fma(gxv, dx, s_gxx);
+      if constexpr (KPR > 1) {
+        r_gg = h == 0 ? gg : r_gg + gg;
+        r_gx = h == 0 ? gxv : r_gx + gxv;
+        // (pins this pair's seven accumulations HERE: the optimiser otherwise sinks the sums of all unrolled pairs of the row behind the
+        //  last one -- everything they read stays live across the row: 137 VGPRs)
+        asm volatile("" : "+v"(a_r), "+v"(a_g), "+v"(a_b), "+v"(a_d), "+v"(s_gxx), "+v"(r_gg), "+v"(r_gx));
+      } else {
+        a_o += gg;                                         // dL/dopacity = sum G dL/dalpha = (this sum) / opacity, divided once after the loop
+        s_gx += gxv;
+        s_gy = __builtin_elementwise_fma(gg, splat2(dy), s_gy);
+        s_gxy = __builtin_elementwise_fma(gxv, splat2(dy), s_gxy);
+        s_gyy = __builtin_elementwise_fma(gg, splat2(dysq), s_gyy);
+      }
     }
-    v2f og = splat2(op) * G;
-    // (alpha = min(0.99, og) >= 1/255  <=>  og >= 1/255: the test does not wait for the clamp; a stashed -1 fails it for power > 0)
-    const bool ok0 = (idx < nc0) && (STASH || power.x <= 0.0f) && (og.x >= kAlphaMin);
-    const bool ok1 = (idx < nc1) && (STASH || power.y <= 0.0f) && (og.y >= kAlphaMin);
-    // a pair that does not contribute takes part with opacity * G = 0: alpha = 0 (factor 1 in the product, weight 0 in the sums) and
-    // G dL/dG = 0 -- ONE select per pixel masks everything downstream
-    og.x = ok0 ? og.x : 0.f;
-    og.y = ok1 ? og.y : 0.f;
-    static_assert(kAlphaMax == 0.99f, "the literal 0x3f7d70a4 below is 0.99f");
-    v2f alpha;                                           // min(0.99, og) (as asm: behind a select fminf() first canonicalises its operand)
-    asm("v_min_f32 %0, 0x3f7d70a4, %2\n\tv_min_f32 %1, 0x3f7d70a4, %3" : "=&v"(alpha.x), "=v"(alpha.y) : "v"(og.x), "v"(og.y));
-    const v2f one_m = splat2(1.f) - alpha;
-    float P0 = one_m.x, P1 = one_m.y;
-    group_scan_mul2<GW>(P0, P1);                         // prod over this splat and all behind it (in chunk)
-    const v2f rP = {__builtin_amdgcn_rcpf(P0), __builtin_amdgcn_rcpf(P1)};
-    const v2f Tj = (v2f){b0.x, b0.y} * rP;               // transmittance in front of splat j
-    const v2f inv1ma = prev_times<GW>(P0, P1, rP, lane); // 1 / (1 - alpha_j) = (prod over all strictly behind it) / (prod incl. it)
-    const v2f dCr = {a0.x, a0.y}, dCg = {a0.z, a0.w}, dCb = {a1.x, a1.y}, dD = {a1.z, a1.w};
-    const v2f w = __builtin_elementwise_fma(dCr, splat2(cr), __builtin_elementwise_fma(dCg, splat2(cg),
-                  __builtin_elementwise_fma(dCb, splat2(cb), dD * splat2(dep))));
-    const v2f aT = alpha * Tj;                           // (Tj is finite: the product only spans contributing splats)
-    const v2f q = w * aT;
-    float Q0 = q.x, Q1 = q.y;
-    group_scan_add2<GW>(Q0, Q1);                         // inclusive: this splat and all behind it
-    const v2f Sc = {b0.z, b0.w};
-    const v2f Sx = prev_plus<GW>(Q0, Q1, Sc, lane);      // strictly behind (+ carried chunks + background term)
-    const v2f dL_dalpha = __builtin_elementwise_fma(Tj, w, -(Sx * inv1ma));
-    if (carry && sl == GW - 1) {
-      // carry to the next (nearer) chunk: the last lane of the group holds the nearest splat of this chunk
-      const v2f S2 = (v2f){Q0, Q1} + Sc;
-      pixB2[gp * 2] = make_float4(Tj.x, Tj.y, S2.x, S2.y);
+    if constexpr (KPR > 1) {
+      a_o += r_gg;
+      s_gx += r_gx;
+      s_gy = __builtin_elementwise_fma(r_gg, splat2(dy), s_gy);
+      s_gxy = __builtin_elementwise_fma(r_gx, splat2(dy), s_gxy);
+      s_gyy = __builtin_elementwise_fma(r_gg, splat2(dysq), s_gyy);
     }
-    a_r = __builtin_elementwise_fma(aT, dCr, a_r);
-    a_g = __builtin_elementwise_fma(aT, dCg, a_g);
-    a_b = __builtin_elementwise_fma(aT, dCb, a_b);
-    a_d = __builtin_elementwise_fma(aT, dD, a_d);
-    const v2f gg = og * dL_dalpha;                       // G * dL/dG = opacity * G * dL/dalpha (the alpha clamp is straight-through)
-    a_o += gg;                                           // dL/dopacity = sum G dL/dalpha = (this sum) / opacity, divided once after the loop
-    const v2f gxv = gg * dx, gyv = gg * dy;
-    s_gx += gxv;
-    s_gy += gyv;
-    s_gxx = __builtin_elementwise_fma(gxv, dx, s_gxx);
-    s_gxy = __builtin_elementwise_fma(gxv, dy, s_gxy);
-    s_gyy = __builtin_elementwise_fma(gyv, dy, s_gyy);
   }
   float t_gx = s_gx.x + s_gx.y, t_gy = s_gy.x + s_gy.y, t_gxx = s_gxx.x + s_gxx.y, t_gxy = s_gxy.x + s_gxy.y,
         t_gyy = s_gyy.x + s_gyy.y, t_o = (a_o.x + a_o.y) * (op > 0.f ? __builtin_amdgcn_rcpf(op) : 0.f), t_r = a_r.x + a_r.y,
@@ -510,7 +595,6 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
     float* fb = (float*)pixB + (lane >> 1) * 8 + (lane & 1);
     fa[0] = pxA[0]; fa[2] = pxA[1]; fa[4] = pxA[2]; fa[6] = pxA[3];
     fb[0] = pxB[0]; fb[2] = pxB[1]; fb[6] = pxB[2];
-    fb[4] = (lane & 1) ? (float)(ty * kTile + (lane >> 3)) : (float)(tx * kTile + (lane & 7));     // the pair's x0 | y
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -526,9 +610,9 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
     const bool carry = start > 0;
     if constexpr (std::is_same<SRC, SrcStaged>::value) {
       if (stash) {            // (a list of <= kStash splats: chunks of 16 / 8 / 4 only)
-        if (gw == 16) bwd_chunk2<16, SRC, true>(lane, start, end, carry, pixA, pixB, src, L, partials, stash);
-        else if (gw == 8) bwd_chunk2<8, SRC, true>(lane, start, end, carry, pixA, pixB, src, L, partials, stash);
-        else bwd_chunk2<4, SRC, true>(lane, start, end, carry, pixA, pixB, src, L, partials, stash);
+        if (gw == 16) bwd_chunk2<16, SRC, true>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials, stash);
+        else if (gw == 8) bwd_chunk2<8, SRC, true>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials, stash);
+        else bwd_chunk2<4, SRC, true>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials, stash);
         end = start;
         if (carry) {
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -537,11 +621,11 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
         continue;
       }
     }
-    if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, pixA, pixB, src, L, partials);
-    else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, pixA, pixB, src, L, partials);
-    else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, pixA, pixB, src, L, partials);
-    else if (gw == 8) bwd_chunk2<8>(lane, start, end, carry, pixA, pixB, src, L, partials);
-    else bwd_chunk2<4>(lane, start, end, carry, pixA, pixB, src, L, partials);
+    if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
+    else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
+    else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
+    else if (gw == 8) bwd_chunk2<8>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
+    else bwd_chunk2<4>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
     end = start;
     if (carry) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -625,7 +709,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   float2* __restrict__ pix_state = (float2*)(saved + L.o_final_T);
   uint32_t* __restrict__ tile_maxc = (uint32_t*)(saved + L.o_tile_maxc);
   int32_t* __restrict__ n_touched = tab.n_touched[vw];
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // SORT_MAX sorted ids (4 B) or keys (8 B) + 64 splats x 48 B (+ FUSED: 2 x 64 float4 of pixel state)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // SORT_MAX sorted ids (4 B) or keys (8 B) + 64 splats x kStageBytes (+ FUSED: 2 x 64 float4 of pixel state)
   constexpr bool REGSORT = sort_in_registers(SORT_MAX);
   constexpr size_t kKeyBytes = REGSORT ? 4 : 8;
   const int ncomp = comp_blocks(L);             // the first blocks of the launch: the view's compact visible list (see above)
@@ -640,16 +724,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  float4* lds = (float4*)slice;                              // 64 staged splats x 48 B
-  uint64_t* keys = (uint64_t*)(slice + kWave * 48);          // mid / heavy build: the keys, sorted in place
-  uint32_t* ids = (uint32_t*)(slice + kWave * 48);           // light build: sorted Gaussian indices (the keys were sorted in registers)
-  // G stash (fused kernel, lists of <= kStash splats -- three quarters of a SLAM view's tiles): such a list is staged in the first 864
-  // bytes and never uses the sorted-index area, so the 4.2 KB behind it hold exp(power) of every (splat, pixel) pair the forward
-  // walk evaluates (row = list position, kStashStride floats apart: rows two banks apart, conflict-free 8-byte reads of a group's
-  // pixel pair), with -1 where power > 0.  The backward reads it back instead of re-evaluating the quadratic form, the exponential and
-  // the sign test: 11 of the ~76 instructions of an iteration.  The same bits the backward would recompute: results unchanged.
+  float4* lds = (float4*)slice;                              // 64 staged splats x kStageBytes
+  uint64_t* keys = (uint64_t*)(slice + kWave * kStageBytes);          // mid / heavy build: the keys, sorted in place
+  uint32_t* ids = (uint32_t*)(slice + kWave * kStageBytes);           // light build: sorted Gaussian indices (the keys were sorted in registers)
+  // G stash (fused kernel, lists of <= kStash splats -- three quarters of a SLAM view's tiles): such a list is staged in the first
+  // kStashOffset bytes and never uses the sorted-index area, so the 4.2 KB behind it hold exp2(-npow) of every (splat, pixel) pair the
+  // forward walk evaluates (row = list position, kStashStride floats apart: rows two banks apart, conflict-free 8-byte reads of a
+  // group's pixel pair), with 0 where the pixel is outside the splat's footprint (in_footprint()).  The backward reads it back instead
+  // of re-evaluating the quadratic form, the exponential and the footprint test.  The same bits the backward would recompute: results
+  // unchanged.
   float* stash = (float*)(slice + kStashOffset);
-  static_assert(!FUSED || kStashOffset + kStash * kStashStride * 4 <= kWave * 48 + SORT_MAX * kKeyBytes, "the stash overlays unused staging + index space");
+  static_assert(!FUSED || kStashOffset + kStash * kStashStride * 4 <= kWave * kStageBytes + SORT_MAX * kKeyBytes, "the stash overlays unused staging + index space");
 
   // ground truth of the fused loss epilogue: fetched NOW so that the round trip hides behind sorting and blending
   const float* __restrict__ gt_image = lt.gt_image[vw];
@@ -718,13 +803,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
     }
     if (lane >= count) rank = (uint32_t)lane;        // lane == count files the zero splat that pads an odd list
     if (!FUSED && lane < count) point_list[begin + rank] = g;      // (the fused backward reads the staged records instead)
-    if (lane <= count) {
-      float* f = (float*)lds + (rank >> 1) * 24 + (rank & 1);
-      f[0] = m.x; f[2] = m.y; f[4] = co.x * kLog2e; f[6] = co.y * kLog2e;
-      f[8] = co.z * kLog2e; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
-      f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
-      if (FUSED) f[22] = __uint_as_float(slot);
-    }
+    if (lane <= count) stage_splat(lds, rank, m, co, cd, g, slot);
   } else if (REGSORT && count <= kLdsSortMax) {
     mode = 1;                                 // 65..512 keys: sorted in registers, 2 / 4 / 8 per lane (count > 64: keys_in = the tile's run)
     if (count <= 2 * kWave) wave_sort_registers<2>(bucket, entries + begin, count, lane, ids);
@@ -765,7 +844,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   // moves per trip less than tracking the index itself
   uint32_t last_trip = 0;
   unsigned long long last_first_m = 0ull;
-  uint32_t mx_trip = 0, mx_second = 0;        // the same for the whole tile (its maximum over the pixels), kept by the scalar unit
+  uint32_t mx_trip = 0;                       // the same for the whole tile (its maximum over the pixels), kept by the scalar unit
+  unsigned long long mx_second_m = 0ull;
   unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside || (L.dbg & 2048));      // finished pixels, one bit per lane (bit 11 of SGR_DEBUG, EXPERIMENT: no walk, no backward -- what the rest of a tile's wave costs)
   const v2f px2 = splat2(pxf), py2 = splat2(pyf);
 
@@ -785,10 +865,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         co = rec[1];
         cd = rec[2];
       }
-      float* f = (float*)lds + (lane >> 1) * 24 + (lane & 1);
-      f[0] = m.x; f[2] = m.y; f[4] = co.x * kLog2e; f[6] = co.y * kLog2e;
-      f[8] = co.z * kLog2e; f[10] = co.w; f[12] = cd.w; f[14] = __uint_as_float(g);
-      f[16] = cd.x; f[18] = cd.y; f[20] = cd.z;
+      stage_splat(lds, (uint32_t)lane, m, co, cd, g, 0xffffffffu);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -799,26 +876,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
 #pragma clang fp contract(off)      // the two instantiations must round alike (T * (1 - alpha) is not to become an fma in one)
       for (int j = 0; j < n; j += 2) {
         if ((j & 3) == 0 && ~done_m == 0ull) break;
-        const float4* e = lds + (j >> 1) * 6;
-        const float4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4];
-        const float2 q5 = *(const float2*)&e[5];
+        const float4* e = lds + (j >> 1) * (kStageFloats / 2);
+        const float4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4], q5 = e[5];
         const v2f dx = (v2f){q0.x, q0.y} - px2, dy = (v2f){q0.z, q0.w} - py2;
-        const v2f qf = __builtin_elementwise_fma((v2f){q1.x, q1.y} * dx, dx, ((v2f){q2.x, q2.y} * dy) * dy);
-        const v2f bdxdy = ((v2f){q1.z, q1.w} * dx) * dy;
-        const v2f power = __builtin_elementwise_fma(splat2(-0.5f), qf, -bdxdy);
-        const v2f G = {exp2_fast(power.x), exp2_fast(power.y)};      // (the staged conic carries log2(e))
+        // npow = dx (A' dx + B' dy) + (C' dy) dy  (stage_shape(); the backward evaluates the same operation sequence)
+        const v2f u = __builtin_elementwise_fma((v2f){q1.x, q1.y}, dx, (v2f){q1.z, q1.w} * dy);
+        const v2f npow = __builtin_elementwise_fma(u, dx, ((v2f){q2.x, q2.y} * dy) * dy);
+        const v2f G = {exp2_fast(-npow.x), exp2_fast(-npow.y)};
+        // Who contributes is decided on wave masks in SGPRs (every lane of the wave is active here: a ballot is the whole comparison):
+        // the and / andn2 / or of the termination logic are scalar instructions.  ONE integer compare per (pixel, splat): in_footprint()
+        const unsigned long long ok0 = __builtin_amdgcn_ballot_w64(in_footprint(npow.x, q5.z));
+        const unsigned long long ok1 = __builtin_amdgcn_ballot_w64(in_footprint(npow.y, q5.w));
         if (decltype(stash_g)::value) {
           float* sp = stash + j * kStashStride + lane;
-          sp[0] = power.x <= 0.0f ? G.x : -1.f;
-          sp[kStashStride] = power.y <= 0.0f ? G.y : -1.f;
+          sp[0] = __builtin_amdgcn_inverse_ballot_w64(ok0) ? G.x : 0.f;
+          sp[kStashStride] = __builtin_amdgcn_inverse_ballot_w64(ok1) ? G.y : 0.f;
         }
         const v2f og = (v2f){q2.z, q2.w} * G;
         const v2f alpha = {fminf(kAlphaMax, og.x), fminf(kAlphaMax, og.y)};
-        // Who contributes is decided on wave masks in SGPRs (every lane of the wave is active here: a ballot is the whole comparison):
-        // the and / andn2 / or of the termination logic are scalar instructions, and the compiler no longer issues the
-        // complement of a floating-point compare as a second compare.  (<=> alpha >= 1/255; the backward tests the same value)
-        const unsigned long long ok0 = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(og.x >= kAlphaMin);
-        const unsigned long long ok1 = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(og.y >= kAlphaMin);
         const v2f one_m = splat2(1.f) - alpha;
         const float test0 = T * one_m.x;
         const unsigned long long live0 = ok0 & ~done_m, lt0 = __builtin_amdgcn_ballot_w64(test0 < kTEps);
@@ -848,7 +923,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
         const unsigned long long any_m = comp0_m | comp1_m;
         last_trip = __builtin_amdgcn_inverse_ballot_w64(any_m) ? (uint32_t)(((base + j) >> 1) + 1) : last_trip;
         last_first_m = (last_first_m & ~any_m) | (comp0_m & ~comp1_m);
-        if (any_m != 0ull) { mx_trip = (uint32_t)(((base + j) >> 1) + 1); mx_second = comp1_m != 0ull ? 1u : 0u; }
+        // (the whole-tile maximum stays on the scalar unit: the trip and the second splat's MASK are selected, the mask is tested once
+        //  after the walk -- `comp1_m != 0 ? 1 : 0` inside the loop came out as v_cndmask + v_readfirstlane per trip)
+        if (any_m != 0ull) { mx_trip = (uint32_t)(((base + j) >> 1) + 1); mx_second_m = comp1_m; }
       }
     };
     if (n_touched) walk(std::true_type{}, std::false_type{});
@@ -861,7 +938,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const uint32_t last = 2u * last_trip - (__builtin_amdgcn_inverse_ballot_w64(last_first_m) ? 1u : 0u);      // (no contributor: 0; the mask bit is then clear)
 
   // per-tile bound for the backward: it never has to look past the last contributor of any pixel
-  const uint32_t mx = mx_trip ? 2u * mx_trip - 1u + mx_second : 0u;       // = the maximum of `last` over the wave
+  const uint32_t mx = mx_trip ? 2u * mx_trip - 1u + (mx_second_m != 0ull ? 1u : 0u) : 0u;       // = the maximum of `last` over the wave
   if (lane == 0) tile_maxc[tile] = mx;
 
   float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;
@@ -923,7 +1000,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   float4* __restrict__ partials = (float4*)(tab.scratch[vw] + L.o_partials);
   // pairs the walk never reached (behind every pixel's last contributor) still own a slot: define it as zero
   float pxB[3] = {T, 0.f, __uint_as_float(last)};
-  float4* pixA = (float4*)(slice + (size_t)SORT_MAX * kKeyBytes + kWave * 48);
+  float4* pixA = (float4*)(slice + (size_t)SORT_MAX * kKeyBytes + kWave * kStageBytes);
   float4* pixB = pixA + kWave;
   if (mode == 0) {
     const SrcStaged src = {(const float*)lds};
@@ -1023,7 +1100,7 @@ template <int SORT_MAX, bool FUSED>
 static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab& lt,
                                const LossCoef& lc, hipStream_t st) {
   int grid = 8 * 4 * ((L.sgx * L.sgy + 7) / 8) + ((((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7);
-  constexpr size_t lds = (size_t)SORT_MAX * (sort_in_registers(SORT_MAX) ? 4 : 8) + kWave * 48 + (FUSED ? 2 * kWave * 16 : 0);
+  constexpr size_t lds = (size_t)SORT_MAX * (sort_in_registers(SORT_MAX) ? 4 : 8) + kWave * kStageBytes + (FUSED ? 2 * kWave * 16 : 0);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

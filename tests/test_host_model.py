@@ -246,13 +246,14 @@ def test_tile_of_block_is_a_bijection_and_its_division_is_exact():
 
 
 def test_g_stash_fits_the_unused_part_of_the_wave_slice():
-    """csrc/sgr_blend.hip: a list of <= 16 splats is staged pair-interleaved (96 bytes per pair, an odd list padded by one splat) in the
-    first 864 bytes of the wave's LDS slice; the stash (16 rows of 64 pixels, 66 floats apart) must end before the pixel state that
-    follows the staging (64 x 48 B) and sorted-index (512 x 4 B) areas, and a row stride of 66 floats keeps the 16 lanes of a group on
-    distinct bank pairs for their 8-byte reads."""
-    staging = ((16 >> 1) + 1) * 96
-    assert staging == 864
-    assert staging + 16 * 66 * 4 <= 64 * 48 + 512 * 4
+    """csrc/sgr_blend.hip: a list of <= 16 splats is staged pair-interleaved (14 floats per splat = 112 bytes per pair, an odd list
+    padded by one splat) in the first 1008 bytes of the wave's LDS slice; the stash (16 rows of 64 pixels, 66 floats apart) must end
+    before the pixel state that follows the staging (64 x 56 B) and sorted-index (512 x 4 B) areas, and a row stride of 66 floats keeps
+    the 16 lanes of a group on distinct bank pairs for their 8-byte reads."""
+    staging = ((16 >> 1) + 1) * 112
+    assert staging == 1008
+    assert staging + 16 * 66 * 4 <= 64 * 56 + 512 * 4
+    assert 512 * 4 + 64 * 56 + 2 * 64 * 16 == 7680 and 160 * 1024 // 7680 >= 20          # the slice still leaves 5 waves per SIMD resident
     for gp in range(32):
         banks = set()
         for idx in range(16):

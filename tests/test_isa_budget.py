@@ -36,30 +36,30 @@ def _valu(block):
 
 
 def _loops(lines):
-    """(instructions, has v_rcp, has v_exp) of every innermost loop body that evaluates splats."""
+    """Every innermost loop of the kernel as a dict of counts: all blocks the assembler tags with the loop's header label."""
     out = []
     for h, l in enumerate(lines):
-        if "Inner Loop Header: Depth=2" not in l:
+        if "Inner Loop Header" not in l:
             continue
         label = None
-        for k in range(h, max(h - 4, 0), -1):
+        for k in range(h, max(h - 3, 0), -1):
             m = re.match(r"(\.LBB\d+_\d+):", lines[k])
             if m:
                 label = m.group(1)
                 break
         if label is None:
             continue
-        # the body = from the block that branches (s_branch) to the header up to the loop's last back edge
-        s = h
-        while s > h - 80 and s > 0 and not re.match(r"\s+s_branch\s+" + re.escape(label) + r"\s*$", lines[s]):
-            s -= 1
-        if not re.match(r"\s+s_branch\s+" + re.escape(label) + r"\s*$", lines[s]):
-            continue                              # (not the rotated loop shape of the chunk loops)
-        e = h
-        while e < len(lines) - 1 and (not re.match(r"\s+s_c?branch\w*\s+\.LBB", lines[e]) or e < h + 20):
-            e += 1
-        body = lines[s + 1:e + 1]
-        out.append((_valu(body), any("v_rcp_f32" in x for x in body), any("v_exp_f32" in x for x in body)))
+        tag = "Header=" + label.replace(".L", "")
+        body, cur = [], False
+        for x in lines:
+            m = re.match(r"(\.LBB\d+_\d+):", x)
+            if m or x.startswith("; %bb."):
+                cur = (tag in x) or (m is not None and m.group(1) == label)
+            if cur:
+                body.append(x)
+        cnt = lambda pat: sum(1 for x in body if pat in x)
+        out.append(dict(valu=_valu(body), rcp=cnt("v_rcp_f32"), exp=cnt("v_exp_f32"), bcast31=cnt("row_bcast:31"), bcast15=cnt("row_bcast:15"),
+                        shr1=cnt("row_shr:1 "), shr2=cnt("row_shr:2 "), ds_write=cnt("ds_write"), atomic=cnt("global_atomic")))
     return out
 
 
@@ -73,34 +73,32 @@ def test_fused_tile_kernel_keeps_its_registers_and_has_no_scratch(fused_asm):
 
 
 def test_backward_loops_stay_within_their_instruction_budget(fused_asm):
+    """Per (pixel pair x group) iteration.  Round 6 runs the loop row by row: a 64-lane chunk's loop body holds the FOUR pairs of a row
+    (eight v_rcp), a 32-lane chunk's two, the narrower ones one."""
     lines, _, _ = fused_asm
-    loops = _loops(lines)
-    bwd = [n for n, rcp, ex in loops if rcp and ex]            # re-evaluates the footprint: 64 / 32 / 16 / 8 / 4 lanes, two sources
-    stash = [n for n, rcp, ex in loops if rcp and not ex]      # reads exp(power) back from the G stash: 16 / 8 / 4 lanes
-    assert len(bwd) >= 8 and len(stash) >= 3, loops              # (5 widths x 2 sources; the narrowest ones are not always laid out as rotated loops)
-    assert max(bwd) <= 88, sorted(bwd)                         # (round 3: 97; measured at the end of round 4: 81-83 at 64 lanes)
-    assert min(bwd) <= 68, sorted(bwd)                         # (8 lanes: 65)
-    assert max(stash) <= 65, sorted(stash)                     # (16 lanes: 62; 75 without the stash)
+    loops = [l for l in _loops(lines) if l["rcp"]]
+    per_pair = lambda l: l["valu"] / (l["rcp"] / 2)
+    wide = [per_pair(l) for l in loops if l["bcast31"]]                              # 64 lanes (two sources)
+    half = [per_pair(l) for l in loops if l["bcast15"] and not l["bcast31"]]         # 32 lanes
+    narrow = [per_pair(l) for l in loops if not l["bcast15"] and l["exp"]]           # 16 / 8 / 4 lanes, footprint re-evaluated
+    stash = [per_pair(l) for l in loops if not l["exp"]]                             # 16 / 8 / 4 lanes reading the G stash
+    assert len(wide) >= 2 and len(half) >= 2 and len(narrow) >= 6 and len(stash) >= 3, loops
+    assert all(l["rcp"] == 8 for l in loops if l["bcast31"]) and all(l["rcp"] == 4 for l in loops if l["bcast15"] and not l["bcast31"]), loops
+    assert max(wide) <= 70 and min(wide) <= 66, wide           # (round 5: 81-83 at 64 lanes; round 6: 66 -- 264 per row of four pairs; one copy 69.5)
+    assert max(half) <= 73, half                               # (71)
+    assert max(narrow) <= 67 and min(narrow) <= 59, narrow     # (16 lanes: 65 (round 5: 75), 8: 61, 4: 57-58)
+    assert max(stash) <= 59 and min(stash) <= 52, stash        # (16 lanes: 57 (round 5: 62), 8: 53, 4: 50)
 
 
 def test_forward_walk_stays_within_its_instruction_budget(fused_asm):
     lines, _, _ = fused_asm
-    # walk bodies: basic blocks with two v_exp_f32 and no v_rcp_f32 that read the pair-interleaved staging area
-    walks = []
-    for i, l in enumerate(lines):
-        if not re.match(r"\.LBB\d+_\d+:", l):
-            continue
-        j = i + 1
-        while j < len(lines) and not re.match(r"\.LBB\d+_\d+:", lines[j]) and "s_cbranch" not in lines[j]:
-            j += 1
-        block = lines[i:j + 1]
-        if sum("v_exp_f32" in x for x in block) == 2 and not any("v_rcp_f32" in x for x in block) and sum("ds_read_b128" in x for x in block) >= 4:
-            walks.append((_valu(block), any("ds_write" in x for x in block), any("global_atomic" in x for x in block)))
-    plain = [n for n, st, at in walks if not st and not at]
-    stashing = [n for n, st, at in walks if st and not at]
+    # the walks: innermost loops with two v_exp_f32 and no v_rcp_f32 (two splats per trip)
+    walks = [l for l in _loops(lines) if l["exp"] == 2 and not l["rcp"]]
+    plain = [l["valu"] for l in walks if not l["ds_write"] and not l["atomic"]]
+    stashing = [l["valu"] for l in walks if l["ds_write"] and not l["atomic"]]
     assert plain and stashing, walks
-    assert min(plain) <= 37, walks                             # (two splats per trip: 35; 45 in round 3)
-    assert min(stashing) <= 41, walks                          # (+3: the masked exp(power) of both splats goes to the stash)
+    assert min(plain) <= 32, walks                             # (two splats per trip: 31; round 5: 35; 45 in round 3)
+    assert min(stashing) <= 35, walks                          # (+3: the masked exp2(-npow) of both splats goes to the stash)
 
 
 def test_no_v_readlane_in_the_rank_sort(fused_asm):
