@@ -20,6 +20,8 @@ Besides the headline the line carries (all measured in this run, outside the hea
   roofline            the fused tile kernel (forward + loss + backward of a tile in one wave): the dominant kernel of the timed loop
   roofline_unfused_blend_bwd   blend_bwd_kernel<true> -- the north-star kernel -- event-timed with the tile kernels UN-fused
   extra.session       40 tracker frames of the configs[1] session (MappingSession, default hyper-parameters): ms per keyframe, PSNR
+  extra.session_full  the WHOLE configs[1] session (160 tracker frames once around the room): final map size, wall
+                      ms per mapped keyframe / keyframes per s, PSNR over all keyframes, HIP- vs oracle-rendered PSNR of the final map
   dropin_keyframes_per_s   the same map() iteration through the drop-in autograd API (GaussianRasterizer per view, reference
                       loop structure intact, torch.optim.Adam)
   extra.opaque_scene  the same N with log-scale + 1.6: a converged, surface-covering map (long per-tile lists)
@@ -75,9 +77,10 @@ def parse():
     ap.add_argument("--profile-all", action="store_true", help="event-time every kernel kind inside the timed region (adds overhead)")
     ap.add_argument("--refine-views", default="world", help="views per optimiser step of the timed final_refine leg on N > 1 GPUs: "
                     "'world' (one random view per rank and step: configs[4]) or 1 (the reference's step, replicated)")
-    ap.add_argument("--settle", type=int, default=150, help="untimed iterations right after the scene is built, BEFORE the --warmup steps: "
-                    "workspace capacities, list hints, allocator pools and the GPU's clocks reach the state a session is in from its "
-                    "second keyframe on (a 20-step timed region that starts 5 steps after an idle GPU reads 8 %% slower)")
+    ap.add_argument("--settle", type=int, default=0, help="extra untimed iterations right after the scene is built, BEFORE the --warmup steps "
+                    "(rounds 3-5: 150, so that capacities, list hints, allocator pools and the GPU's clocks were settled; round 6: the "
+                    "event-timed roofline legs run before the headline instead and this is 0 -- the line's `warmup` is all the warm-up "
+                    "the headline gets beyond work the line reports anyway, see `iterations_before_timed_region`)")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 --pmc child passes that measure `roofline.traffic` "
                     "(HBM bytes of the dominant kernel, FETCH_SIZE / WRITE_SIZE)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing protocol only, no GPU work (CPU test of --gpus N)")
@@ -130,11 +133,18 @@ def dry_run(args):
 _PMC_BROKEN = []          # (a failed pass is not tried again in this run: a box whose profiler hangs must not cost the line minutes)
 
 
-def measure_traffic(extra_args, kernels, timeout=90):
-    """HBM bytes per launch of `kernels`, measured NOW: two short rocprofv3 child passes of this same script (counters in their own
-    runs, --pmc + --kernel-trace only, from /tmp: MI355X_MICROARCH.md), FETCH_SIZE and WRITE_SIZE averaged over the batched
-    (largest-grid) launches, bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts a 128-byte request as 64 in FETCH_SIZE; both
-    counters are in KiB).  Returns ({kernel: bytes}, how) -- ({}, reason) when rocprofv3 is not on this box or a pass fails."""
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0          # G wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz (the
+                                                # clock at which 16 lanes x 2 flop x 2 (packed) give the guide's 157.3 TFLOP/s fp32 vector peak)
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"))
+
+
+def measure_counters(extra_args, kernels, timeout=90, passes=PMC_PASSES):
+    """Counters of `kernels`, measured NOW: short rocprofv3 child passes of this same script (counters in their own runs, --pmc +
+    --kernel-trace only, from /tmp: MI355X_MICROARCH.md), averaged over the batched (largest-grid) launches.
+      hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts a 128-byte request as 64 in FETCH_SIZE; both are in KiB);
+      valu_insts_per_wave = SQ_INSTS_VALU / SQ_WAVES, waves = the launch's grid in waves, valu_busy = SQ_ACTIVE_INST_VALU x 4 /
+      (SQ_BUSY_CYCLES x 32 SIMDs per shader engine) -- the share of the launch during which a SIMD's VALU is issuing.
+    Returns ({kernel: {...}}, how) -- ({}, reason) when rocprofv3 is not on this box or a pass fails."""
     import collections
     import csv
     import glob
@@ -150,39 +160,70 @@ def measure_traffic(extra_args, kernels, timeout=90):
     # GPU pool's launcher refuses
     if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return {}, "this process runs under a profiler itself: no nested rocprofv3 passes"
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--settle", "20", "--no-cpu-baseline", "--no-extras",
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-extras",
              "--refine-iters", "0", "--no-pmc"] + list(extra_args)
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counters in passes:
         d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
         try:
-            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+            r = subprocess.run(["rocprofv3", "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                _PMC_BROKEN.append("rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode))
+                _PMC_BROKEN.append("rocprofv3 --pmc %s pass failed (rc %d)" % (" ".join(counters), r.returncode))
                 return {}, _PMC_BROKEN[0]
-            agg = collections.defaultdict(list)
+            agg = collections.defaultdict(lambda: collections.defaultdict(list))
             for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == counter:
-                    agg[row["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
-            for k, v in agg.items():
-                g = max(x[0] for x in v)
-                sel = [x[1] for x in v if x[0] == g]
-                vals.setdefault(k, {})[counter] = sum(sel) / len(sel)
+                if row["Counter_Name"] in counters:
+                    agg[row["Kernel_Name"].split("(")[0].replace("void ", "")][row["Counter_Name"]].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+            for k, cs in agg.items():
+                for cn, v in cs.items():
+                    g = max(x[0] for x in v)
+                    sel = [x[1] for x in v if x[0] == g]
+                    vals.setdefault(k, {})[cn] = sum(sel) / len(sel)
+                    vals[k]["grid_threads"] = g
         except Exception as e:      # noqa: BLE001
-            _PMC_BROKEN.append("rocprofv3 --pmc %s pass: %r" % (counter, e))
+            _PMC_BROKEN.append("rocprofv3 --pmc %s pass: %r" % (" ".join(counters), e))
             return {}, _PMC_BROKEN[0]
         finally:
             shutil.rmtree(d, ignore_errors=True)
     out = {}
     for want in kernels:
         for k, c in vals.items():
-            if k.endswith(want) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                out[want] = int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
-    return out, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of `bench.py %s` (batched launches; "
-                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, MI355X_MICROARCH.md)" % " ".join(child[2:]))
+            if not k.endswith(want):
+                continue
+            o = {}
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                o["hbm_bytes"] = int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+            if c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c:
+                o["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)
+                o["waves"] = int(c["grid_threads"] // 64)
+                if c.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in c:
+                    o["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (c["SQ_BUSY_CYCLES"] * 32.0), 4)
+            if o:
+                out[want] = o
+    return out, ("measured by this run: rocprofv3 --pmc child passes (%s) of `bench.py %s` (batched launches; "
+                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, MI355X_MICROARCH.md)" % (" | ".join(" ".join(c) for c in passes), " ".join(child[2:])))
+
+
+def apply_counters(roof, c, how):
+    """Folds one kernel's measured counters into its roofline object.  With an instruction count the object states the bound the
+    counters show -- VALU issue -- and keeps the SURVEY.md 8d byte formula and the measured traffic as HBM fractions of their own."""
+    ms = roof["avg_launch_ms"]
+    if "hbm_bytes" in c:
+        roof["traffic"], roof["traffic_source"] = c["hbm_bytes"], how
+        roof["traffic_over_algorithmic"] = round(c["hbm_bytes"] / roof["algorithmic_bytes"], 4)
+        roof["hbm_frac_measured_traffic"] = round(c["hbm_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None
+    if "valu_insts_per_wave" in c and ms > 0:
+        ginst = c["valu_insts_per_wave"] * c["waves"] / (ms * 1e-3) / 1e9
+        roof.update({"bound": "valu", "achieved": round(ginst, 2), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+                     "frac": round(ginst / VALU_PEAK_GINST, 5), "valu_instructions_per_wave": c["valu_insts_per_wave"],
+                     "waves_per_launch": c["waves"], "valu_busy_share_of_launch": c.get("valu_busy"),
+                     "bound_note": "SQ_INSTS_VALU x waves / launch time against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles: the share of the chip's "
+                                   "VALU issue slots this kernel fills (SQ_ACTIVE_INST_VALU says how long the VALUs are busy: transcendental "
+                                   "and 64-bit instructions hold theirs longer than one slot).  hbm_frac_survey_formula = SURVEY.md 8d bytes / "
+                                   "time / 8 TB/s (rounds 1-5 printed it as `frac`); hbm_frac_measured_traffic = the PMC traffic / time / 8 TB/s"})
 
 
 class Bench:
@@ -345,7 +386,8 @@ class Bench:
         # `traffic` is filled in by main() from rocprofv3 --pmc child passes of THIS run (measure_traffic); the committed profile's
         # figure is kept beside it under its own name
         roof = {"kernel": "blend_bwd_kernel<true>", "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": None, "traffic_from_committed_profile": traffic, "in_timed_region": False,
+                "frac": round(a / HBM_PEAK_GBS, 5), "hbm_frac_survey_formula": round(a / HBM_PEAK_GBS, 5), "hbm_frac_measured_traffic": None,
+                "traffic": None, "traffic_from_committed_profile": traffic, "in_timed_region": False,
                 "traffic_source": "not measured (see main(): --no-pmc, or rocprofv3 missing); traffic_from_committed_profile = "
                                   "profiles/latest_pmc_hbm_bytes.json (scripts/collect_profiles.py on the builder's box), null unless "
                                   "that pass ran this workload and its kernel duration agrees with this run's within 10 %",
@@ -360,7 +402,7 @@ class Bench:
         af = gbs(bytes_fused, fus_ms)
         roof_f = {"kernel": "blend_fwd_kernel<*, FUSED=true> (forward + loss + backward of a tile in one wave)", "bound": "hbm",
                   "achieved": round(af, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(af / HBM_PEAK_GBS, 5),
-                  "traffic": None, "traffic_from_committed_profile": committed_traffic("sgr::blend_fwd_kernel<512, true>", fus_ms),
+                  "hbm_frac_survey_formula": round(af / HBM_PEAK_GBS, 5), "hbm_frac_measured_traffic": None, "traffic": None, "traffic_from_committed_profile": committed_traffic("sgr::blend_fwd_kernel<512, true>", fus_ms),
                   "in_timed_region": True, "traffic_source": roof["traffic_source"],
                   "avg_launch_ms": round(fus_ms, 5), "launches": fus_n, "views_per_launch": nv, "algorithmic_bytes": bytes_fused,
                   "algorithmic_bytes_formula": "SURVEY 8d: blend-bwd 84 R_eff + 24 HW + 40 N  +  blend-fwd 48 R_eff + 28 HW, per view",
@@ -471,6 +513,8 @@ class Bench:
         t_refine = time.perf_counter() - t1
         res = {"frames": frames_n, "keyframes_mapped": mapped, "skipped": status.count("skipped"),
                "ms_per_keyframe": round(1e3 * (t_map - t_kf[0]) / max(1, mapped), 3),
+               "ms_per_mapped_keyframe": round(1e3 * (t_map - t_kf[0]) / max(1, mapped), 3),
+               "keyframes_per_s": round(mapped / max(1e-9, t_map - t_kf[0]), 3),
                "ms_init_keyframe_1050_iterations": round(1e3 * t_kf[0], 1),
                "ms_per_keyframe_second_half": round(1e3 * sum(t for t, st in list(zip(t_kf, status))[frames_n // 2:] if st == "mapped")
                                                     / max(1, status[frames_n // 2:].count("mapped")), 3),
@@ -479,10 +523,14 @@ class Bench:
                "psnr_all_keyframes_mean": round(float(np.mean(scores)), 3), "psnr_min": round(float(np.min(scores)), 3),
                "overflow_events": loop.overflow_events, "feed_s_rendering_ground_truth_untimed": round(t_feed, 2),
                "warmup_frames_untimed_throwaway_session": warm_frames,
-               "ms_by_frame": [round(1e3 * t, 1) for t in t_kf],
-               "note": "the first %d of the %d tracker frames of scripts/run_session_config1.py (same angular step); includes seeding, "
-                       "densify / prune, keyframe management; a whole session's later keyframes see a larger map "
-                       "(profiles/r0*_session_configs1.json)" % (frames_n, step_of)}
+               "ms_by_frame": [round(1e3 * t, 1) for t in t_kf] if frames_n <= 48 else None,
+               "ms_per_keyframe_by_quarter": [round(1e3 * sum(t for t, st in list(zip(t_kf, status))[max(1, q * frames_n // 4):(q + 1) * frames_n // 4] if st == "mapped")
+                                                    / max(1, status[max(1, q * frames_n // 4):(q + 1) * frames_n // 4].count("mapped")), 2) for q in range(4)],
+               "note": ("the WHOLE configs[1] session as SURVEY.md 8d C1 states it: %d tracker frames once around the room, default "
+                        "splat_slam.yaml hyper-parameters (mapper.py:834-1116), wall clock incl. seeding, densify / prune, keyframe management"
+                        % frames_n) if frames_n >= step_of else
+                       ("the first %d of the %d tracker frames of the configs[1] session (same angular step); includes seeding, "
+                        "densify / prune, keyframe management; the whole session is extra.session_full" % (frames_n, step_of))}
         # ---- one view of the final map: HIP render vs oracle render (the oracle is the checker, never the product path)
         from oracle import raster_oracle as O
         from splat_slam_amd.mapper import PipelineParams
@@ -525,11 +573,26 @@ def main():
     world, rank, dev, intr, lib = B.world, B.rank, B.dev, B.intr, B.lib
     N = args.gaussians
     loop, cams = B.build(args.loop, args.scale_add)
+    untimed = 0
     if args.settle:
         B.run_steps(loop, args.settle)
+        untimed += args.settle
     trace("setup done")
+    # The kernel-level legs of the line (event-timed rooflines of the fused tile kernel and of the un-fused pair) run BEFORE the
+    # headline: they are part of what this script reports anyway, and after them workspace capacities, list hints, allocator pools and
+    # the GPU's clocks are where a session has them from its second keyframe on -- rounds 3-5 reached that state with 150 extra untimed
+    # iterations (--settle, now 0 by default) on top of the --warmup the caller asked for.  Then exactly --warmup untimed steps, then
+    # exactly --steps timed ones.  `iterations_before_timed_region` counts everything this process ran before the clock started.
+    per_view = hist = roof_bwd = roof_f = None
+    if args.loop == "fused" and world == 1:
+        B.run_steps(loop, 2)
+        per_view, hist = B.work_counters(loop)
+        roof_bwd, roof_f = B.rooflines(loop, per_view, 30)
+        untimed += 2 + 2 * 33
+        trace("rooflines done")
     if args.warmup:
         B.run_steps(loop, args.warmup)
+        untimed += args.warmup
     trace("warmup done")
     if args.profile_all:
         lib.sgr_profile_enable((1 << len(KINDS)) - 1)
@@ -565,6 +628,7 @@ def main():
                    ("view-parallel x%d, %s" % (world, "RCCL reduce-scatter + Adam on 1/%d of the Gaussians + all-gather (ZeRO-1)" % world
                                                  if args.sync == "zero1" else "one RCCL all-reduce of the flat gradient buffer"))},
         "host_enqueue_ms_per_step": round(1e3 * host_issue / args.steps, 4), "settle_iterations_untimed": args.settle,
+        "iterations_before_timed_region": untimed,
         "map_iterations_per_s": round(args.steps / elapsed, 2),
         "world_size_seen": (B.dist.get_world_size() if B.dist is not None else 1), "transport": B.transport,
     }
@@ -584,14 +648,14 @@ def main():
         out["kernel_ms"] = kernel_ms
 
     if args.loop == "fused":
-        per_view, hist = B.work_counters(loop)
+        if per_view is None:
+            per_view, hist = B.work_counters(loop)
         nv = len(per_view)
         out["work_per_view"] = {"visible_gaussians": sum(p[0] for p in per_view) // nv, "tile_pairs_R": sum(p[1] for p in per_view) // nv,
                                 "tile_pairs_walked_R_eff": sum(p[2] for p in per_view) // nv,
                                 "nonempty_tiles": sum(p[3] for p in per_view) // nv, "views_in_last_launch": nv,
                                 "tiles_by_walked_list_length_last_view": hist}
     if args.loop == "fused" and world == 1:
-        roof_bwd, roof_f = B.rooflines(loop, per_view, 30)
         # `roofline` (the contract key) = the dominant kernel of the headline's timed region: the fused tile kernel;
         # `roofline_unfused_blend_bwd` = the north-star's kernel as a stand-alone launch (SGR_OPT_FUSED_BLEND = 0 leg of this run);
         # `roofline_fused` stays as an alias of `roofline` so that earlier rounds' readers find it
@@ -599,11 +663,10 @@ def main():
         if not args.no_pmc:
             pass_args = ["--gaussians", str(N), "--camera", args.camera, "--views", str(args.views), "--scale-add", str(args.scale_add),
                          "--order", args.order]
-            tr, how = measure_traffic(pass_args, ["blend_fwd_kernel<512, true>", "blend_bwd_kernel<true>"])
+            tr, how = measure_counters(pass_args, ["blend_fwd_kernel<512, true>", "blend_bwd_kernel<true>"])
             for roof, k in ((roof_f, "blend_fwd_kernel<512, true>"), (roof_bwd, "blend_bwd_kernel<true>")):
                 if k in tr:
-                    roof["traffic"], roof["traffic_source"] = tr[k], how
-                    roof["traffic_over_algorithmic"] = round(tr[k] / roof["algorithmic_bytes"], 4)
+                    apply_counters(roof, tr[k], how)
                 else:
                     roof["traffic_source"] = "not measured: %s; " % how + roof["traffic_source"]
         trace("rooflines done")
@@ -666,7 +729,8 @@ def main():
             trace("dropin done")
             torch.cuda.empty_cache()
             out["extra"] = {}
-            for name, leg in (("session", B.session_leg), ("opaque_scene", lambda: B.scene_leg(args.scale_add + 1.6)), ("keyframe_ordered_map", B.order_leg),
+            for name, leg in (("session", B.session_leg), ("session_full", lambda: B.session_leg(frames_n=160, step_of=160, warm_frames=0)),
+                              ("opaque_scene", lambda: B.scene_leg(args.scale_add + 1.6)), ("keyframe_ordered_map", B.order_leg),
                               ("opaque_scene_keyframe_ordered", lambda: B.scene_leg(args.scale_add + 1.6, order="keyframe"))):
                 try:
                     out["extra"][name] = leg()
@@ -685,11 +749,10 @@ def main():
         ro = dict(ex["opaque_scene"].pop("_roofline_fused"))
         ro["workload"] = "same N, every log-scale + 1.6 (extra.opaque_scene): %d walked (tile, Gaussian) pairs per view" % ex["opaque_scene"]["tile_pairs_walked_R_eff"]
         if not args.no_pmc:
-            tr, how = measure_traffic(["--gaussians", str(N), "--camera", args.camera, "--views", str(args.views), "--scale-add",
-                                       str(args.scale_add + 1.6), "--order", args.order], ["blend_fwd_kernel<512, true>"])
+            tr, how = measure_counters(["--gaussians", str(N), "--camera", args.camera, "--views", str(args.views), "--scale-add",
+                                        str(args.scale_add + 1.6), "--order", args.order], ["blend_fwd_kernel<512, true>"])
             if tr:
-                ro["traffic"], ro["traffic_source"] = tr["blend_fwd_kernel<512, true>"], how
-                ro["traffic_over_algorithmic"] = round(ro["traffic"] / ro["algorithmic_bytes"], 4)
+                apply_counters(ro, tr["blend_fwd_kernel<512, true>"], how)
         out["roofline_opaque"] = ro
     if ex:        # the headline scene is a FRESH map (mean list 11); what a converged map costs belongs next to the number
         out["value_context"] = {
@@ -697,7 +760,9 @@ def main():
             "same_N_surface_covering_map_keyframes_per_s": (ex.get("opaque_scene") or {}).get("keyframes_per_s"),
             "same_N_surface_covering_map_ms_per_step": (ex.get("opaque_scene") or {}).get("ms_per_step"),
             "session_ms_per_keyframe_incl_seeding_densify_prune": (ex.get("session") or {}).get("ms_per_keyframe"),
-            "session_keyframes_per_s": (round(1e3 / ex["session"]["ms_per_keyframe"], 2) if (ex.get("session") or {}).get("ms_per_keyframe") else None)}
+            "session_keyframes_per_s": (round(1e3 / ex["session"]["ms_per_keyframe"], 2) if (ex.get("session") or {}).get("ms_per_keyframe") else None),
+            "full_160_frame_session_keyframes_per_s": (ex.get("session_full") or {}).get("keyframes_per_s"),
+            "full_160_frame_session_gaussians_final": (ex.get("session_full") or {}).get("gaussians_final")}
     if rank == 0:
         print(json.dumps(out))
     if B.dist is not None:

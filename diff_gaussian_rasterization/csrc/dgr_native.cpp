@@ -298,19 +298,23 @@ struct Batch {
   // same versions.  The later views' own activation tensors then simply get no gradient: all of it flows through the FIRST view's
   // chain, summed over the views -- exact, because the views' chains apply the same linear map to their gradients
   // (sum_k J g_k = J sum_k g_k, up to fp32 summation order).
-  static bool pure_op(const std::string& n) {
-    static const char* ok[] = {"ExpBackward0", "SigmoidBackward0", "CatBackward0", "RepeatBackward0", "DivBackward0", "ExpandBackward0",
-                               "ClampMinBackward0", "LinalgVectorNormBackward0", "NormBackward1", "TransposeBackward0", "ViewBackward0",
-                               "UnsafeViewBackward0", "ReshapeAliasBackward0", "CloneBackward0", "AliasBackward0", "PermuteBackward0",
-                               "UnsqueezeBackward0", "SqueezeBackward1"};
-    for (auto* k : ok)
-      if (n == k) return true;
-    return false;
+  // index of a whitelisted operator (-1: not on the list).  The order is that of `kPure` below: same_attributes() switches on it.
+  enum PureOp { P_EXP, P_SIGMOID, P_CAT, P_REPEAT, P_DIV, P_EXPAND, P_CLAMPMIN, P_VECNORM, P_NORM1, P_TRANSPOSE, P_VIEW, P_UNSAFEVIEW,
+                P_RESHAPEALIAS, P_CLONE, P_ALIAS, P_PERMUTE, P_UNSQUEEZE, P_SQUEEZE1, P_COUNT };
+  static int pure_op(const std::string& n) {
+    static const char* kPure[P_COUNT] = {"ExpBackward0", "SigmoidBackward0", "CatBackward0", "RepeatBackward0", "DivBackward0", "ExpandBackward0",
+                                         "ClampMinBackward0", "LinalgVectorNormBackward0", "NormBackward1", "TransposeBackward0", "ViewBackward0",
+                                         "UnsafeViewBackward0", "ReshapeAliasBackward0", "CloneBackward0", "AliasBackward0", "PermuteBackward0",
+                                         "UnsqueezeBackward0", "SqueezeBackward1"};
+    for (int i = 0; i < P_COUNT; ++i)
+      if (n == kPure[i]) return i;
+    return -1;
   }
   // The whitelisted operators are pure functions of their tensor inputs AND of a few non-tensor arguments (cat / norm / squeeze
   // dims, the clamp's minimum, repeat / expand / view sizes, permutations).  Two chains that differ only in such an argument -- a
   // permute of a square tensor, another eps -- have the same node names and the same topology: the arguments are compared as
   // well, and so is the shape of every intermediate result (a node's input metadata = its forward outputs).
+  // (`op` identifies the node type -- both nodes carry that name -- so the casts are static: this runs ~60 times per render.)
   static bool same_syms(const std::vector<c10::SymInt>& x, const std::vector<c10::SymInt>& y) {
     if (x.size() != y.size()) return false;
     for (size_t i = 0; i < x.size(); ++i)
@@ -320,32 +324,34 @@ struct Batch {
   static bool same_scalar(const at::Scalar& x, const at::Scalar& y) {
     return x.isFloatingPoint() == y.isFloatingPoint() && x.isIntegral(true) == y.isIntegral(true) && x.toDouble() == y.toDouble();
   }
-  static bool same_attributes(const torch::autograd::Node* a, const torch::autograd::Node* b) {
+  static bool same_attributes(const torch::autograd::Node* a, const torch::autograd::Node* b, int op) {
     namespace G = torch::autograd::generated;
     if (a->num_inputs() != b->num_inputs()) return false;
     for (uint32_t i = 0; i < a->num_inputs(); ++i)
       if (a->input_metadata(i).shape_as_dim_vector() != b->input_metadata(i).shape_as_dim_vector()) return false;
-#define DGR_SAME(T, EXPR)                                  \
-  if (auto* x = dynamic_cast<const G::T*>(a)) {            \
-    auto* y = dynamic_cast<const G::T*>(b);                \
-    return y != nullptr && (EXPR);                         \
+#define DGR_SAME(T, EXPR)                                                                      \
+  {                                                                                            \
+    auto *x = static_cast<const G::T*>(a), *y = static_cast<const G::T*>(b);                   \
+    return (EXPR);                                                                             \
   }
-    DGR_SAME(CatBackward0, x->dim == y->dim && x->tensors_size_ == y->tensors_size_)
-    DGR_SAME(RepeatBackward0, same_syms(x->repeats, y->repeats) && same_syms(x->self_sym_sizes, y->self_sym_sizes))
-    DGR_SAME(ExpandBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
-    DGR_SAME(ClampMinBackward0, same_scalar(x->min, y->min))
-    DGR_SAME(LinalgVectorNormBackward0, x->keepdim == y->keepdim && same_scalar(x->ord, y->ord) && x->dim.list == y->dim.list)
-    DGR_SAME(NormBackward1, x->keepdim == y->keepdim && x->dim == y->dim && x->p.has_value() == y->p.has_value() &&
-                                (!x->p.has_value() || same_scalar(*x->p, *y->p)))
-    DGR_SAME(TransposeBackward0, x->dim0 == y->dim0 && x->dim1 == y->dim1)
-    DGR_SAME(ViewBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
-    DGR_SAME(UnsafeViewBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
-    DGR_SAME(ReshapeAliasBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
-    DGR_SAME(PermuteBackward0, x->dims == y->dims)
-    DGR_SAME(UnsqueezeBackward0, x->dim == y->dim)
-    DGR_SAME(SqueezeBackward1, x->dim == y->dim && same_syms(x->self_sym_sizes, y->self_sym_sizes))
+    switch (op) {
+      case P_CAT: DGR_SAME(CatBackward0, x->dim == y->dim && x->tensors_size_ == y->tensors_size_)
+      case P_REPEAT: DGR_SAME(RepeatBackward0, same_syms(x->repeats, y->repeats) && same_syms(x->self_sym_sizes, y->self_sym_sizes))
+      case P_EXPAND: DGR_SAME(ExpandBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
+      case P_CLAMPMIN: DGR_SAME(ClampMinBackward0, same_scalar(x->min, y->min))
+      case P_VECNORM: DGR_SAME(LinalgVectorNormBackward0, x->keepdim == y->keepdim && same_scalar(x->ord, y->ord) && x->dim.list == y->dim.list)
+      case P_NORM1: DGR_SAME(NormBackward1, x->keepdim == y->keepdim && x->dim == y->dim && x->p.has_value() == y->p.has_value() &&
+                                                (!x->p.has_value() || same_scalar(*x->p, *y->p)))
+      case P_TRANSPOSE: DGR_SAME(TransposeBackward0, x->dim0 == y->dim0 && x->dim1 == y->dim1)
+      case P_VIEW: DGR_SAME(ViewBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
+      case P_UNSAFEVIEW: DGR_SAME(UnsafeViewBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
+      case P_RESHAPEALIAS: DGR_SAME(ReshapeAliasBackward0, same_syms(x->self_sym_sizes, y->self_sym_sizes))
+      case P_PERMUTE: DGR_SAME(PermuteBackward0, x->dims == y->dims)
+      case P_UNSQUEEZE: DGR_SAME(UnsqueezeBackward0, x->dim == y->dim)
+      case P_SQUEEZE1: DGR_SAME(SqueezeBackward1, x->dim == y->dim && same_syms(x->self_sym_sizes, y->self_sym_sizes))
+      default: return true;        // Exp, Sigmoid, Div, Clone, Alias: nothing but their tensor inputs
+    }
 #undef DGR_SAME
-    return true;        // Exp, Sigmoid, Div, Clone, Alias: nothing but their tensor inputs
   }
   void record_leaves(const torch::autograd::Node* fn, int depth) {
     if (!fn || depth > 8) return;
@@ -365,8 +371,10 @@ struct Batch {
       }
       return true;
     }
-    if (a->name() != b->name() || !pure_op(a->name()) || a->num_outputs() != b->num_outputs()) return false;
-    if (!same_attributes(a, b)) return false;
+    const std::string na = a->name();
+    const int op = pure_op(na);
+    if (op < 0 || a->num_outputs() != b->num_outputs() || na != b->name()) return false;
+    if (!same_attributes(a, b, op)) return false;
     for (uint32_t j = 0; j < a->num_outputs(); ++j) {
       const auto& ea = a->next_edge(j);
       const auto& eb = b->next_edge(j);

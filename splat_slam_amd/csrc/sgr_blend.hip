@@ -471,7 +471,10 @@ __device__ __forceinline__ void bwd_chunk2(
       group_scan_mul2<GW>(P0, P1);                         // prod over this splat and all behind it (in chunk)
       const v2f rP = {__builtin_amdgcn_rcpf(P0), __builtin_amdgcn_rcpf(P1)};
       const v2f Tj = (v2f){b0.x, b0.y} * rP;               // transmittance in front of splat j
-      const v2f inv1ma = prev_times<GW>(P0, P1, rP, lane); // 1 / (1 - alpha_j) = (prod over all strictly behind it) / (prod incl. it)
+      // 1 / (1 - alpha_j) = (prod over all strictly behind it) / (prod incl. it).  (Scanning the reciprocals 1 / (1 - alpha) instead --
+      // the factor is then the scan's INPUT -- saves these two DPP multiplies and costs two copies: the scan works in place.  Measured
+      // in the ISA, round 6: 264 instructions per row either way.)
+      const v2f inv1ma = prev_times<GW>(P0, P1, rP, lane);
       const v2f dCr = {a0.x, a0.y}, dCg = {a0.z, a0.w}, dCb = {a1.x, a1.y}, dD = {a1.z, a1.w};
       const v2f w = __builtin_elementwise_fma(dCr, splat2(cr), __builtin_elementwise_fma(dCg, splat2(cg),
                     __builtin_elementwise_fma(dCb, splat2(cb), dD * splat2(dep))));
@@ -839,13 +842,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   const bool use_stash = FUSED && mode == 0 && count <= kStash && !n_touched;
   float T = 1.f;
   v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, Dd = {0.f, 0.f};   // (even, odd) list positions, added at the end
-  // last contributor of this pixel = 2 * (its last contributing trip, counted from 1 over the whole list) - (1 if that trip's FIRST
-  // splat was the last one): the trip per lane (one select per trip), which half as a wave mask (scalar) -- two selects and two
-  // moves per trip less than tracking the index itself
-  uint32_t last_trip = 0;
-  unsigned long long last_first_m = 0ull;
-  uint32_t mx_trip = 0;                       // the same for the whole tile (its maximum over the pixels), kept by the scalar unit
-  unsigned long long mx_second_m = 0ull;
+  // Where this pixel's walk ENDS: the list position of the splat at which its transmittance would have fallen below kTEps (that splat
+  // is not composited), 0x7fffffff while it has not.  That is all the backward needs to know (`idx < nc`): every splat in front of
+  // that position that passes the footprint test WAS composited, so the backward's own footprint test singles out the contributors.
+  // Rounds 1-5 tracked the last CONTRIBUTOR instead -- a move and a select per trip for every pixel; a pixel terminates at most once,
+  // and which pixels do in a trip is a wave mask the termination logic has anyway: the select now sits behind a scalar branch that a
+  // fresh map's tiles never take.
+  uint32_t term = inside ? 0x7fffffffu : 0u;
+  uint32_t term_last = 0;                     // position of the latest termination in the tile (monotonic; scalar)
   unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside || (L.dbg & 2048));      // finished pixels, one bit per lane (bit 11 of SGR_DEBUG, EXPERIMENT: no walk, no backward -- what the rest of a tile's wave costs)
   const v2f px2 = splat2(pxf), py2 = splat2(pyf);
 
@@ -920,12 +924,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
           if (tm != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(q3.w)], (int)__popcll(tm));
         }
         T = comp1 ? test1 : T1;
-        const unsigned long long any_m = comp0_m | comp1_m;
-        last_trip = __builtin_amdgcn_inverse_ballot_w64(any_m) ? (uint32_t)(((base + j) >> 1) + 1) : last_trip;
-        last_first_m = (last_first_m & ~any_m) | (comp0_m & ~comp1_m);
-        // (the whole-tile maximum stays on the scalar unit: the trip and the second splat's MASK are selected, the mask is tested once
-        //  after the walk -- `comp1_m != 0 ? 1 : 0` inside the loop came out as v_cndmask + v_readfirstlane per trip)
-        if (any_m != 0ull) { mx_trip = (uint32_t)(((base + j) >> 1) + 1); mx_second_m = comp1_m; }
+        const unsigned long long end0_m = live0 & lt0, end1_m = live1 & lt1;
+        if ((end0_m | end1_m) != 0ull) {
+          asm volatile("" ::: "memory");            // (a real branch: speculated, the selects would be back in every trip)
+          const uint32_t p0 = (uint32_t)(base + j);
+          term = __builtin_amdgcn_inverse_ballot_w64(end0_m) ? p0 : (__builtin_amdgcn_inverse_ballot_w64(end1_m) ? p0 + 1u : term);
+          term_last = end1_m != 0ull ? p0 + 1u : p0;
+        }
       }
     };
     if (n_touched) walk(std::true_type{}, std::false_type{});
@@ -935,10 +940,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
     if (~done_m == 0ull) break;
   }
   const float C0 = Cr.x + Cr.y, C1 = Cg.x + Cg.y, C2 = Cb.x + Cb.y, D = Dd.x + Dd.y;
-  const uint32_t last = 2u * last_trip - (__builtin_amdgcn_inverse_ballot_w64(last_first_m) ? 1u : 0u);      // (no contributor: 0; the mask bit is then clear)
+  const uint32_t last = term;
 
-  // per-tile bound for the backward: it never has to look past the last contributor of any pixel
-  const uint32_t mx = mx_trip ? 2u * mx_trip - 1u + (mx_second_m != 0ull ? 1u : 0u) : 0u;       // = the maximum of `last` over the wave
+  // per-tile bound for the backward: when every pixel's walk has ended, nothing behind the latest end was composited anywhere
+  const uint32_t mx = (~done_m == 0ull) ? term_last : (uint32_t)count;
   if (lane == 0) tile_maxc[tile] = mx;
 
   float l_rgb = 0.f, l_dep = 0.f, l_da = 0.f, l_db = 0.f;

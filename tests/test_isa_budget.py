@@ -49,12 +49,12 @@ def _loops(lines):
                 break
         if label is None:
             continue
-        tag = "Header=" + label.replace(".L", "")
+        tag = re.compile("Header=" + re.escape(label.replace(".L", "")) + r"(?!\d)")
         body, cur = [], False
         for x in lines:
             m = re.match(r"(\.LBB\d+_\d+):", x)
             if m or x.startswith("; %bb."):
-                cur = (tag in x) or (m is not None and m.group(1) == label)
+                cur = bool(tag.search(x)) or (m is not None and m.group(1) == label)
             if cur:
                 body.append(x)
         cnt = lambda pat: sum(1 for x in body if pat in x)
@@ -97,8 +97,9 @@ def test_forward_walk_stays_within_its_instruction_budget(fused_asm):
     plain = [l["valu"] for l in walks if not l["ds_write"] and not l["atomic"]]
     stashing = [l["valu"] for l in walks if l["ds_write"] and not l["atomic"]]
     assert plain and stashing, walks
-    assert min(plain) <= 32, walks                             # (two splats per trip: 31; round 5: 35; 45 in round 3)
-    assert min(stashing) <= 35, walks                          # (+3: the masked exp2(-npow) of both splats goes to the stash)
+    # (counts include the five instructions of the rarely taken "a pixel's walk ended in this trip" block)
+    assert min(plain) <= 34, walks                             # (two splats per trip: 28 + 5; round 5: 35; 45 in round 3)
+    assert min(stashing) <= 37, walks                          # (+3: the masked exp2(-npow) of both splats goes to the stash)
 
 
 def test_no_v_readlane_in_the_rank_sort(fused_asm):
