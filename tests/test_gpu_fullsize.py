@@ -42,8 +42,8 @@ import math
 import pytest
 import torch
 
-from gpu_utils import (GRAD_KEYS, check_depth_keys, hip_depth_keys, knife_ids, move_off_knife_edges, outlier_report, rel_linf,
-                       run_hip, run_oracle)
+from gpu_utils import (GRAD_KEYS, check_depth_keys, hip_depth_keys, knife_ids, move_off_knife_edges, move_off_knife_edges_and_depth_ties,
+                       outlier_report, rel_linf, run_hip, run_oracle)
 from oracle import raster_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -176,18 +176,23 @@ WIDTH = {"means3D": 3, "means2D": 3, "opacities": 1, "shs": 3, "scales": 3, "rot
 
 
 @pytest.mark.parametrize("case", [("configs0", 20000, "replica", 0.0, True), ("configs1", 300000, "metric", 0.0, True),
+                                  ("configs0_own_sort", 20000, "replica", 0.0, "own"), ("configs1_own_sort", 300000, "metric", 0.0, "own"),
                                   ("configs1_raw", 300000, "metric", 0.0, "raw"), ("configs1_opaque", 150000, "metric", 1.6, False)],
                          ids=lambda c: c[0])
 def test_autograd_api_matches_oracle_at_config_size(case):
     name, n, camera, scale_add, deknife = case
     raw = deknife == "raw"          # the scene as generated: knife-edge Gaussians stay, and must be the ONLY ones beyond the tolerance
-    deknife = deknife is True
+    own = deknife == "own"          # additionally de-tied in depth, the oracle sorts by its OWN depths (no hand-over of
+    deknife = deknife is True or own    # the HIP forward's keys), nothing is excused, pose gradients at 1 x REL like everything else
     syn, intr, params, cams = _room(n, camera, 1, scale_add=scale_add)
     gm = syn.model_from_parameters(params, device=DEV)
     inp = _activated_inputs(gm)
     s = _oracle_settings(cams[0], intr)
     soft = Soft()
-    if deknife:        # the two headline configs are compared WITHOUT exceptions: first move the scene off its knife edges
+    if own:
+        rounds, moves = move_off_knife_edges_and_depth_ties(inp, s)
+        soft.check(True, f"{name}: {rounds} rounds, {moves} Gaussians pushed apart in depth: no knife edge, no near tie of depth left")
+    elif deknife:      # the two headline configs are compared WITHOUT exceptions: first move the scene off its knife edges
         rounds = move_off_knife_edges(inp, s)
         soft.check(True, f"{name}: {rounds} rounds of nudging (opacity; centre and scale for tile-rectangle or radius edges) to clear the knife edges")
     g = torch.Generator().manual_seed(5)
@@ -197,11 +202,14 @@ def test_autograd_api_matches_oracle_at_config_size(case):
     view = s.viewmatrix.double().t()
     check_depth_keys(keys, hip_out[1], inp["means3D"] @ view[2, :3] + view[2, 3])
     knife = {}
-    ref_out, ref_g = run_oracle(inp, s, wc, wd, dtype=torch.float64, depth_sort_key=keys, knife=knife)
+    ref_out, ref_g = run_oracle(inp, s, wc, wd, dtype=torch.float64, depth_sort_key=None if own else keys, knife=knife)
     on_edge = knife_ids(knife, n)
     nvis = int((ref_out[1] > 0).sum())
     assert nvis > (1000 if n < 100000 else 10000), "scene is not visible enough to mean anything"
-    _check_radii(soft, hip_out[1], ref_out[1], name)
+    if own:
+        soft.check(torch.equal(hip_out[1], ref_out[1]), f"{name}: radii differ at {int((hip_out[1] != ref_out[1]).sum())} Gaussians (exact match required)")
+    else:
+        _check_radii(soft, hip_out[1], ref_out[1], name)
     if deknife:
         soft.check(int(on_edge.sum()) == 0, f"{name}: {int(on_edge.sum())} Gaussians still on a knife edge")
         for i, what in ((0, "color"), (2, "depth"), (3, "opacity")):

@@ -1,0 +1,237 @@
+"""-m gpu, round 6 (VERDICT r5 items 4 and 7 + ADVICE r5).
+
+  * every case of tests/test_gpu_parity.py again WITHOUT an excuse: the Gaussians that sit on a cut-off or in a near tie of depth are
+    removed (gpu_utils.drop_knife_edges_and_depth_ties), the oracle sorts by its own depths, and then radii and n_touched are exact,
+    no pixel and no gradient is beyond 1e-4 -- pose gradients included;
+  * the settings flags the reference passes and the rasterizer must ignore (prefiltered, debug), images narrower / lower than a tile;
+  * the rows SURVEY.md 8(a) pins on the CPU only (A5 camera matrices, A17 median depth / keyframe management, A18 PSNR) once more on
+    device tensors against the same reference-generated golden vectors;
+  * a forward that overflows in the MIDDLE of a span: the sticky header count must bring the replay about."""
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_scene
+from gpu_utils import GRAD_KEYS, drop_knife_edges_and_depth_ties, hip_settings, rel_linf, run_hip, run_oracle, to_fp32_inputs
+from test_gpu_parity import CASES, _weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REL = 1e-4
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _exact_against_oracle(name, inp, s, seed=5):
+    H, W = s.image_height, s.image_width
+    wc, wd = _weights(seed, H, W)
+    hip_out, hip_g = run_hip(inp, s, wc, wd)
+    ref_out, ref_g = run_oracle(inp, s, wc, wd, dtype=torch.float64)           # (its own depths: no sort-key hand-over)
+    assert torch.equal(hip_out[1], ref_out[1]), f"{name}: radii differ at {int((hip_out[1] != ref_out[1]).sum())} Gaussians"
+    assert torch.equal(hip_out[4].long(), ref_out[4].long()), f"{name}: n_touched differs by {(hip_out[4].long() - ref_out[4].long()).abs().sum().item()} counts"
+    for i, what in ((0, "color"), (2, "depth"), (3, "opacity")):
+        r = rel_linf(hip_out[i], ref_out[i])
+        assert r <= REL or ref_out[i].abs().max() == 0, f"{name}/{what}: rel err {r:.3e} (no outlier pixel allowed)"
+    for k in GRAD_KEYS:
+        if ref_g.get(k) is None:
+            continue
+        r = rel_linf(hip_g[k].reshape(-1), ref_g[k].reshape(-1))
+        assert r <= REL or ref_g[k].abs().max() == 0, f"{name}: grad {k} rel err {r:.3e}"
+    return hip_out, ref_out
+
+
+# (what must survive the thinning for the case to still exercise what it is there for)
+MIN_KEPT = {"heavy": 150, "skewed": 200, "dense": 600, "wide": 150}
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_every_parity_case_is_exact_off_the_knife_edges(case):
+    name, n, W, H, kw = case
+    inp, s = random_scene(n, seed=11, W=W, H=H, **kw)
+    inp, s = to_fp32_inputs(inp, s)
+    inp, kept, rounds = drop_knife_edges_and_depth_ties(inp, s)
+    assert kept >= MIN_KEPT.get(name, 1), (name, kept)
+    hip_out, ref_out = _exact_against_oracle(name, inp, s)
+    if name in ("heavy", "skewed"):        # still the multi-chunk backward: more splats than one 64-lane chunk
+        assert int((ref_out[1] > 0).sum()) > 128, int((ref_out[1] > 0).sum())
+
+
+@pytest.mark.parametrize("wh", [(5, 40), (40, 6), (7, 7), (3, 17)], ids=lambda wh: "%dx%d" % wh)
+def test_images_narrower_or_lower_than_a_tile(wh):
+    """W or H below 8 (one partial 8x8 bin, one partial 16x16 reference tile in that direction): tile grids of 1, lanes outside the
+    image in every wave, the tile-major pixel state."""
+    W, H = wh
+    inp, s = random_scene(40, seed=5, W=W, H=H, fx=0.9 * W, fy=0.9 * H, cx=0.45 * W, cy=0.55 * H, spread=0.4)
+    inp, s = to_fp32_inputs(inp, s)
+    inp, kept, _ = drop_knife_edges_and_depth_ties(inp, s)
+    assert kept >= 10
+    _exact_against_oracle("%dx%d" % wh, inp, s)
+
+
+def test_prefiltered_and_debug_flags_are_inert():
+    """GaussianRasterizationSettings.prefiltered / .debug (gaussian_renderer/__init__.py:70-71: the reference always passes False,
+    False).  Upstream's `prefiltered` only skips a frustum test that the Splat-SLAM patch removed and `debug` only adds error
+    checks: neither may change a single bit of any output or gradient."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    inp, s = random_scene(300, seed=9, W=64, H=48)
+    wc, wd = _weights(3, 48, 64)
+
+    def run(prefiltered, debug):
+        x = {k: v.detach().to(device=DEV, dtype=torch.float32).requires_grad_(True) for k, v in inp.items()}
+        st = hip_settings(s, DEV)._replace(prefiltered=prefiltered, debug=debug)
+        out = GaussianRasterizer(raster_settings=st)(means3D=x["means3D"], means2D=x["means2D"], shs=x.get("shs"), colors_precomp=None,
+                                                     opacities=x["opacities"], scales=x.get("scales"), rotations=x.get("rotations"),
+                                                     cov3D_precomp=None, theta=x.get("theta"), rho=x.get("rho"))
+        ((out[0] * wc.to(DEV).float()).sum() + (out[2] * wd.to(DEV).float()).sum()).backward()
+        torch.cuda.synchronize()
+        return [o.detach().cpu() for o in out], {k: v.grad.detach().cpu() for k, v in x.items() if v.grad is not None}
+
+    base_out, base_g = run(False, False)
+    for flags in ((True, False), (False, True), (True, True)):
+        out, g = run(*flags)
+        for a, b in zip(base_out, out):
+            assert torch.equal(a, b), flags
+        for k in base_g:
+            assert torch.equal(base_g[k], g[k]), (flags, k)
+
+
+# ------------------------------------------------------------------------------------------------ A5 / A17 / A18 on device tensors
+G = np.load(os.path.join(HERE, "golden", "reference_vectors.npz"))
+NAMES = ["default640x480", "replica640x320", "tum512x384", "scannet320x240"]
+
+
+def _t(x, dev=DEV):
+    return torch.from_numpy(np.asarray(x)).to(dev)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_a5_camera_matrices_on_the_device_match_the_reference_golden(name):
+    """Golden G1 (getWorld2View2 / getProjectionMatrix2 / Camera properties of the imported reference, tests/golden/make_golden.py) with
+    the Camera living on cuda:0 -- where every render of the product builds them (splat_slam_amd/camera.py)."""
+    from splat_slam_amd.camera import Camera, focal2fov, getProjectionMatrix2
+    W, H, fx, fy, cx, cy = G[f"g1_{name}_intr"]
+    W, H = int(W), int(H)
+    P = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=fx, fy=fy, cx=cx, cy=cy, W=W, H=H).transpose(0, 1).to(DEV)
+    assert torch.equal(P.cpu(), torch.from_numpy(G[f"g1_{name}_proj"]))
+    for i in range(8):
+        cam = Camera(0, None, None, torch.eye(4, device=DEV), P, fx, fy, cx, cy, focal2fov(fx, W), focal2fov(fy, H), H, W, device=DEV)
+        cam.update_RT(_t(G["g1_pose_R"][i]), _t(G["g1_pose_T"][i]))
+        assert cam.world_view_transform.device.type == "cuda"
+        assert torch.allclose(cam.world_view_transform, _t(G[f"g1_{name}_view"][i]), atol=2e-6, rtol=1e-6)
+        assert torch.allclose(cam.full_proj_transform, _t(G[f"g1_{name}_full"][i]), atol=1e-5, rtol=1e-5)
+        assert torch.allclose(cam.camera_center, _t(G[f"g1_{name}_center"][i]), atol=1e-5, rtol=1e-5)
+
+
+def test_a17_median_depth_on_the_device_matches_the_reference_golden():
+    from splat_slam_amd.losses import get_median_depth
+    d, o = _t(G["g5_med_depth"]), _t(G["g5_med_opacity"])
+    assert get_median_depth(d, o * 0 + 0.96).item() == float(G["g5_median"])
+    assert get_median_depth(d, torch.where(o > 0.5, o * 0 + 0.99, o * 0)).item() == float(G["g5_median_masked"])
+
+
+def test_a17_keyframe_management_on_the_device_matches_the_reference_golden():
+    """is_keyframe / add_to_window (mapper.py:744-831) with poses and visibility masks on cuda:0 -- the tensors MappingSession really
+    holds -- against the decisions the imported reference took (tests/golden/reference_loop.npz, make_golden_loop.py)."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden_loop import CX, CY, FX, FY, H, W, keyframe_cases
+    from splat_slam_amd.camera import Camera, getProjectionMatrix2
+    from splat_slam_amd.session import MappingSession
+    GL = np.load(os.path.join(HERE, "golden", "reference_loop.npz"))
+    P = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=FX, fy=FY, cx=CX, cy=CY, W=W, H=H).transpose(0, 1).to(DEV)
+    for ci, case in enumerate(keyframe_cases()):
+        loop = types.SimpleNamespace(config={"mapping": {"Training": {"kf_translation": 0.04, "kf_min_translation": 0.02, "kf_overlap": 0.95}}},
+                                     device=DEV, window_size=case["window_size"])
+        sess = MappingSession.__new__(MappingSession)
+        sess.loop, sess.config, sess.device = loop, loop.config, DEV
+        sess.cameras, sess.median_depth = {}, case["median_depth"]
+        for k, w2c in enumerate(case["poses"]):
+            c = Camera(k, None, None, w2c.to(DEV), P, FX, FY, CX, CY, 1.0, 1.0, H, W, device=DEV)
+            c.update_RT(c.R_gt, c.T_gt)
+            sess.cameras[k] = c
+        masks = [m.to(DEV) for m in case["masks"]]
+        occ = {k: m for k, m in enumerate(masks)}
+        cur = len(case["poses"]) - 1
+        assert sess.is_keyframe(cur, case["window"][0], masks[cur], occ) == bool(GL[f"kf{ci}_is_keyframe"])
+        win, removed = sess.add_to_window(cur, masks[cur], occ, list(case["window"]))
+        assert win == GL[f"kf{ci}_window"].tolist()
+        assert (-1 if removed is None else removed) == int(GL[f"kf{ci}_removed"])
+
+
+def test_a18_psnr_on_the_device_matches_the_reference_golden():
+    from splat_slam_amd.eval import psnr
+    assert torch.allclose(psnr(_t(G["g6_a"]), _t(G["g6_b"])).cpu(), torch.from_numpy(G["g6_psnr"]), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ overflow in the middle of a span
+def test_a_forward_that_overflows_in_the_middle_of_a_span_is_replayed():
+    """ADVICE r5 (medium).  A span (sgr_map_run) renders its random picks in shared workspace SLOTS: slot j holds a different pool
+    camera every iteration, and SavedHeader.overflow describes the last forward only.  Here the pool camera with the LARGEST pair
+    count is picked in the middle of the span only, and the capacity is sabotaged to lie between its count and everybody else's:
+    only K2's sticky event count can tell the check.  The run must replay and end bit for bit where a run with ample capacity ends."""
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    intr = syn.INTRINSICS["metric"]
+
+    def drive(sabotage):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        params = syn.room_parameters(60000, seed=5, device=DEV)
+        params["scaling"] = params["scaling"] + 1.2
+        cams = syn.make_views(params, 7, intr, DEV, seed=5)
+        cfg = copy.deepcopy(syn.DEFAULT_CONFIG)
+        f = FusedMappingLoop(cfg, device=DEV)
+        f.gaussians = syn.model_from_parameters(params, device=DEV)
+        f.viewpoints = {c.uid: c for c in cams}
+        f.current_window = [0, 1, 2]
+        f.build_keyframe_optimizers()
+        f.iteration_count = 50
+        f._ensure_state()
+        R0, T0 = cams[0].R.clone(), cams[0].T.clone()
+        T0[2] = T0[2] + 1.5                          # camera 0 steps 1.5 m BACK from the wall it faces: it sees about twice as many splats
+        cams[0].update_RT(R0, T0)
+        for c in cams:                               # every camera's pair count at this map (header read-backs)
+            f.render_forward(c)
+        torch.cuda.synchronize()
+        pairs = {c.uid: f._pair_hint[c.uid][0] for c in cams}
+        order = sorted(pairs, key=pairs.get)
+        big = f.viewpoints[order[-1]]                # the greedy camera: a POOL camera; the window = the three leanest ones
+        f.current_window = order[:3]
+        f.build_keyframe_optimizers()
+        others = max(v for k, v in pairs.items() if k != big.uid)
+        assert big.uid == 0 and pairs[big.uid] > 1.25 * others, pairs
+        ev0, rp0 = f.overflow_events, f.replayed_transactions
+        if sabotage:          # every count "measured" at half the others' size, the capacity between the others and `big`: only `big` overflows
+            for vb in f._views.values():
+                vb.pairs, vb.estimated = others // 2, False
+            f._cap = (others + pairs[big.uid]) // 2
+            f.capacity_floor = min(f.capacity_floor, f._cap)
+            f._views_dirty()
+        f.verify_estimates = False
+        # the span's picks are torch.randperm draws (mapper.py:470): a seed whose 12 iterations pick the greedy camera in the MIDDLE only
+        pool = [c for c in cams if c.uid not in f.current_window]
+        for seed in range(500):
+            torch.manual_seed(seed)
+            idx = [torch.randperm(len(pool))[:2].tolist() for _ in range(12)]
+            where = [i for i, p in enumerate(idx) if pool.index(big) in p]
+            if where and min(where) >= 3 and max(where) <= 8:
+                break
+        else:
+            raise AssertionError("no seed picks the greedy camera in the middle of the span only")
+        torch.manual_seed(seed)
+        f.map(f.current_window, iters=12)
+        torch.cuda.synchronize()
+        gm = f.gaussians
+        state = {k: getattr(gm, k).detach().clone() for k in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")}
+        return state, f.overflow_events - ev0, f.replayed_transactions - rp0, f
+
+    ample, ev_a, rp_a, _ = drive(False)
+    tight, ev_t, rp_t, f = drive(True)
+    assert ev_a == 0 and rp_a == 0
+    assert ev_t >= 1 and rp_t >= 1, (ev_t, rp_t)
+    for k in ample:
+        assert torch.equal(ample[k], tight[k]), k
+    assert f.check_overflow() == []

@@ -161,3 +161,40 @@ def test_zero1_plan_exchange_world_size_2_equals_replicated_adam(n):
         assert torch.equal(ref.view(p0, name, shapes[name]), P[name]), name
         assert torch.equal(ref.view(m0, name, shapes[name]), M[name]), name
     assert plan.rows["xyz"] == (0, n)
+
+
+@pytest.mark.parametrize("world,n", [(4, 7), (4, 1001), (8, 5), (8, 1001)])
+def test_zero1_plan_exchange_world_size_4_and_8(world, n):
+    """the ZeRO-1 plan beyond two ranks, on map sizes that are no multiple of 12 x world (and smaller than the
+    world: ranks that own no row of a group).  Replicas bitwise equal after the all-gathers, every group's rows tile [0, n) over the
+    ranks in rank order, and the result equals the single-process step on the summed gradient up to the summation order of `world`
+    fp32 terms (two ranks: bitwise, the test above)."""
+    from splat_slam_amd.parallel import WIDTHS, Zero1Plan
+    out = mp.Manager().dict()
+    mp.spawn(_zero1_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    res = [out[r] for r in range(world)]
+    start = res[0][0]
+    for r in range(1, world):
+        assert torch.equal(res[r][2], res[0][2]) and torch.equal(res[r][3], res[0][3]), r
+    for name, _ in WIDTHS:
+        edge = 0
+        for r in range(world):
+            a, b = res[r][4][name]
+            assert b >= a
+            if b > a:
+                assert a == edge, (name, r, a, edge)
+                edge = b
+        assert edge == n, (name, edge)
+    ref = Zero1Plan(n, world, 0)
+    shapes = {"xyz": (n, 3), "f_dc": (n, 3), "opacity": (n, 1), "scaling": (n, 3), "rotation": (n, 4)}
+    lrs = {"xyz": 1e-3, "f_dc": 2.5e-3, "opacity": 0.05, "scaling": 6e-3, "rotation": 1e-3}
+    P = {name: ref.view(start.clone(), name, shapes[name]).clone().double() for name, _ in WIDTHS}
+    M = {name: torch.zeros(shapes[name], dtype=torch.float64) for name, _ in WIDTHS}
+    V = {name: torch.zeros(shapes[name], dtype=torch.float64) for name, _ in WIDTHS}
+    for step in (1, 2, 3):
+        for name, _ in WIDTHS:
+            g = sum(ref.view(res[r][1][step - 1], name, shapes[name]).double() for r in range(world))
+            _torch_group_step(name, P[name], g, M[name], V[name], lrs[name], step, 10.0 / (3.0 * n))
+    for name, _ in WIDTHS:
+        assert torch.allclose(ref.view(res[0][2], name, shapes[name]).double(), P[name], atol=2e-6, rtol=1e-5), name
+        assert torch.allclose(ref.view(res[0][3], name, shapes[name]).double(), M[name], atol=2e-6, rtol=1e-5), name

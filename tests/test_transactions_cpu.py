@@ -115,7 +115,7 @@ def _worker(rank, world, port, out):
     from splat_slam_amd.parallel import Comm
     f, log = _loop(), []
     f.set_parallel(world, rank, split_views=True, sync="allreduce", comm=Comm())
-    answers = [["cam 3"], []] if rank == 1 else [[], []]          # only rank 1 sees a truncated forward
+    answers = [["cam 3"], []] if rank == world - 1 else [[], []]          # only the LAST rank sees a truncated forward
 
     def span():
         _fake_iteration(f, log)
@@ -130,14 +130,20 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_replay_together_over_gloo():
-    world, port = 2, _free_port()
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_all_ranks_replay_together_over_gloo(world):
+    port = _free_port()
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    (n0, r0, first0, s0), (n1, r1, first1, s1) = out[0], out[1]
-    assert n0 == 4 and n1 == 4 and r0 == 1 and r1 == 1          # two launches, replayed once, on BOTH ranks
-    assert first0 == [] and first1 == ["cam 3"]
-    _equal(s0, s1)
+    for r in range(world):
+        n, rep, first, st = out[r]
+        assert n == 4 and rep == 1, (r, n, rep)                 # two launches, replayed once, on EVERY rank
+        assert first == (["cam 3"] if r == world - 1 else [])
+        _equal(st, out[0][3])
+    s0 = out[0][3]
     ref, rlog = _loop(), []
     ref._read_overflows = lambda: []
     for _ in range(2):
