@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 9
+#define SGR_ABI_VERSION 10
 
 typedef enum SgrStatus {
   SGR_OK = 0,

@@ -170,7 +170,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.sgr_abi_version() != 9:
+        if h.sgr_abi_version() != 10:
             raise ImportError("libsplat_hip.so ABI version mismatch")
         _lib = h
     return _lib

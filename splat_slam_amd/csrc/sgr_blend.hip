@@ -27,8 +27,16 @@
 #ifndef SGR_TILE_WAVES
 #define SGR_TILE_WAVES 5      // fused tile kernel: 84 VGPRs; 4 waves per SIMD measured 10 % slower, 6 (80 VGPRs, 4 spilled) no faster
 #endif
+// The stand-alone backward is the kernel of FRESH maps' drop-in path and of the north-star roofline: lists of ~11, latency hidden by
+// resident waves.  Round 6's row-wise loop cost it its sixth wave per SIMD (74 -> 85 VGPRs: light scene 78 -> 83 us despite 5 % fewer
+// instructions); with HALF rows per outer iteration of a 64-lane chunk (74.5 instead of 66 instructions per pair there, 81 in round 5)
+// it fits 80 registers again -- one value spilled around the 64-lane loop, stored and reloaded once per CHUNK.  The fused kernel
+// keeps whole rows: its LDS slice bounds it to 5 waves per SIMD anyway.
 #ifndef SGR_BWD_WAVES
-#define SGR_BWD_WAVES 5       // stand-alone backward
+#define SGR_BWD_WAVES 6       // stand-alone backward
+#endif
+#ifndef SGR_BWD_KPR64
+#define SGR_BWD_KPR64 2       // stand-alone backward: pairs per outer iteration of a 64-lane chunk (see bwd_chunk2)
 #endif
 
 namespace sgr {
@@ -372,14 +380,15 @@ struct SrcStaged {
 // three gradient sums that carry a factor dy (sum G dL/dG dy, ... dx dy, ... dy^2 = dy * or dy^2 * a ROW's sum of G dL/dG (dx)) -- is
 // formed once per row, and the lane's dx against its (at most four) pair columns once per CHUNK; the coordinates come from the
 // tile's position, not from LDS.  80 -> 66 instructions per iteration at 64 lanes.
-template <int GW, typename SRC, bool STASH = false>
+template <int GW, typename SRC, bool STASH = false, int KPR64 = 4>
 __device__ __forceinline__ void bwd_chunk2(
     int lane, int start, int end, bool carry, int tx, int ty, const float4* pixA2 /*LDS*/, float4* pixB2 /*LDS*/, const SRC& src,
     const LOff& L, float4* __restrict__ partials, const float* stash = nullptr /*LDS: exp2(-npow) of the forward walk, see blend_fwd_kernel*/) {
   constexpr int PP = kWave / GW;                 // pixel pairs the wave works on at once
-  constexpr int KPR = PP >= 4 ? 1 : 4 / PP;      // pairs of one row that ONE lane meets (64 lanes: 4, 32: 2, narrower: 1)
+  constexpr int KPR = GW == 64 ? KPR64 : (GW == 32 ? 2 : 1);   // pairs of one row that ONE lane meets per outer iteration (64 lanes: 4 -- or 2: fewer registers --, 32: 2, narrower: 1)
   constexpr int KST = PP >= 4 ? 0 : PP;          // ... their distance in pair columns
-  constexpr int RPO = PP >= 4 ? PP / 4 : 1;      // rows the wave covers per outer iteration (8 lanes: 2, 4 lanes: 4)
+  constexpr int PPO = PP >= 4 ? PP : PP * KPR;   // pairs the wave covers per outer iteration (a whole row = 4 or a part of one)
+  constexpr int KCOL = PP >= 4 ? 1 : 4 / PP;     // pair columns of a row that one lane meets at all
   // (opaque to the optimiser: the five instantiations sit in one loop, and hoisting each one's lane arithmetic out of it
   //  cost more live registers than the kernel has at 5 waves per SIMD -- they were spilled to scratch: +37 MB of writes per launch)
   asm volatile("" : "+v"(lane));
@@ -404,10 +413,10 @@ __device__ __forceinline__ void bwd_chunk2(
   // dx = mx - x of their one or two columns in registers for the whole chunk; a 64-wide chunk meets all four columns, which are the same
   // for every lane: their x live in SGPRs (eight VGPRs of dx put the fused kernel over its 96) and dx is ONE packed subtract per pair
   const int k0 = sub & 3, row0 = sub >> 2;
-  v2f dxs[KPR];
-  float xs0[KPR], xs1[KPR];
+  v2f dxs[KCOL];
+  float xs0[KCOL], xs1[KCOL];
 #pragma unroll
-  for (int h = 0; h < KPR; ++h) {
+  for (int h = 0; h < KCOL; ++h) {
     const float xf = (float)(tx * kTile + 2 * (k0 + h * KST));
     if constexpr (GW == kWave) {
       xs0[h] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xf)));
@@ -424,27 +433,32 @@ __device__ __forceinline__ void bwd_chunk2(
     live = __builtin_amdgcn_ballot_w64(nc_mine > start);
   }
   const int gp0 = row0 * 4 + k0;                 // this lane's pair in the wave's first outer iteration
-  float yf = (float)(ty * kTile + row0);
+  const float y0f = (float)(ty * kTile + row0);
+  float yrun = y0f;                              // (whole rows per outer iteration: the row's y is a running sum, no conversion in the loop)
 
 #pragma unroll 1
-  for (int o = 0; o < kTile / RPO; ++o, yf += (float)RPO) {
-    if (GW == kWave && ((live >> (8 * o)) & 0xffull) == 0ull) continue;
+  for (int o = 0; o < 32 / PPO; ++o, yrun += (float)(PPO / 4)) {
+    const int prow = (o * PPO) >> 2;             // the tile row of this outer iteration's pairs (narrow groups: of the group's first row)
+    if (GW == kWave && ((live >> (8 * prow)) & 0xffull) == 0ull) continue;
+    const float yf = PPO >= 4 ? yrun : y0f + (float)prow;
     const float dy = my - yf;
-    const float Bdy = B * dy, Cdy2 = (Cc * dy) * dy, dysq = dy * dy;
-    v2f r_gg = {0.f, 0.f}, r_gx = {0.f, 0.f};    // the row's sums of G dL/dG and G dL/dG dx (KPR > 1)
+    const float Bdy = B * dy, Cdy2 = (Cc * dy) * dy;
+    v2f r_gg = {0.f, 0.f}, r_gx = {0.f, 0.f};    // a half row's sums of G dL/dG and G dL/dG dx (KPR > 1)
 #pragma unroll
     for (int h = 0; h < KPR; ++h) {
       // (the unrolled pairs of a row stay one after the other: left alone, the scheduler moves the LDS reads of all four to the top and
       //  the kernel spills ~200 registers)
       if constexpr (KPR > 1) __builtin_amdgcn_sched_barrier(0);
-      const int gp = o * (RPO * 4) + gp0 + h * KST;      // this lane's pixel pair (same for the whole group)
+      const int gp = o * PPO + gp0 + h * KST;             // this lane's pixel pair (same for the whole group)
       const float4 a0 = pixA2[gp * 2], a1 = pixA2[gp * 2 + 1];     // LDS, broadcast inside the group
       const float4 b0 = pixB2[gp * 2];
       const int2 ncp = *(const int2*)((const float*)(pixB2 + gp * 2 + 1) + 2);
       const int nc0 = ncp.x, nc1 = ncp.y;
       v2f dx;
-      if constexpr (GW == kWave) dx = splat2(mx) - (v2f){xs0[h], xs1[h]};
-      else dx = dxs[h];
+      if constexpr (GW == kWave) {
+        if constexpr (KPR == KCOL) dx = splat2(mx) - (v2f){xs0[h], xs1[h]};
+        else dx = splat2(mx) - ((o & 1) ? (v2f){xs0[2 + h], xs1[2 + h]} : (v2f){xs0[h], xs1[h]});      // (half rows: a scalar select)
+      } else dx = dxs[h];
       v2f G;
       bool ok0 = idx < nc0, ok1 = idx < nc1;
       if constexpr (STASH) {
@@ -498,9 +512,18 @@ __device__ __forceinline__ void bwd_chunk2(
       const v2f gxv = gg * dx;
       s_gxx = __builtin_elementwise_fma(gxv, dx, s_gxx);
       if constexpr (KPR > 1) {
-        r_gg = h == 0 ? gg : r_gg + gg;
-        r_gx = h == 0 ? gxv : r_gx + gxv;
-        // (pins this pair's seven accumulations HERE: the optimiser otherwise sinks the sums of all unrolled pairs of the row behind the
+        // the sums that carry a factor dy are folded per HALF row (two pairs), whatever part of a row an outer iteration covers: the
+        // stand-alone backward runs half rows (SGR_BWD_KPR64), the fused kernel whole rows, and the two must stay bitwise equal
+        r_gg = (h & 1) == 0 ? gg : r_gg + gg;
+        r_gx = (h & 1) == 0 ? gxv : r_gx + gxv;
+        if ((h & 1) == 1) {
+          a_o += r_gg;
+          s_gx += r_gx;
+          s_gy = __builtin_elementwise_fma(r_gg, splat2(dy), s_gy);
+          s_gxy = __builtin_elementwise_fma(r_gx, splat2(dy), s_gxy);
+          s_gyy = __builtin_elementwise_fma(r_gg, splat2(dy * dy), s_gyy);
+        }
+        // (pins this pair's accumulations HERE: the optimiser otherwise sinks the sums of all unrolled pairs of the row behind the
         //  last one -- everything they read stays live across the row: 137 VGPRs)
         asm volatile("" : "+v"(a_r), "+v"(a_g), "+v"(a_b), "+v"(a_d), "+v"(s_gxx), "+v"(r_gg), "+v"(r_gx));
       } else {
@@ -508,15 +531,8 @@ __device__ __forceinline__ void bwd_chunk2(
         s_gx += gxv;
         s_gy = __builtin_elementwise_fma(gg, splat2(dy), s_gy);
         s_gxy = __builtin_elementwise_fma(gxv, splat2(dy), s_gxy);
-        s_gyy = __builtin_elementwise_fma(gg, splat2(dysq), s_gyy);
+        s_gyy = __builtin_elementwise_fma(gg, splat2(dy * dy), s_gyy);
       }
-    }
-    if constexpr (KPR > 1) {
-      a_o += r_gg;
-      s_gx += r_gx;
-      s_gy = __builtin_elementwise_fma(r_gg, splat2(dy), s_gy);
-      s_gxy = __builtin_elementwise_fma(r_gx, splat2(dy), s_gxy);
-      s_gyy = __builtin_elementwise_fma(r_gg, splat2(dysq), s_gyy);
     }
   }
   float t_gx = s_gx.x + s_gx.y, t_gy = s_gy.x + s_gy.y, t_gxx = s_gxx.x + s_gxx.y, t_gxy = s_gxy.x + s_gxy.y,
@@ -586,7 +602,7 @@ __device__ __forceinline__ void bwd_chunk2(
 // The backward of one tile given this lane's pixel state (pxA = dL/dC r, g, b and dL/dD; pxB[0] = final transmittance,
 // pxB[2] = last contributor as uint bits) and a source for the tile's sorted splats.  Used by blend_bwd_kernel (state read
 // back from HBM) and by the fused tile kernel (state still in the forward walk's registers).
-template <typename SRC>
+template <typename SRC, int KPR64 = 4>
 __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty, const float pxA[4], float pxB[3],
                                               const float* __restrict__ bg, float4* pixA /*LDS*/, float4* pixB /*LDS*/, const SRC& src,
                                               const LOff& L, float4* __restrict__ partials, const float* stash = nullptr) {
@@ -624,7 +640,7 @@ __device__ __forceinline__ void tile_backward(int lane, int eff, int tx, int ty,
         continue;
       }
     }
-    if (gw == 64) bwd_chunk2<64>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
+    if (gw == 64) bwd_chunk2<64, SRC, false, KPR64>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
     else if (gw == 32) bwd_chunk2<32>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
     else if (gw == 16) bwd_chunk2<16>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
     else if (gw == 8) bwd_chunk2<8>(lane, start, end, carry, tx, ty, pixA, pixB, src, L, partials);
@@ -1098,7 +1114,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_BWD
   }
   if (eff == 0) return;
   const SrcPointList src = {point_list, begin, grec, saved, tx, ty, cap};
-  tile_backward(lane, eff, tx, ty, pxA, pxB, bg, pixbuf[0], pixbuf[1], src, L, partials);
+  tile_backward<SrcPointList, SGR_BWD_KPR64>(lane, eff, tx, ty, pxA, pxB, bg, pixbuf[0], pixbuf[1], src, L, partials);
 }
 
 template <int SORT_MAX, bool FUSED>

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
         assert name in nat.SIGNATURES, f"{name} has no ctypes signature in splat_slam_amd/_native.py"
     assert sorted(nat.SIGNATURES) == declared
     lib = nat.lib()
-    assert lib.sgr_abi_version() == 9
+    assert lib.sgr_abi_version() == 10
     assert isinstance(nat.last_error(), str)
 
 
@@ -39,7 +39,7 @@ def test_dropin_cpp_extension_builds_loads_and_links_the_c_abi():
     assert os.path.exists(path)
     import diff_gaussian_rasterization as drg
     ext = drg.native_extension()
-    assert ext is not None and ext.abi_version() == 9
+    assert ext is not None and ext.abi_version() == 10
     for name in ("try_rasterize", "mapping_loss", "adam_group_step", "densify_stats_views", "saved_block_of", "check_overflow", "stats",
                  "set_capacity", "profile_enable", "profile_read"):
         assert callable(getattr(ext, name)), name

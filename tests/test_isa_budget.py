@@ -84,7 +84,7 @@ def test_backward_loops_stay_within_their_instruction_budget(fused_asm):
     stash = [per_pair(l) for l in loops if not l["exp"]]                             # 16 / 8 / 4 lanes reading the G stash
     assert len(wide) >= 2 and len(half) >= 2 and len(narrow) >= 6 and len(stash) >= 3, loops
     assert all(l["rcp"] == 8 for l in loops if l["bcast31"]) and all(l["rcp"] == 4 for l in loops if l["bcast15"] and not l["bcast31"]), loops
-    assert max(wide) <= 70 and min(wide) <= 66, wide           # (round 5: 81-83 at 64 lanes; round 6: 66 -- 264 per row of four pairs; one copy 69.5)
+    assert max(wide) <= 70 and min(wide) <= 67.5, wide         # (round 5: 81-83 at 64 lanes; round 6: 67 -- 269 per row of four pairs, the dy sums folded per half row)
     assert max(half) <= 73, half                               # (71)
     assert max(narrow) <= 67 and min(narrow) <= 59, narrow     # (16 lanes: 65 (round 5: 75), 8: 61, 4: 57-58)
     assert max(stash) <= 59 and min(stash) <= 52, stash        # (16 lanes: 57 (round 5: 62), 8: 53, 4: 50)
