@@ -57,7 +57,7 @@ __device__ __forceinline__ void file_overfull_runs(char* saved, char* scratch, c
 //   (1) segment bases of the partial-slot offsets;
 //   (2) the number of visible Gaussians (and the segments' bases in the compact visible list; the list itself is written by the
 //       first blocks of the tile kernel's launch, sgr_blend.hip: nothing before the backward reads it).
-// The later of blocks 0 and 1 folds the two pair counts into the header.  A fresh map (lists within the 64-entry buckets)
+// The later of blocks 0 and 1 folds the two pair counts into the header.  A map whose lists stay within the buckets (kBucket = 256 since round 6)
 // therefore needs no third binning launch at all.
 __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, int k3_follows) {
   __shared__ uint32_t red[16];

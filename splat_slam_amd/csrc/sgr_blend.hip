@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   }
 
   // unsorted keys: the tile's bucket (filled by K1) unless the tile had more than kBucket pairs (then its exact run).
-  // The bucket's address does not depend on the tile's range: lane j fetches bucket entry j (kBucket = one wave) in the
+  // The bucket's address does not depend on the tile's range: lane j fetches bucket entry j (kBucket >= one wave) in the
   // same round trip as the range -- the first half of the bucket, which covers 98 % of the tiles of a SLAM view; the
   // rest follows once the count is known (entries behind the tile's count are ignored).
   const uint64_t* __restrict__ bucket = (const uint64_t*)(tab.scratch[vw] + L.o_bucket) + (size_t)tile * kBucket;
@@ -843,7 +843,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   } else {
     mode = 2;                                 // slow path: in place in HBM through device-coherent accesses
     uint64_t* e = entries + begin;
-    if (lane < kBucket) __hip_atomic_store(e + lane, bucket[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the bucket part joins its run)
+    for (int i = lane; i < kBucket; i += kWave) __hip_atomic_store(e + i, bucket[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the bucket part joins its run)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     __builtin_amdgcn_wave_barrier();
     wave_sort_any(count, lane,

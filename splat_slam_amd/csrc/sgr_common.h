@@ -44,7 +44,16 @@ constexpr int kRngStride = 2;          // uint2 units between two tiles' (start,
 // Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the
 // key goes straight into the tile's fixed bucket -- no second pass.  Only tiles with more than kBucket pairs are re-scattered
 // by scatter_kernel into the exactly sized runs (ranges[t].x carries kOverfull for them).
-constexpr int kBucket = 64;
+// Round 6: 256 entries (rounds 2-5: 64).  On a converged map (lists of 65-256) a third to a half of all pairs used to leave K1 through
+// the overflow list -- a 16-byte entry appended behind a per-view cursor inside a wave-serial loop, read and filed again by K3 --;
+// with buckets that hold such lists whole K1 takes 0.186 -> 0.153 ms on the opaque bench scene, K3 is not launched at all (0.018 ms),
+// the iteration goes from 0.88 to 0.835 ms and a 40-frame session from 51-55 to 48-49 ms per keyframe (same-box A/B of three builds,
+// scripts/micro/r06_bucket_ab.sh: 64 / 128 / 256; bitwise the same maps).  Costs address space only: 2 KB per tile and view that
+// nobody touches beyond the tile's count (9.8 MB per 640x480 view).  A fresh map (lists <= 32) is unaffected.
+#ifndef SGR_BUCKET
+#define SGR_BUCKET 256
+#endif
+constexpr int kBucket = SGR_BUCKET;
 constexpr uint32_t kOverfull = 0x80000000u;
 constexpr int kSeg = 256;              // Gaussians per preprocess segment (one 256-thread block), see preprocess_fwd_kernel
 constexpr int kSegShift = 8;

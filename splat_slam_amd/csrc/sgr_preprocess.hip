@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     };
     // Binning of a batch of (up to) four operations per lane; desc(jj) -> (on, view, key) of operation jj, geo[jj] its block.
     // A pair whose rank fits the tile's bucket is written there; the others join their view's overflow list.  On a converged
-    // map a third of all pairs overflow (lists of ~100 against kBucket = 64) and the list cursor is ONE word per view, so the
+    // map a third of all pairs overflowed the 64-entry buckets of rounds 2-5 (lists of ~100; round 6: kBucket = 256 holds them whole) and the list cursor is ONE word per view, so the
     // append is aggregated as far as it goes: per batch the wave takes ONE returning atomic per view present in it (5-bit-plane
     // ballots give every lane its offset), where one atomic per (operation, tile) -- sixteen dependent round trips per batch
     // -- cost 220 of K1's 395 us.

@@ -608,10 +608,11 @@ class FusedMappingLoop(MappingLoop):
         return R, ov
 
     def _build_class(self):
-        """What the library derives from the hint: -1 nothing measured yet, 0 lists within the 64-entry buckets (no scatter launch),
-        1 / 2 / 3 the light / mid / heavy sort build of the tile kernels."""
+        """What the library derives from the hint: -1 nothing measured yet, 0 a fresh map (lists <= 64: K1 keeps one view part per
+        segment), 1 lists within the 256-entry buckets (no scatter launch), 2 / 3 / 4 the light / mid / heavy sort build of the tile
+        kernels (sgr_common.h: k1_parts_for, kBucket; sgr_blend.hip: blend_build)."""
         m = self._max_list()
-        return -1 if m == 0 else (0 if m <= 64 else (1 if m <= 768 else (2 if m <= 1536 else 3)))
+        return -1 if m == 0 else (0 if m <= 64 else (1 if m <= 256 else (2 if m <= 768 else (3 if m <= 1536 else 4))))
 
     def _estimate_pairs(self, cam, vb):
         """Pair count of a camera whose buffers are new.  A synchronous probe forward per camera and map size cost a converged

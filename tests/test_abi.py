@@ -74,7 +74,7 @@ def test_workspace_sizes_cover_every_carved_array():
         saved, scratch = lib.sgr_saved_bytes(n, h, w, cap), lib.sgr_scratch_bytes(n, h, w, cap)
         # saved: 64-B record + 3 index words per Gaussian, 4 B per pair, (T, last contributor) per pixel of whole tiles
         assert saved >= 64 * n + 12 * n + 4 * cap + 8 * 64 * tiles
-        # scratch: forward keys (runs + one 64-entry bucket per tile) FOLLOWED by (not aliased with: the fused tile kernel
+        # scratch: forward keys (runs + one bucket of >= 64 entries per tile: 256 since round 6) FOLLOWED by (not aliased with: the fused tile kernel
         # writes partials while other tiles still read their keys) 48-B partials + 64-B records
         assert scratch >= (8 * cap + 8 * 64 * tiles) + (48 * cap + 64 * n)
         assert lib.sgr_saved_bytes(n + 256, h, w, cap) > saved and lib.sgr_saved_bytes(n, h + 8, w, cap) > saved
