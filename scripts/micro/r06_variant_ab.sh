@@ -1,8 +1,9 @@
-# round 6 experiment: 128-entry tile buckets (SGR_BUCKET=128 build in splat_slam_amd/lib_b128) against the default 64, same box, alternating
+# round 6: same-box A/B of library BUILDS (splat_slam_amd/lib_<name>/libsplat_hip.so; "default" = the tree's own build), alternating twice.
+#   bash scripts/micro/r06_variant_ab.sh default p1 p4
 cd $GRAFT_REPO_ROOT
 for i in 1 2; do
- for lib in b128 b256; do
-  export SPLAT_HIP_LIB=$GRAFT_REPO_ROOT/splat_slam_amd/lib_$lib/libsplat_hip.so
+ for lib in "$@"; do
+  if [ $lib = default ]; then unset SPLAT_HIP_LIB; else export SPLAT_HIP_LIB=$GRAFT_REPO_ROOT/splat_slam_amd/lib_$lib/libsplat_hip.so; fi
   python - <<PY
 import json, os, sys
 sys.path.insert(0, os.getcwd())

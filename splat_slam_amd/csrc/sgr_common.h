@@ -37,8 +37,11 @@ constexpr int kK1MaxParts = 4;
 // (opaque bench scene 0.21 -> 0.185 ms; a fresh map loses 8 us to the doubled cull and keeps one part, and so does a map of
 // more than half a million Gaussians, where the cull itself is the larger half of K1: 1.5 M Gaussians, 0.913 ms per iteration
 // with one part, 0.997 with two).
+#ifndef SGR_K1_DENSE_PARTS
+#define SGR_K1_DENSE_PARTS 2
+#endif
 __host__ __device__ inline int k1_parts_for(int nseg, int longest_list_hint = 0) {
-  return nseg >= 768 ? ((longest_list_hint > 64 && nseg < 2048) ? 2 : 1) : (nseg >= 384 ? 2 : kK1MaxParts);
+  return nseg >= 768 ? ((longest_list_hint > 64 && nseg < 2048) ? SGR_K1_DENSE_PARTS : 1) : (nseg >= 384 ? 2 : kK1MaxParts);
 }
 constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
 // Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the
@@ -48,7 +51,7 @@ constexpr int kRngStride = 2;          // uint2 units between two tiles' (start,
 // the overflow list -- a 16-byte entry appended behind a per-view cursor inside a wave-serial loop, read and filed again by K3 --;
 // with buckets that hold such lists whole K1 takes 0.186 -> 0.153 ms on the opaque bench scene, K3 is not launched at all (0.018 ms),
 // the iteration goes from 0.88 to 0.835 ms and a 40-frame session from 51-55 to 48-49 ms per keyframe (same-box A/B of three builds,
-// scripts/micro/r06_bucket_ab.sh: 64 / 128 / 256; bitwise the same maps).  Costs address space only: 2 KB per tile and view that
+// scripts/micro/r06_variant_ab.sh on builds with -DSGR_BUCKET=64 / 128 / 256; bitwise the same maps).  Costs address space only: 2 KB per tile and view that
 // nobody touches beyond the tile's count (9.8 MB per 640x480 view).  A fresh map (lists <= 32) is unaffected.
 #ifndef SGR_BUCKET
 #define SGR_BUCKET 256
