@@ -15,7 +15,7 @@ namespace sgr {
 
 void launch_preprocess_fwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, hipStream_t);
 void launch_preprocess_bwd(const ViewTab&, int, const LOff&, const Common&, const SgrInputs&, const SgrGradInputs&, const FusedAdam*,
-                           hipStream_t);
+                           hipStream_t, bool mapping_loop = false);
 void launch_binning(const ViewTab&, int, const LOff&, hipStream_t);
 void launch_zero_heads(const ViewTab&, int, const LOff&, size_t, hipStream_t);
 void launch_blend_fwd(const ViewTab&, int, const LOff&, const float*, const LossTab*, const LossCoef*, hipStream_t);
@@ -458,7 +458,7 @@ static int map_views_impl(int32_t num_views, const SgrMapView* views, const SgrI
       launch_mapping_loss_final(lt, nv, HW, L.ntiles, alpha, st);
     }
     if (!fused_blend) launch_blend_bwd(tab, nv, d, f.settings.bg, &lt, &lc, st);
-    launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, fuse ? fused : nullptr, st);
+    launch_preprocess_bwd(tab, nv, d, cm, *in, *grads, fuse ? fused : nullptr, st, /*mapping_loop=*/true);
     if (fuse && fused_done) *fused_done = true;
   }
   HIP_TRY(hipGetLastError());

@@ -962,6 +962,11 @@ __device__ __forceinline__ void preprocess_bwd_one_view(
 // Phase 1 (dense): thread = entry of a view's compact visible list; grid = (ceil(N/256), views), blocks beyond the
 // list exit at once.  Writes one 64-byte gradient record per (view, visible Gaussian) and the view's pose partials.
 // With a single view the rarely used extras (SH degree > 0, precomputed colour / covariance) go straight to the outputs.
+// LPG = lanes per Gaussian.  1: thread = list entry (a fresh map: runs of a few slots).  4: a QUAD of lanes = list entry (dense maps, round 6):
+// the quad sums its Gaussian's run together -- lane q takes slots q, q + 4, ... --, sixteen Gaussians per wave instead of 64, so the
+// chain of dependent round trips a wave goes through is a quarter as long and four times as many waves hide it; only the quad's
+// first lane goes on to the projection backward.
+template <int LPG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) preprocess_bwd_dense_kernel(
     ViewTab tab, LOff L, Common cm, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -969,8 +974,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   const int v = blockIdx.y;
   const char* saved = tab.saved[v];
   const int V = (int)((const SavedHeader*)(saved + L.o_hdr))->num_visible;
-  if ((int)(blockIdx.x * blockDim.x) >= V) return;             // whole block beyond the list (uniform)
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int kPerBlock = 256 / LPG;
+  if ((int)(blockIdx.x * kPerBlock) >= V) return;             // whole block beyond the list (uniform)
+  const int t = blockIdx.x * kPerBlock + (int)threadIdx.x / LPG;
   const bool have = t < V;
   const int i = have ? (int)((const uint32_t*)(saved + L.o_vis_list))[t] : 0;
   uint4 q3 = make_uint4(0u, 0u, 0u, 0u);
@@ -1008,7 +1014,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 #pragma unroll
     for (int j = 0; j < 10; ++j) gsum[j] = 0.f;
     const int longest = __builtin_amdgcn_readfirstlane(wave_max_i32((int)my_cnt));
-    if (longest <= 6) {              // a fresh map (splats of a few tiles): every lane sums its own short run
+    constexpr uint32_t kLongRunQuad = 192u;       // (a quad takes 12 slots per batch: beyond 16 batches the whole wave is faster even one Gaussian at a time)
+    if constexpr (LPG == 4) {
+      const uint32_t q = (uint32_t)lane & 3u;
+      const uint32_t c = my_cnt > kLongRunQuad ? 0u : my_cnt;
+      for (uint32_t k0 = q; k0 < c; k0 += 12u) {
+        float4 ld[9];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const uint32_t k = k0 + 4u * (uint32_t)u;
+          const uint64_t e = (uint64_t)my_off + k;
+          const bool in = k < c && (int64_t)e < L.cap && !slot_unwritten(foot, my_r01, my_r23, k);
+#pragma unroll
+          for (int w = 0; w < 3; ++w) ld[3 * u + w] = in ? partials[e * 3 + w] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const float4 p0 = ld[3 * u], p1 = ld[3 * u + 1], p2 = ld[3 * u + 2];
+          gsum[0] += p0.x; gsum[1] += p0.y; gsum[2] += p0.z; gsum[3] += p0.w; gsum[4] += p1.x;
+          gsum[5] += p1.y; gsum[6] += p1.z; gsum[7] += p1.w; gsum[8] += p2.x; gsum[9] += p2.y;
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 4; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) gsum[j] += __shfl_xor(gsum[j], off);
+    } else if (longest <= 6) {              // a fresh map (splats of a few tiles): every lane sums its own short run
       for (uint32_t k0 = 0; k0 < my_cnt; k0 += 3u) {         // (same: three slots' loads in flight together)
         float4 ld[9];
 #pragma unroll
@@ -1027,7 +1058,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
       }
     } else
 #pragma unroll 1
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < (LPG == 1 ? 8 : 0); ++r) {
       const int src = r * 8 + grp;                    // the lane whose Gaussian this group sums in round r
       const uint32_t o = (uint32_t)__shfl((int)my_off, src), c_all = (uint32_t)__shfl((int)my_cnt, src);
       const uint32_t c = c_all > kLongRun ? 0u : c_all;           // (long runs: the whole wave, below)
@@ -1071,8 +1102,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     // would keep ONE 8-lane group busy for c / 24 dependent round trips while the rest of the wave waits (the dense backward
     // was the most expensive kernel of a session's first 40 keyframes: 0.29 ms per launch).  Those runs are summed by the
     // whole wave, one Gaussian at a time: 192 slots per batch.
-    if (longest > (int)kLongRun) {
-      unsigned long long lm = __ballot(my_cnt > kLongRun);
+    constexpr uint32_t kWholeWave = LPG == 4 ? kLongRunQuad : kLongRun;
+    if (longest > (int)kWholeWave) {
+      unsigned long long lm = __ballot(my_cnt > kWholeWave && (LPG == 1 || (lane & (LPG - 1)) == 0));
       while (lm != 0ull) {
         const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
         lm &= lm - 1ull;
@@ -1104,13 +1136,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         for (int off = 1; off < 64; off <<= 1)
 #pragma unroll
           for (int j = 0; j < 10; ++j) part[j] += __shfl_xor(part[j], off);
-        if (lane == src)
+        if ((lane & ~(LPG - 1)) == src)      // (the Gaussian's lane; quad mode: its four lanes)
 #pragma unroll
           for (int j = 0; j < 10; ++j) gsum[j] = part[j];
       }
     }
   }
-  if (!have) return;
+  if (!have || (LPG > 1 && (threadIdx.x & (LPG - 1)) != 0)) return;
   {
     // the slots hold RAW sums (sgr_blend.hip: gx gy gxx gxy | o r g b | gyy d - -); this Gaussian's conic (A, B, C) and the
     // half-image factors turn their totals into dL/dmean2D (NDC-scaled pixel units) and the true partials of the conic
@@ -1271,11 +1303,25 @@ void launch_preprocess_fwd(const ViewTab& tab, int nviews, const LOff& L, const 
 }
 
 void launch_preprocess_bwd(const ViewTab& tab, int nviews, const LOff& L, const Common& cm, const SgrInputs& in,
-                           const SgrGradInputs& g, const FusedAdam* fused, hipStream_t st) {
+                           const SgrGradInputs& g, const FusedAdam* fused, hipStream_t st, bool mapping_loop) {
   if (L.N <= 0) return;
   ProfScope prof(PK_PRE_BWD, st);
-  hipLaunchKernelGGL(preprocess_bwd_dense_kernel, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
-                     in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, g.dL_dshs, g.dL_dcov3D_precomp, g.accumulate);
+  // Quad mode (four lanes per list entry) for the mapping loops' SINGLE-view iterations -- initialize_map's 1050 and final_refine's
+  // thousands: one view's list is 300-500 waves at 64 entries per wave, less than half a wave per SIMD, and a young map's splats cover
+  // hundreds to thousands of bins: the waves walk their long runs one Gaussian at a time.  A quarter of the entries per wave = four
+  // times the waves and a quarter of the serial chain: the initialisation keyframe 358 -> 290 ms (same-box A/B, SGR_DENSE_QUAD=0/1);
+  // a 12-view batch has waves enough and is 3 % slower in quad mode (light +4 us, opaque +4 us): it keeps thread = entry.  The rule
+  // is a function of the CALL (sgr_map_views / sgr_map_step / sgr_map_run with one view -- with or without the fused optimiser tail, so
+  // that the two stay bitwise equal --, never of measured history: two identical calls round alike); the drop-in's sgr_backward keeps
+  // thread = entry (its batched and per-view backward are compared bit for bit).  SGR_DENSE_QUAD=0 / 1 forces a mode.
+  static const int forced = []() { const char* e = getenv("SGR_DENSE_QUAD"); return e ? atoi(e) : -1; }();
+  const bool quad = forced >= 0 ? forced != 0 : (mapping_loop && nviews == 1);
+  if (quad)
+    hipLaunchKernelGGL(preprocess_bwd_dense_kernel<4>, dim3(L.pre_blocks * 4, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
+                       in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, g.dL_dshs, g.dL_dcov3D_precomp, g.accumulate);
+  else
+    hipLaunchKernelGGL(preprocess_bwd_dense_kernel<1>, dim3(L.pre_blocks, nviews), dim3(256), 0, st, tab, L, cm, in.means3D, in.shs,
+                       in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, g.dL_dshs, g.dL_dcov3D_precomp, g.accumulate);
   if (fused) {               // single-GPU mapping iteration: the gather rides in the optimiser pass (no gradient round trip)
     launch_gather_adam(tab, nviews, L, *fused, st);
     return;
