@@ -1,7 +1,8 @@
 """GPU box: the bench session (bench.py extra.session: 40 tracker frames, default hyper-parameters) under the host-path switches of
 FusedMappingLoop, alternating in ONE call so that box speed cancels.
     python scripts/session_ab.py [--repeat 2] [--out x.json]
-Variants (environment of a child process each): round-4 host path (SPLAT_SPAN_CACHE=0 SPLAT_VERIFY_ESTIMATES=1) vs round 5."""
+Variants (environment of a child process each): round-4 host path (SPLAT_SPAN_CACHE=0 SPLAT_VERIFY_ESTIMATES=1) vs round 5 (launch structs dropped at every keyframe: SPLAT_KEYFRAME_STRUCTS=0) vs round 6.
+--full: the 160-frame session (bench.py extra.session_full) instead."""
 import argparse
 import json
 import os
@@ -12,15 +13,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--repeat", type=int, default=2)
 ap.add_argument("--out", default=None)
+ap.add_argument("--full", action="store_true")
 ap.add_argument("--only", default=None, help="comma-separated variant names")
 a = ap.parse_args()
 CHILD = ("import json, sys; sys.path.insert(0, %r); import bench; sys.argv=['bench.py']; B = bench.Bench(bench.parse()); "
-         "r = B.session_leg(refine_iters=0); print('RESULT ' + json.dumps({k: r[k] for k in ('ms_per_keyframe', 'ms_per_keyframe_second_half', "
-         "'gaussians_final', 'psnr_all_keyframes_mean', 'overflow_events')}))" % ROOT)
+         "r = B.session_leg(refine_iters=0%s); print('RESULT ' + json.dumps({k: r[k] for k in ('ms_per_keyframe', 'ms_per_keyframe_second_half', "
+         "'gaussians_final', 'psnr_all_keyframes_mean', 'overflow_events')}))" % (ROOT, ", frames_n=160, step_of=160, warm_frames=0" if a.full else ""))
 VARIANTS = {"round4_host_path": {"SPLAT_SPAN_CACHE": "0", "SPLAT_VERIFY_ESTIMATES": "1"},
             "span_cache_only": {"SPLAT_SPAN_CACHE": "1", "SPLAT_VERIFY_ESTIMATES": "1"},
             "no_verify_only": {"SPLAT_SPAN_CACHE": "0", "SPLAT_VERIFY_ESTIMATES": "0"},
-            "round5_default": {}}
+            "round5_default": {"SPLAT_KEYFRAME_STRUCTS": "0"},
+            "round6_default": {}}
 if a.only:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in a.only.split(",")}
 res = {k: [] for k in VARIANTS}

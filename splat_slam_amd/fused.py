@@ -280,6 +280,7 @@ class FusedMappingLoop(MappingLoop):
         self.verify_estimates = os.environ.get("SPLAT_VERIFY_ESTIMATES", "0") == "1"
         self._span_cache = None    # (window, pool) SgrMapView arrays of the spans of one map() call (_span_arrays)
         self.cache_span_arrays = os.environ.get("SPLAT_SPAN_CACHE", "1") != "0"      # (0: A/B measurements of the host path)
+        self.keep_structs_over_keyframes = os.environ.get("SPLAT_KEYFRAME_STRUCTS", "1") != "0"   # (0: round-5 behaviour, for A/B)
         self._txn_pool = None      # snapshot buffers, reused while the tensor shapes stay
         self._replaying = False
         self.replayed_transactions = 0
@@ -604,7 +605,7 @@ class FusedMappingLoop(MappingLoop):
             old = self._build_class()
             self._list_hint[uid] = longest
             if self._build_class() != old:
-                self._views_dirty()            # the cached SgrMapViews carry the hint
+                self._hint_changed()           # the cached SgrMapViews carry the hint
         return R, ov
 
     def _build_class(self):
@@ -689,8 +690,12 @@ class FusedMappingLoop(MappingLoop):
         images=False: loss + gradients only (the rendered colour / depth / opacity are not written to HBM).
         slot=True: a pool entry of a span whose picks render in shared workspace slots: no workspace of its own."""
         vb = self._view(cam)
-        key = (cam._version, self._cap, id(cam.exposure_a), id(cam.original_image), vb.gt_depth.data_ptr(), initialization,
-               self.keyframe_optimizers is not None)
+        # (storage addresses, not id()s: an id can be re-used by the object that replaces a freed one -- the exposure parameters are
+        #  re-bound to their slab row by attach() / _grow())
+        row = self._exp.row_of(cam) if self._exp is not None else None
+        key = (cam._version, self._cap, cam.exposure_a.data_ptr(), cam.exposure_b.data_ptr(), cam.original_image.data_ptr(),
+               vb.gt_depth.data_ptr(), initialization, self.keyframe_optimizers is not None,
+               None if row is None else self._exp.grad.data_ptr() + 8 * row)
         if vb.mv is None:
             vb.mv = {}
         hit = vb.mv.get((images, slot))
@@ -723,7 +728,6 @@ class FusedMappingLoop(MappingLoop):
         mv.exposure_a = None if initialization else cam.exposure_a.data_ptr()
         mv.exposure_b = None if initialization else cam.exposure_b.data_ptr()
         mv.loss, mv.dL_dimage, mv.dL_ddepth = vb.loss.data_ptr(), vb.d_color.data_ptr(), vb.d_depth.data_ptr()
-        row = self._exp.row_of(cam) if self._exp is not None else None
         mv.dL_dexposure = vb.d_exp.data_ptr() if row is None else self._exp.grad.data_ptr() + 8 * row
         mv.dL_dtau = vb.d_tau.data_ptr() if self.keyframe_optimizers is not None else None
         mv.loss_scratch, mv.loss_scratch_bytes = vb.loss_scratch.data_ptr(), vb.loss_scratch.numel()
@@ -1128,7 +1132,12 @@ class FusedMappingLoop(MappingLoop):
             self._exp.attach(cam)                      # every camera writes its exposure gradient into its slab row
         self._exp.reset(rows)
         self._exp_rows = rows
-        self._views_dirty()
+        # (no _views_dirty() here any more: what a cached launch struct takes from the exposure slab -- the addresses of the camera's
+        #  a / b and of its gradient row -- is part of the struct's key (_map_view).  Dropping every camera's structs at EVERY keyframe
+        #  cost a late session ~190 rebuilds = 3-5 ms per keyframe with the GPU idle, growing with the number of keyframes.)
+        self._span_cache = None
+        if not self.keep_structs_over_keyframes:
+            self._views_dirty()
         pose_opt = bool(self.config["mapping"]["BA"]) and not self.config["mapping"]["Training"].get("gt_camera", False)
         self.keyframe_optimizers = None
         if pose_opt:                                   # pose deltas (off by default) stay on torch.optim.Adam
@@ -1142,6 +1151,17 @@ class FusedMappingLoop(MappingLoop):
                 groups.append({"params": [cam.cam_rot_delta], "lr": lr["cam_rot_delta"] * 0.5})
                 groups.append({"params": [cam.cam_trans_delta], "lr": lr["cam_trans_delta"] * 0.5})
             self.keyframe_optimizers = torch.optim.Adam(groups) if groups else None
+
+    def _hint_changed(self):
+        """The longest-list hint moved into another build class: the cached launch structs are PATCHED (one field), not dropped.
+        Dropping them (rounds 3-5: _views_dirty) re-made every camera's settings struct -- and late in a session, where the longest
+        list hovers around a class boundary, that happened at almost every keyframe: ~190 struct rebuilds per keyframe at 150
+        keyframes, with the GPU idle behind the capacity check (scripts/profile_session.py)."""
+        hint = self._max_list()
+        for vb in self._views.values():
+            for ent in (vb.mv or {}).values():
+                ent[1].ws.max_list_hint = hint
+        self._span_cache = None            # (its arrays hold COPIES of the structs)
 
     def _views_dirty(self):
         self._gen += 1

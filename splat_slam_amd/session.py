@@ -34,7 +34,9 @@ class MappingSession:
 
     # ---- keyframe management on the consumers of n_touched (mapper.py:744-831), batched over the window
     def _w2c(self, idxs):
-        return torch.stack([getWorld2View2(self.cameras[k].R, self.cameras[k].T) for k in idxs])
+        # the cameras cache getWorld2View2(R, T) (transposed, camera.py _matrices): the same bits without two linalg.inv launches per
+        # camera and decision (16 small launches per keyframe with the GPU idle behind the keyframe-selection read-back)
+        return torch.stack([self.cameras[k].world_view_transform.transpose(0, 1) for k in idxs])
 
     @staticmethod
     def _shared(vis_a, vis_b):
