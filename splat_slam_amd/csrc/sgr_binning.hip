@@ -50,13 +50,67 @@ __device__ __forceinline__ void file_overfull_runs(char* saved, char* scratch, c
   }
 }
 
-// K2: independent jobs per view, one 1024-thread block each (grid = (3, views)):
+// K2 block 3: the order the tile kernels take the view's 16x16 super tiles in -- LONGEST LISTS FIRST (a counting sort of the super
+// tiles by the pairs on their four 8x8 tiles, 16 pairs per class).  A tile kernel launch is ~12 rounds of resident waves and every
+// wave runs at a fifth of a SIMD: a 250-splat tile that starts in the last round finishes ~100 us after its neighbours, with the
+// chip idle around it.  With the long lists dispatched first the launch ends on its shortest ones.  (Scheduling only: no result
+// depends on it; the order inside a class is whatever the LDS atomics make it.)
+__device__ void order_super_tiles(char* saved, const LOff& L, SavedHeader* hdr) {
+  constexpr int kClasses = 128;
+  __shared__ uint32_t hist[kClasses];
+  unsigned long long* tile_count = (unsigned long long*)(saved + L.o_tile_count);
+  uint32_t* order = (uint32_t*)(saved + L.o_tile_order);
+  const int nsuper = L.sgx * L.sgy;                      // (counter word w = super tile w: ((gy + 1) / 2) x gxp words, gxp == sgx)
+  auto class_of = [&](int w) {
+    const unsigned long long c = tile_count[(size_t)w * (kCntSlotWords / 2)];
+    const uint32_t pairs = (uint32_t)(c & 0xffffu) + (uint32_t)((c >> 16) & 0xffffu) + (uint32_t)((c >> 32) & 0xffffu) + (uint32_t)(c >> 48);
+    const uint32_t k = (pairs + 15u) >> 4;               // 0: no pair at all
+    return (int)(kClasses - 1u - (k < (uint32_t)kClasses - 1u ? k : (uint32_t)kClasses - 1u));     // ascending class = descending length
+  };
+  for (int k = threadIdx.x; k < kClasses; k += 1024) hist[k] = 0u;
+  __syncthreads();
+  constexpr int kKeep = 4;                               // classes kept in registers between the two passes (4096 super tiles = 1024 x 1024 px)
+  int cls[kKeep];
+#pragma unroll
+  for (int r = 0; r < kKeep; ++r) {
+    const int w = (int)threadIdx.x + r * 1024;
+    cls[r] = w < nsuper ? class_of(w) : -1;
+    if (cls[r] >= 0) atomicAdd(&hist[cls[r]], 1u);
+  }
+  for (int w = (int)threadIdx.x + kKeep * 1024; w < nsuper; w += 1024) atomicAdd(&hist[class_of(w)], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) {                                // exclusive scan of the 128 class counts by one wave, two per lane
+    const uint32_t a = hist[2 * threadIdx.x], b = hist[2 * threadIdx.x + 1];
+    const uint32_t inc = wave_scan_add_u32(a + b);
+    hist[2 * threadIdx.x] = inc - a - b;
+    hist[2 * threadIdx.x + 1] = inc - b;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kKeep; ++r) {
+    const int w = (int)threadIdx.x + r * 1024;
+    if (cls[r] >= 0) order[atomicAdd(&hist[cls[r]], 1u)] = (uint32_t)w;
+  }
+  for (int w = (int)threadIdx.x + kKeep * 1024; w < nsuper; w += 1024) order[atomicAdd(&hist[class_of(w)], 1u)] = (uint32_t)w;
+  // both readers are done with the counters (this block: the loop above; block 0: its flag): leave them clean for the next forward.
+  // Block 0 used to, on its critical path; here the stores and the wait hide behind block 0's scan and header.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(&hdr->counts_read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+    __hip_atomic_store(&hdr->counts_read, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < ((L.gy + 1) / 2) * L.gxp; w += 1024) tile_count[(size_t)w * (kCntSlotWords / 2)] = 0ull;
+}
+
+// K2: independent jobs per view, one 1024-thread block each (grid = (3 or 4, views)):
 //   (0) tile starts: ranges[t] = (start, end) of the tile's run; for tiles with more than kBucket pairs .x carries kOverfull.
 //       When no scatter launch follows (`k3_follows` == 0: the caller's measured longest list fits the buckets) this block also
 //       files the overflow list, should there be one after all -- correct for any map, just not parallel;
 //   (1) segment bases of the partial-slot offsets;
 //   (2) the number of visible Gaussians (and the segments' bases in the compact visible list; the list itself is written by the
 //       first blocks of the tile kernel's launch, sgr_blend.hip: nothing before the backward reads it).
+//   (3) the launch order of the super tiles (order_super_tiles above) -- where it is used (tile_order_used, sgr_common.h).
 // The later of blocks 0 and 1 folds the two pair counts into the header.  A map whose lists stay within the buckets (kBucket = 256 since round 6)
 // therefore needs no third binning launch at all.
 __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, int k3_follows) {
@@ -116,8 +170,18 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, in
     saturated = __syncthreads_or((int)saturated) ? 1u : 0u;
     longest = (uint32_t)wave_max_i32((int)longest);
     if ((threadIdx.x & 63) == 0) red_max[threadIdx.x >> 6] = longest;
-    // consumed: leave the counters clean for the next forward
-    for (int w = threadIdx.x; w < ((L.gy + 1) / 2) * L.gxp; w += 1024) tile_count[(size_t)w * (kCntSlotWords / 2)] = 0ull;
+    // consumed (the barrier above is behind every thread's counter reads).  Block 3 reads the counters as well and is the one that
+    // leaves them clean for the next forward -- once it has seen this flag.  (Blocks are dispatched x-fastest: this block is on the chip
+    // before its view's block 3 can be, the wait cannot starve.)
+    // (relaxed on both sides: nothing this block WROTE is read over there, and its counter reads have returned -- their values are in
+    //  the scan above; a release here would write this block's `ranges` back through L2 first)
+    if (tile_order_used(L)) {
+      if (threadIdx.x == 64) __hip_atomic_store(&hdr->counts_read, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {                                       // no block 3 in this launch
+      // (the order array still gets a valid permutation: a later backward of this forward may come with another hint and read it)
+      uint32_t* order = (uint32_t*)(saved + L.o_tile_order);
+      for (int w = threadIdx.x; w < ((L.gy + 1) / 2) * L.gxp; w += 1024) { tile_count[(size_t)w * (kCntSlotWords / 2)] = 0ull; order[w] = (uint32_t)w; }
+    }
     if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = over;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -145,6 +209,9 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(ViewTab tab, LOff L, in
     const uint32_t* bt = (const uint32_t*)(saved + L.o_block_touched);
     const uint32_t slots = block1024_scan([&](int i) { return bt[i]; }, (uint32_t*)(saved + L.o_block_base_t), L.nseg, red);
     if (threadIdx.x == 0) hdr->slot_total = slots;
+  } else if (blockIdx.x == 3) {
+    order_super_tiles(saved, L, hdr);
+    return;
   } else if (blockIdx.x == 2) {
     const uint32_t* bv = (const uint32_t*)(saved + L.o_block_vis);
     uint32_t V = block1024_scan([&](int i) { return bv[i]; }, (uint32_t*)(saved + L.o_block_base_v), L.nseg, red);
@@ -208,7 +275,7 @@ void launch_binning(const ViewTab& tab, int nviews, const LOff& L, hipStream_t s
   const int k3 = (L.N > 0 && (L.mean_hint == 0 || L.mean_hint > kBucket)) ? 1 : 0;
   {
     ProfScope prof(PK_SCAN, st);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(3, nviews), dim3(1024), 0, st, tab, L, k3);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order_used(L) ? 4 : 3, nviews), dim3(1024), 0, st, tab, L, k3);
   }
   if (k3) {
     ProfScope prof(PK_SCATTER, st);

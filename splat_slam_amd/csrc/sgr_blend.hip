@@ -693,15 +693,39 @@ __device__ __forceinline__ void compact_visible_list(char* saved, const LOff& L,
 // Workgroup = ONE wave = one 8x8 tile.  The four waves of a 16x16 super tile used to share a 256-thread workgroup: they never
 // synchronise, but a workgroup's LDS (5 workgroups per CU) is released only when its LAST wave retires, and the four lists of a
 // super tile differ in length -- the counters showed 3.7 resident waves per SIMD on average where the registers allow 5.
-// tile_of_block(): hardware places block b on XCD b % 8; every XCD gets a contiguous run of super tiles and walks it tile by tile, so
-// neighbouring tiles (which share Gaussians) still hit the same 4 MiB L2 at about the same time.
-__device__ __forceinline__ bool tile_of_block(int b, const LOff& L, int& tx, int& ty) {
+// tile_of_block(): hardware places block b on XCD b % 8.  Round 6: the view's super tiles are taken in K2's launch order (longest lists
+// first: order_super_tiles, sgr_binning.hip) and DEALT to the XCDs round robin -- until then every XCD owned a band of the image (a
+// contiguous run of super tiles) and the launch ended when the XCD with the heaviest band did (opaque scene: 0.503 -> 0.484 ms from
+// the dealing alone).  The four tiles of a super tile still run back to back on one XCD (they share most of their Gaussians: single
+// tiles dealt round robin cost +2.5 %).
+// Launch geometry of the tile kernels: grid = (32, rows, views).  x = xcd + 8 * (tile of the super tile); y = rank of the super tile in
+// its XCD's share of the launch order (+ `lead` rows in front: blocks that do something else first, compact_visible_list); z = view.
+// Dispatch is x-fastest, views one after the other.  (Measured and not kept: the views INTERLEAVED -- rank r of every view on the chip
+// before rank r + 1 of any, so that the launch ends on the shortest lists of all views: opaque scene +-0, and with the identity
+// order of a light map +4 % -- the same image region of twelve views then runs at the same time, and sparse regions coincide.)
+struct TileGrid { int view, lead_index; bool is_lead; int k, wv; };
+__device__ __forceinline__ TileGrid tile_grid(int lead_blocks_per_view) {
+  TileGrid g;
+  const int x = blockIdx.x, lead_rows = (lead_blocks_per_view + 31) >> 5;
+  g.view = (int)blockIdx.z;
+  g.is_lead = (int)blockIdx.y < lead_rows;
+  g.lead_index = (int)blockIdx.y * 32 + (x & 31);
+  g.k = ((int)blockIdx.y - lead_rows) * 8 + (x & 7);
+  g.wv = (x >> 3) & 3;
+  return g;
+}
+__host__ inline dim3 tile_grid_dim(const LOff& L, int nviews, int lead_blocks_per_view) {
+  const int rows = (L.sgx * L.sgy + 7) / 8 + (lead_blocks_per_view + 31) / 32;
+  return dim3(32, rows, nviews);
+}
+__device__ __forceinline__ bool tile_of_block(const TileGrid& g, const LOff& L, const char* saved, int& tx, int& ty) {
   // everything here is wave-uniform and must STAY in SGPRs (the tile's coordinates feed most of the kernel's address arithmetic):
   // the division by the super-tile row length is a multiply-high by a host-made reciprocal -- the compiler's integer division goes
   // through the VALU's float reciprocal and left tx / ty (and everything derived from them) in vector registers, ~35 instructions
-  const int sgx = L.sgx, nsuper = L.sgx * L.sgy, per = (nsuper + 7) >> 3;
-  const int j = b >> 3, st = (b & 7) * per + (j >> 2), wv = j & 3;
-  if (st >= nsuper || j >= 4 * per) return false;
+  const int sgx = L.sgx, nsuper = L.sgx * L.sgy;
+  const int k = g.k, wv = g.wv;
+  if (k >= nsuper) return false;
+  const int st = tile_order_used(L) ? __builtin_amdgcn_readfirstlane((int)((const uint32_t*)(saved + L.o_tile_order))[k]) : k;
   // st / sgx  (st * sgx < 2^32; an image of one super-tile column -- W <= 16 -- has no 32-bit reciprocal: 2^32 / 1 + 1 wraps to 1)
   const int row = sgx == 1 ? st : (int)__builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)st, L.sgx_magic));
   const int col = st - row * sgx;
@@ -709,12 +733,12 @@ __device__ __forceinline__ bool tile_of_block(int b, const LOff& L, int& tx, int
   ty = __builtin_amdgcn_readfirstlane(row * 2 + (wv >> 1));
   return true;
 }
-__device__ __forceinline__ int tile_blocks(int sgx, int sgy) { return 8 * 4 * ((sgx * sgy + 7) >> 3); }
 
 template <int SORT_MAX, bool FUSED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TILE_WAVES))) blend_fwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, LossTab lt,
                                                         LossCoef lc) {
-  const int vw = blockIdx.y;
+  const TileGrid tg = tile_grid(comp_blocks(L));
+  const int vw = tg.view;
   char* saved = tab.saved[vw];
   const int H = L.H, W = L.W, gx = L.gx, gy = L.gy;
   const int64_t cap = L.cap;
@@ -731,10 +755,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
   extern __shared__ __attribute__((aligned(16))) char smem[];   // SORT_MAX sorted ids (4 B) or keys (8 B) + 64 splats x kStageBytes (+ FUSED: 2 x 64 float4 of pixel state)
   constexpr bool REGSORT = sort_in_registers(SORT_MAX);
   constexpr size_t kKeyBytes = REGSORT ? 4 : 8;
-  const int ncomp = comp_blocks(L);             // the first blocks of the launch: the view's compact visible list (see above)
-  if ((int)blockIdx.x < ncomp) { compact_visible_list(saved, L, (int)blockIdx.x); return; }
+  // the first rows of the launch: the view's compact visible list (see above)
+  if (tg.is_lead) { if (tg.lead_index < comp_blocks(L)) compact_visible_list(saved, L, tg.lead_index); return; }
   int tx, ty;
-  if (!tile_of_block((int)blockIdx.x - ncomp, L, tx, ty)) return;
+  if (!tile_of_block(tg, L, saved, tx, ty)) return;
   const int lane = threadIdx.x;
   constexpr int kLdsSortMax = SORT_MAX;
   char* slice = smem;
@@ -1054,7 +1078,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_TIL
 
 template <bool PACKED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES))) blend_bwd_kernel(ViewTab tab, LOff L, const float* __restrict__ bg, SignGrad sg) {
-  const int vw = blockIdx.y;
+  const TileGrid tg = tile_grid(0);
+  const int vw = tg.view;
   const char* saved = tab.saved[vw];
   const int H = L.H, W = L.W, gx = L.gx, gy = L.gy;
   const int64_t cap = L.cap;
@@ -1068,7 +1093,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_BWD
   float4* __restrict__ partials = (float4*)(tab.scratch[vw] + L.o_partials);
   __shared__ float4 pixbuf[2][kWave];         // pixel gradients + running (T, S) carries
   int tx, ty;
-  if (!tile_of_block((int)blockIdx.x, L, tx, ty)) return;
+  if (!tile_of_block(tg, L, saved, tx, ty)) return;
   const int lane = threadIdx.x;
   if (tx >= gx || ty >= gy) return;
   const int tile = ty * gx + tx;
@@ -1120,14 +1145,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_BWD
 template <int SORT_MAX, bool FUSED>
 static void launch_blend_fwd_t(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab& lt,
                                const LossCoef& lc, hipStream_t st) {
-  int grid = 8 * 4 * ((L.sgx * L.sgy + 7) / 8) + ((((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7);
+  const dim3 grid = tile_grid_dim(L, nviews, (((L.nseg + kCompSegs - 1) / kCompSegs) + 7) & ~7);
   constexpr size_t lds = (size_t)SORT_MAX * (sort_in_registers(SORT_MAX) ? 4 : 8) + kWave * kStageBytes + (FUSED ? 2 * kWave * 16 : 0);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute((const void*)blend_fwd_kernel<SORT_MAX, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((blend_fwd_kernel<SORT_MAX, FUSED>), dim3(grid, nviews), dim3(kWave), lds, st, tab, L, bg, lt, lc);
+  hipLaunchKernelGGL((blend_fwd_kernel<SORT_MAX, FUSED>), grid, dim3(kWave), lds, st, tab, L, bg, lt, lc);
 }
 
 // 0 light / 1 mid / 2 heavy from the longest list the caller has MEASURED for the cameras of the batch (max_list_hint =
@@ -1172,15 +1197,15 @@ void launch_blend_fused(const ViewTab& tab, int nviews, const LOff& L, const flo
 // lt / lc given: the pixel gradients are the code bytes blend_fwd's loss epilogue wrote for these views
 void launch_blend_bwd(const ViewTab& tab, int nviews, const LOff& L, const float* bg, const LossTab* lt, const LossCoef* lc,
                       hipStream_t st) {
-  int grid = 8 * 4 * ((L.sgx * L.sgy + 7) / 8);
+  const dim3 grid = tile_grid_dim(L, nviews, 0);
   ProfScope prof(PK_BLEND_BWD, st);
   SignGrad sg = {};
   if (lt && lc) {
     for (int v = 0; v < nviews; ++v) sg.exp_a[v] = lt->exp_a[v];
     sg.w_rgb = lc->w_rgb; sg.w_dep = lc->w_dep;
-    hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid, nviews), dim3(kWave), 0, st, tab, L, bg, sg);
+    hipLaunchKernelGGL(blend_bwd_kernel<true>, grid, dim3(kWave), 0, st, tab, L, bg, sg);
   } else {
-    hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid, nviews), dim3(kWave), 0, st, tab, L, bg, sg);
+    hipLaunchKernelGGL(blend_bwd_kernel<false>, grid, dim3(kWave), 0, st, tab, L, bg, sg);
   }
 }
 

@@ -137,7 +137,8 @@ struct SavedHeader {
   // remembers the count it saw at its previous check: a changed count = some forward since then was truncated.
   uint32_t overflow_events;   // forwards of this workspace whose `overflow` came out non-zero
   uint32_t max_rendered;      // largest num_rendered of any forward of this workspace (what a replay sizes the capacity by)
-  uint32_t pad[2];
+  uint32_t counts_read;    // K2: block 0 (tile starts) tells block 3 (launch order), which zeroes the tile counters, that it has read them
+  uint32_t pad;
 };
 static_assert(sizeof(SavedHeader) == 64, "the header is one 64-byte record (sgr_query_header copies 16 words)");
 
@@ -172,9 +173,17 @@ struct LOff {
   __host__ void set_hint(int h) { mean_hint = h; k1_parts = k1_parts_for(nseg, h); }
   int64_t cap;
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
-      o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
+      o_tile_maxc, o_final_T, o_tile_order, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
       o_seg_list, o_vismask, o_entries, o_bucket, o_ovf, o_partials, o_tau_part, o_gradrec, o_taurec;
 };
+// Longest-first launch order of the super tiles (K2 block 3 -> tile_of_block): worth its microsecond of K2 and the extra dependent
+// load in every tile wave's prologue where lists are long enough for a late heavy tile to hold the launch up (opaque scene: tile
+// kernel -5 %; a map whose measured lists stay within 64 splats: +1 us of K2 and +0.7 us of tile kernel for nothing).  A function of
+// the CALL (the caller's measured longest list; unknown = ordered), like every other build choice.
+#ifndef SGR_TILE_ORDER_MIN_LIST
+#define SGR_TILE_ORDER_MIN_LIST 64
+#endif
+__host__ __device__ inline bool tile_order_used(const LOff& L) { return !(L.mean_hint != 0 && L.mean_hint <= SGR_TILE_ORDER_MIN_LIST); }
 // one pair that did not fit its tile's bucket: K1 knows its tile and its rank inside the tile (the counting atomic returned it)
 // but not yet where the tile's run starts -- K3 files it at start(tile) + rank once K2 has scanned the counts
 struct __attribute__((aligned(16))) OvfEntry { uint32_t tile, rank; uint64_t key; };
@@ -221,7 +230,7 @@ struct Layout {
   int tile_bits;
   // saved
   size_t o_hdr, o_tile_count, o_grec, o_point_list, o_ranges,
-      o_tile_maxc, o_final_T, o_n_contrib, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
+      o_tile_maxc, o_final_T, o_tile_order, o_block_touched, o_block_vis, o_block_base_t, o_block_base_v, o_vis_list,
       o_seg_list, o_vismask, saved_bytes, zero_bytes;
   // scratch (forward)
   size_t o_entries, o_bucket, o_ovf;
@@ -251,7 +260,8 @@ struct Layout {
     o_ranges = take((size_t)ntiles * 8 * kRngStride);
     o_tile_maxc = take((size_t)ntiles * 4);
     o_final_T = take((size_t)ntiles * 64 * 8);   // per pixel (final T, last contributor), TILE-major: a wave's 64 pixels are 512 contiguous bytes
-    o_n_contrib = take(16);                      // (folded into o_final_T)
+    o_tile_order = take((size_t)sgx * sgy * 4 + 16);   // the launch order of the view's super tiles: longest lists first (K2 writes it, every tile
+                                                       // kernel of this forward AND its backward reads it: tile_of_block, sgr_blend.hip)
     o_block_touched = take(nb * 4);
     o_block_vis = take(nb * 4);
     o_block_base_t = take(nb * 4);
@@ -280,7 +290,7 @@ struct Layout {
     d.cap = cap;
     d.o_hdr = o_hdr; d.o_tile_count = o_tile_count; d.o_grec = o_grec;
     d.o_point_list = o_point_list; d.o_ranges = o_ranges; d.o_tile_maxc = o_tile_maxc; d.o_final_T = o_final_T;
-    d.o_n_contrib = o_n_contrib; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
+    d.o_tile_order = o_tile_order; d.o_block_touched = o_block_touched; d.o_block_vis = o_block_vis;
     d.o_block_base_t = o_block_base_t; d.o_block_base_v = o_block_base_v; d.o_vis_list = o_vis_list;
     d.o_seg_list = o_seg_list; d.o_vismask = o_vismask; d.o_entries = o_entries; d.o_bucket = o_bucket; d.o_ovf = o_ovf; d.o_partials = o_partials; d.o_tau_part = o_tau_part;
     d.o_gradrec = o_gradrec; d.o_taurec = o_taurec;

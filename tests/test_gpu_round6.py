@@ -235,3 +235,47 @@ def test_a_forward_that_overflows_in_the_middle_of_a_span_is_replayed():
     for k in ample:
         assert torch.equal(ample[k], tight[k]), k
     assert f.check_overflow() == []
+
+
+def test_the_launch_order_of_the_tiles_is_scheduling_only():
+    """Round 6: the tile kernels take a view's super tiles longest lists first (K2 block 3 writes the order, sgr_binning.hip
+    order_super_tiles; tile_of_block reads it) unless the caller's measured longest list says the map is light (<= 64: identity
+    order, K2 keeps its three blocks and its tile-start block cleans the pair counters itself).  Which of the two a launch takes is
+    a function of the hint alone and must not show in a single bit: two iterations (the second one runs on the counters the first
+    one's K2 left behind) under hint 0 (unknown: ordered), 40 (identity -- on a map whose lists are in fact longer) and 200."""
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    from test_gpu_fused import _loop
+    intr = syn.INTRINSICS["replica"]
+    params = syn.room_parameters(120000, seed=12, device=DEV)
+    params["scaling"] = params["scaling"] + 1.8
+    cams = syn.make_views(params, 5, intr, DEV, seed=12)
+    res = []
+    for hint in (0, 40, 200):
+        f = _loop(FusedMappingLoop, syn, params, cams, range(5))
+        f._ensure_state()
+        f._activate()
+        f._run_views(cams, stats=True)                                  # sizes the workspaces (probe renders)
+        torch.cuda.synchronize()
+        longest = f._max_list()
+        f._list_hint = {c.uid: hint for c in cams} if hint else {}
+        f._views_dirty()
+        out = {}
+        for it in range(2):
+            f._acc["flat"].zero_()
+            f._acc_clean = True
+            f._run_views(cams, stats=False)
+            torch.cuda.synchronize()
+            out["flat%d" % it] = f._acc["flat"].clone()
+        assert f._max_list() == hint
+        out.update(radii=torch.stack([f._views[c.uid].radii for c in cams]).clone(),
+                   nt=torch.stack([f._views[c.uid].n_touched for c in cams]).clone(),
+                   loss=torch.cat([f._views[c.uid].loss for c in cams]).clone(),
+                   img=torch.stack([f._views[c.uid].color for c in cams]).clone())
+        res.append(out)
+    assert longest > 64, longest                                        # (hint 40 understates this map: correct anyway)
+    for other in res[1:]:
+        for k in res[0]:
+            assert torch.equal(res[0][k], other[k]), k
+    assert torch.equal(res[0]["flat0"], res[0]["flat1"])                # same parameters, same counters: same gradients
+    assert int((res[0]["radii"] > 0).sum()) > 5000 and float(res[0]["flat0"].abs().max()) > 0
