@@ -12,7 +12,7 @@ B = bench.Bench(bench.parse())
 out = {"lib": "$lib"}
 for name, sa in (("light", 0.0), ("opaque", 1.6)):
     r = B.scene_leg(sa, steps=60)
-    out[name] = [r["ms_per_step"], r["kernel_ms"]["tile_scan"], r["kernel_ms"]["blend_fused_fwd_loss_bwd"]]
+    out[name] = [r["ms_per_step"]] + [round(v, 5) for v in r["kernel_ms"].values()]
 print(json.dumps(out))
 PY
  done

@@ -724,8 +724,17 @@ __device__ __forceinline__ bool tile_of_block(const TileGrid& g, const LOff& L, 
   // through the VALU's float reciprocal and left tx / ty (and everything derived from them) in vector registers, ~35 instructions
   const int sgx = L.sgx, nsuper = L.sgx * L.sgy;
   const int k = g.k, wv = g.wv;
-  if (k >= nsuper) return false;
-  const int st = tile_order_used(L) ? __builtin_amdgcn_readfirstlane((int)((const uint32_t*)(saved + L.o_tile_order))[k]) : k;
+  int st;
+  if (tile_order_used(L)) {
+    if (k >= nsuper) return false;
+    st = __builtin_amdgcn_readfirstlane((int)((const uint32_t*)(saved + L.o_tile_order))[k]);
+  } else {
+    // a light map (no launch order): every XCD keeps a BAND of the image, as in rounds 1-5 -- neighbouring tiles write neighbouring
+    // partial slots of the Gaussians they share, and dealt to different XCDs those 48-byte slots share cache lines across L2s: the
+    // dense backward that reads them took +3.5 us (light scene) with nothing gained in the tile kernel
+    st = (k & 7) * ((nsuper + 7) >> 3) + (k >> 3);
+    if (st >= nsuper) return false;
+  }
   // st / sgx  (st * sgx < 2^32; an image of one super-tile column -- W <= 16 -- has no 32-bit reciprocal: 2^32 / 1 + 1 wraps to 1)
   const int row = sgx == 1 ? st : (int)__builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)st, L.sgx_magic));
   const int col = st - row * sgx;
