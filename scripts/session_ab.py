@@ -22,7 +22,8 @@ CHILD = ("import json, sys; sys.path.insert(0, %r); import bench; sys.argv=['ben
 VARIANTS = {"round4_host_path": {"SPLAT_SPAN_CACHE": "0", "SPLAT_VERIFY_ESTIMATES": "1"},
             "span_cache_only": {"SPLAT_SPAN_CACHE": "1", "SPLAT_VERIFY_ESTIMATES": "1"},
             "no_verify_only": {"SPLAT_SPAN_CACHE": "0", "SPLAT_VERIFY_ESTIMATES": "0"},
-            "round5_default": {"SPLAT_KEYFRAME_STRUCTS": "0"},
+            "round5_default": {"SPLAT_KEYFRAME_STRUCTS": "0", "SPLAT_SNAPSHOT_STORE": "0"},
+            "no_snapshot_store": {"SPLAT_SNAPSHOT_STORE": "0"},
             "round6_default": {}}
 if a.only:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in a.only.split(",")}

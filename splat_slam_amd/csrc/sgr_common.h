@@ -40,8 +40,11 @@ constexpr int kK1MaxParts = 4;
 #ifndef SGR_K1_DENSE_PARTS
 #define SGR_K1_DENSE_PARTS 2
 #endif
+#ifndef SGR_K1_LARGE_PARTS
+#define SGR_K1_LARGE_PARTS 1
+#endif
 __host__ __device__ inline int k1_parts_for(int nseg, int longest_list_hint = 0) {
-  return nseg >= 768 ? ((longest_list_hint > 64 && nseg < 2048) ? SGR_K1_DENSE_PARTS : 1) : (nseg >= 384 ? 2 : kK1MaxParts);
+  return nseg >= 768 ? ((longest_list_hint > 64 && nseg < 2048) ? SGR_K1_DENSE_PARTS : SGR_K1_LARGE_PARTS) : (nseg >= 384 ? 2 : kK1MaxParts);
 }
 constexpr int kRngStride = 2;          // uint2 units between two tiles' (start, cursor) ranges
 // Binning fast path: the counting atomic of K1 RETURNS the pair's rank inside its tile, and while the tile has room the

@@ -281,7 +281,9 @@ class FusedMappingLoop(MappingLoop):
         self._span_cache = None    # (window, pool) SgrMapView arrays of the spans of one map() call (_span_arrays)
         self.cache_span_arrays = os.environ.get("SPLAT_SPAN_CACHE", "1") != "0"      # (0: A/B measurements of the host path)
         self.keep_structs_over_keyframes = os.environ.get("SPLAT_KEYFRAME_STRUCTS", "1") != "0"   # (0: round-5 behaviour, for A/B)
+        self.snapshot_store = os.environ.get("SPLAT_SNAPSHOT_STORE", "1") != "0"                  # (0: a fresh buffer per tensor and map size, for A/B)
         self._txn_pool = None      # snapshot buffers, reused while the tensor shapes stay
+        self._txn_store = None     # ... the byte store they are views of (kept with head-room across map sizes)
         self._replaying = False
         self.replayed_transactions = 0
         self._hdr_pinned = None
@@ -1302,6 +1304,22 @@ class FusedMappingLoop(MappingLoop):
             ts += [e.param, e.grad, e.m, e.v, e.step, e.stale]
         return ts
 
+    def _snapshot_buffers(self, ts):
+        """One buffer per tensor of `ts`: views of ONE byte store that is kept with head-room.  The map changes size at every keyframe
+        (new Gaussians, prune passes), and eighteen torch.empty_like of never-seen sizes were eighteen allocator misses -- 1.5 ms per
+        snapshot, two or three snapshots per keyframe with the GPU idle behind them (scripts/micro/txn_begin_parts.py: 4 ms per
+        keyframe of a young session)."""
+        if not self.snapshot_store:
+            return [torch.empty_like(t) for t in ts]
+        offs, need = [], 0
+        for t in ts:
+            offs.append(need)
+            need += (t.numel() * t.element_size() + 255) // 256 * 256
+        if self._txn_store is None or self._txn_store.numel() < need:
+            self._txn_store = self._txn_pool = None          # (freed first: the allocator may hand the block back for the larger one)
+            self._txn_store = torch.empty(int(need * 1.5) + (1 << 20), dtype=torch.uint8, device=self.device)
+        return [self._txn_store[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(offs, ts)]
+
     def _txn_begin(self):
         """Opens a transaction in front of the first state-changing launch after a check (no-op while one is open)."""
         if self._txn is not None or self._replaying:
@@ -1315,7 +1333,7 @@ class FusedMappingLoop(MappingLoop):
             ts.append(self._acc["flat"])
         pool = self._txn_pool
         if pool is None or len(pool) != len(ts) or any(b.shape != t.shape or b.dtype != t.dtype for b, t in zip(pool, ts)):
-            pool = self._txn_pool = [torch.empty_like(t) for t in ts]
+            pool = self._txn_pool = self._snapshot_buffers(ts)
         with torch.no_grad():
             for dt in {t.dtype for t in ts}:
                 torch._foreach_copy_([b for b, t in zip(pool, ts) if t.dtype == dt], [t for t in ts if t.dtype == dt])
