@@ -200,7 +200,8 @@ int sgr_query(const void* saved, int64_t* num_rendered_host, int32_t* overflow_h
  * than 64 pairs, [5..8] internal, [9] pairs actually binned, [10] longest per-tile list, [11] internal, [12] STICKY: number of
  * forwards of this workspace whose overflow flag came out non-zero since the block's counters were last zeroed (counters_clean = 0),
  * [13] STICKY: the largest [0] of any of those forwards -- [1] only describes the LAST forward, and a span of sgr_map_run puts dozens
- * of forwards through one workspace between two host checks -- [14..15] zero. */
+ * of forwards through one workspace between two host checks -- [14] internal (a flag between two blocks of the binning kernel: zero
+ * whenever no forward is running), [15] zero. */
 int sgr_query_header(const void* saved, uint32_t words_host[16], void* stream);
 
 /* Asynchronous variant: enqueues a 64-byte copy of the same header into PINNED host memory on `stream`.
