@@ -279,3 +279,36 @@ def test_the_launch_order_of_the_tiles_is_scheduling_only():
             assert torch.equal(res[0][k], other[k]), k
     assert torch.equal(res[0]["flat0"], res[0]["flat1"])                # same parameters, same counters: same gradients
     assert int((res[0]["radii"] > 0).sum()) > 5000 and float(res[0]["flat0"].abs().max()) > 0
+
+
+def test_the_launch_order_covers_an_image_of_more_than_4096_super_tiles():
+    """order_super_tiles keeps the classes of the first 4096 super tiles in registers between its two passes and re-reads the counters
+    for the rest: a 2048x1152 view has 9216.  The ordered launch (hint 0) must render and differentiate every tile exactly like the
+    band mapping of a light map (hint 40) does -- a hole or a duplicate in the order would be missing / doubled tiles."""
+    from splat_slam_amd import synthetic as syn
+    from splat_slam_amd.fused import FusedMappingLoop
+    from test_gpu_fused import _loop
+    intr = dict(W=2048, H=1152, fx=1100.0, fy=1100.0, cx=1023.5, cy=575.5)
+    params = syn.room_parameters(40000, seed=14, device=DEV)
+    params["scaling"] = params["scaling"] + 0.8
+    cams = syn.make_views(params, 2, intr, DEV, seed=14)
+    res = []
+    for hint in (0, 40):
+        f = _loop(FusedMappingLoop, syn, params, cams, range(2))
+        f._ensure_state()
+        f._activate()
+        f._run_views(cams, stats=True)
+        torch.cuda.synchronize()
+        f._list_hint = {c.uid: hint for c in cams} if hint else {}
+        f._views_dirty()
+        f._acc["flat"].zero_()
+        f._acc_clean = True
+        f._run_views(cams, stats=False)
+        torch.cuda.synchronize()
+        res.append(dict(flat=f._acc["flat"].clone(), nt=torch.stack([f._views[c.uid].n_touched for c in cams]).clone(),
+                        loss=torch.cat([f._views[c.uid].loss for c in cams]).clone(),
+                        img=torch.stack([f._views[c.uid].color for c in cams]).clone()))
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    img = res[0]["img"]
+    assert float((img.sum(dim=1) > 0).float().mean()) > 0.5 and float(res[0]["flat"].abs().max()) > 0
